@@ -1,0 +1,538 @@
+"""CPU oracle for the VQA fusion-model hot path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for
+this path and its arithmetic lives in
+tensorflow-gpu==1.6.0 (requirements.txt:1), which is not installable here.
+This file is therefore a NumPy restatement of the reference's graph code plus
+the published TF-1.6 op semantics it calls; it is pinned only by (i) the
+known-answer tests in tests/test_oracle_known_answers.py, (ii) an independent
+torch-autograd restatement (oracle/torch_ref.py) and (iii) central finite
+differences in float64.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product path (vqa-transfer-externaldata_amd/) never does.
+
+Reference lines restated (paths relative to /root/reference):
+  * feature gather            vqa/model_vlmap_answer.py:110-123
+  * fc_layer (FC -> LN -> act) vlmap/modules.py:630-650
+  * embedding lookup          vqa/model_vlmap_answer.py:134, vlmap/modules.py:415-448
+  * encode_L (GRU)            vlmap/modules.py:124-140
+  * hadamard_attention        vlmap/modules.py:67-97
+  * attention_pooling         vlmap/modules.py:23-39
+  * fusion MLP + head         vqa/model_vlmap_answer.py:163-187 (WordWeightAnswer
+                              vlmap/modules.py:589-627); vqa/model_standard.py:251-275
+  * loss + report             vqa/model_vlmap_answer.py:192-288; vqa/model_standard.py:281-374
+  * optimiser                 vqa/trainer.py:87-114 (optimize_loss: global-norm
+                              clip 20.0 then Adam)
+TF semantics followed: SURVEY.md section 5.2 items 1-9.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LN_EPS = 1e-12          # tf.contrib.layers.layer_norm -> nn.batch_normalization(variance_epsilon=1e-12)
+KEEP_ATT = 0.8          # vlmap/modules.py:82
+KEEP_JOINT = 0.5        # vqa/model_vlmap_answer.py:180
+CLIP_NORM = 20.0        # vqa/trainer.py:111
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults
+
+# Variable names = the checkpoint / transfer contract.
+FC_LN_SCOPES_VLMAP = ["v_linear_v", "q_linear_v", "pooled_linear_l", "q_linear_l", "joint_fc"]
+FROZEN_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer")
+TRANSFER_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc")
+
+REPORT_KEYS = [
+    "answer_train_loss", "answer_report_loss", "answer_acc", "exist_acc", "test_acc",
+    "normal_test_acc", "normal_test_object_acc", "normal_test_attribute_acc",
+    "normal_exist_acc", "normal_train_exist_acc", "max_exist_acc", "test_max_acc",
+    "test_max_exist_acc",
+]
+
+
+def scope_names(model_type: str) -> dict:
+    """Maps logical layer -> TF variable scope for the two models.
+
+    vqa/model_vlmap_answer.py:126-185 vs vqa/model_standard.py:223-275 (the
+    latter nests the fusion MLP under 'reasoning/' and uses a plain
+    'classifier' fc_layer as head).
+    """
+    if model_type == "vlmap_answer":
+        pre = ""
+        head = "WordWeightAnswer"
+    elif model_type == "standard":
+        pre = "reasoning/"
+        head = "reasoning/classifier"
+    else:
+        raise ValueError("unknown model_type %r" % (model_type,))
+    return {
+        "embed": "LearnGloVe/embed_map",
+        "v_linear_v": "v_linear_v",
+        "gru_gates": "encode_L/rnn/gru_cell/gates",
+        "gru_cand": "encode_L/rnn/gru_cell/candidate",
+        "q_linear_v": "q_linear_v",
+        "score": "hadamard_attention/compute/score",
+        "pooled_linear_l": pre + "pooled_linear_l",
+        "q_linear_l": pre + "q_linear_l",
+        "joint_fc": pre + "joint_fc",
+        "head": head,
+    }
+
+
+def train_var_names(params: dict, model_type: str) -> list:
+    """filter_train_vars: vqa/model_vlmap_answer.py:81-89, vqa/model_standard.py:80-84."""
+    names = sorted(params.keys())
+    if model_type == "standard":
+        return names
+    return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
+
+
+def transfer_var_names(params: dict, model_type: str) -> list:
+    """filter_transfer_vars: vqa/model_vlmap_answer.py:91-100 (standard: :86-93)."""
+    names = sorted(params.keys())
+    if model_type == "standard":
+        return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
+    return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
+
+
+# ----------------------------------------------------------------------------
+# parameter initialisation
+# ----------------------------------------------------------------------------
+def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=3000,
+                dtype=np.float32, head="random"):
+    """Random-init weights of the reference architecture.
+
+    layers.fully_connected: Xavier-uniform weights, zero bias; layer_norm: beta 0,
+    gamma 1; GRUCell: gates bias 1.0, candidate bias 0 (tf.contrib.rnn.GRUCell);
+    embeddings small uniform (GloVe files are not available offline).
+    head='random' Xavier head; head='untrained' reproduces WordWeightAnswer with
+    word_weight_dir=None (weights 0, bias -100: vlmap/modules.py:601-602).
+    """
+    sc = scope_names(model_type)
+    p = {}
+
+    def xavier(fan_in, fan_out):
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(dtype)
+
+    def fc(scope, fin, fout, ln):
+        p[scope + "/fc/weights"] = xavier(fin, fout)
+        p[scope + "/fc/biases"] = np.zeros(fout, dtype)
+        if ln:
+            p[scope + "/LayerNorm/beta"] = np.zeros(fout, dtype)
+            p[scope + "/LayerNorm/gamma"] = np.ones(fout, dtype)
+
+    p[sc["embed"]] = rng.uniform(-0.01, 0.01, size=(Vq, W)).astype(dtype)
+    fc(sc["v_linear_v"], D, H, True)
+    p[sc["gru_gates"] + "/kernel"] = xavier(W + H, 2 * H)
+    p[sc["gru_gates"] + "/bias"] = np.ones(2 * H, dtype)
+    p[sc["gru_cand"] + "/kernel"] = xavier(W + H, H)
+    p[sc["gru_cand"] + "/bias"] = np.zeros(H, dtype)
+    fc(sc["q_linear_v"], H, H, True)
+    fc(sc["score"], H, 1, False)
+    fc(sc["pooled_linear_l"], D, H, True)
+    fc(sc["q_linear_l"], H, H, True)
+    fc(sc["joint_fc"], H, 2 * H, True)
+    if head == "untrained":
+        p[sc["head"] + "/fc/weights"] = np.zeros((2 * H, A), dtype)
+        p[sc["head"] + "/fc/biases"] = np.full(A, -100.0, dtype)
+    else:
+        fc(sc["head"], 2 * H, A, False)
+    return p
+
+
+def perturb_ln_params(params, rng, scale=0.1):
+    """Make LN beta/gamma and biases non-trivial so parity tests exercise them."""
+    for k in params:
+        if k.endswith("LayerNorm/beta") or k.endswith("/biases"):
+            params[k] = (params[k] + scale * rng.standard_normal(params[k].shape)).astype(params[k].dtype)
+        elif k.endswith("LayerNorm/gamma"):
+            params[k] = (params[k] + scale * rng.standard_normal(params[k].shape)).astype(params[k].dtype)
+    return params
+
+
+# ----------------------------------------------------------------------------
+# primitive forward ops
+# ----------------------------------------------------------------------------
+def sigmoid(x):
+    # numerically stable logistic, same value as tf.sigmoid to rounding
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = 1.0 / (1.0 + np.exp(-x[pos]))
+    e = np.exp(x[~pos])
+    out[~pos] = e / (1.0 + e)
+    return out
+
+
+def fc_forward(x, W, b):
+    """layers.fully_connected on the last axis."""
+    return x @ W + b
+
+
+def layer_norm_forward(x, gamma, beta):
+    """tf.contrib.layers.layer_norm defaults: statistics over ALL
+    axes except 0, gamma/beta on the last axis, biased variance, eps 1e-12."""
+    axes = tuple(range(1, x.ndim))
+    mu = x.mean(axis=axes, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=axes, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + x.dtype.type(LN_EPS))
+    xhat = (x - mu) * rstd
+    return xhat * gamma + beta, xhat, rstd
+
+
+def fc_ln_relu_forward(x, params, scope):
+    """modules.fc_layer(use_bias, use_ln, relu): vlmap/modules.py:630-650."""
+    pre = fc_forward(x, params[scope + "/fc/weights"], params[scope + "/fc/biases"])
+    ln, xhat, rstd = layer_norm_forward(pre, params[scope + "/LayerNorm/gamma"],
+                                        params[scope + "/LayerNorm/beta"])
+    y = np.maximum(ln, 0)
+    return y, (x, pre, xhat, rstd, ln)
+
+
+def gru_forward(x, lens, Wg, bg, Wc, bc):
+    """tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn(sequence_length).
+
+    x [B,T,W]; returns final state [B,H] and the per-step tape for backward.
+    r,u = split(sigmoid([x,h]Wg+bg)) with r FIRST; c = tanh([x, r*h]Wc+bc);
+    h' = u*h + (1-u)*c; for t >= len the state is copied through.
+    """
+    B, T, Wd = x.shape
+    H = Wc.shape[1]
+    h = np.zeros((B, H), x.dtype)
+    tape = []
+    for t in range(T):
+        xt = x[:, t, :]
+        g = sigmoid(np.concatenate([xt, h], axis=1) @ Wg + bg)
+        r, u = g[:, :H], g[:, H:]
+        rh = r * h
+        c = np.tanh(np.concatenate([xt, rh], axis=1) @ Wc + bc)
+        hn = u * h + (1 - u) * c
+        live = (t < lens)[:, None]
+        hn = np.where(live, hn, h)
+        tape.append((xt, h, r, u, c, live))
+        h = hn
+    return h, tape
+
+
+def hadamard_attention_forward(v, nbox, qv, w, b, mask_att):
+    """vlmap/modules.py:67-97.  mask_att is the explicit Bernoulli(keep=.8)
+    0/1 mask replacing tf.nn.dropout's internal RNG."""
+    dt = v.dtype.type
+    feat = v * qv[:, None, :]
+    feat = feat * mask_att * dt(1.0 / KEEP_ATT)
+    s = feat @ w[:, 0] + b[0]                      # [B,R]
+    R = v.shape[1]
+    valid = np.arange(R)[None, :] < nbox[:, None]   # tf.sequence_mask
+    s = np.where(valid, s, dt(-np.inf))
+    with np.errstate(invalid="ignore"):
+        m = s.max(axis=1, keepdims=True)
+        e = np.exp(s - m)
+        att = e / e.sum(axis=1, keepdims=True)      # nbox == 0 -> NaN row, as TF
+    return att, feat
+
+
+def sigmoid_ce(z, t):
+    """tf.nn.sigmoid_cross_entropy_with_logits."""
+    return np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z)))
+
+
+def _guarded_ratio(num, den):
+    # tf.where(tf.equal(den, 0), den, num / den)
+    return den if den == 0 else num / den
+
+
+def loss_and_report(z, tgt, answer_masks, model_type):
+    """vqa/model_vlmap_answer.py:192-288 / vqa/model_standard.py:281-374.
+
+    answer_masks: dict of float [A] arrays: train, obj, attr, exist.
+    """
+    dt = z.dtype.type
+    train = answer_masks["train"]
+    test = dt(1) - train
+    obj, attr, exist = answer_masks["obj"], answer_masks["attr"], answer_masks["exist"]
+    ell = sigmoid_ce(z, tgt)
+    report_loss = ell.sum(axis=1).mean()
+    if model_type == "vlmap_answer":
+        train_loss = (ell * train).sum(axis=1).mean()
+    else:
+        train_loss = report_loss
+    pred = np.argmax(z, axis=1).astype(np.int32)        # first max
+    B = z.shape[0]
+    tp = tgt[np.arange(B), pred]                         # one_hot(pred) * target, summed
+
+    def at_pred(mask):
+        return tp * mask[pred]
+
+    out = {
+        "pred": pred,
+        "all_score": tp,
+        "max_train_score": (tgt * train).max(axis=1),
+        "test_obj_score": at_pred(test * obj),
+        "test_obj_max_score": (tgt * test * obj).max(axis=1),
+        "test_attr_score": at_pred(test * attr),
+        "test_attr_max_score": (tgt * test * attr).max(axis=1),
+    }
+    acc = tp.mean()
+    exist_acc = at_pred(exist).mean()
+    test_acc = at_pred(test).mean()
+    test_obj_acc = out["test_obj_score"].mean()
+    test_attr_acc = out["test_attr_score"].mean()
+    train_exist_acc = at_pred(exist * train).mean()
+    max_exist = (tgt * exist).max(axis=1).mean()
+    max_train_exist = (tgt * exist * train).max(axis=1).mean()
+    test_obj_max = out["test_obj_max_score"].mean()
+    test_attr_max = out["test_attr_max_score"].mean()
+    test_max = (tgt * test).max(axis=1).mean()
+    test_max_exist = (tgt * exist * test).max(axis=1).mean()
+    report = {
+        "answer_train_loss": train_loss,
+        "answer_report_loss": report_loss,
+        "answer_acc": acc,
+        "exist_acc": exist_acc,
+        "test_acc": test_acc,
+        "normal_test_acc": _guarded_ratio(test_acc, test_max),
+        "normal_test_object_acc": _guarded_ratio(test_obj_acc, test_obj_max),
+        "normal_test_attribute_acc": _guarded_ratio(test_attr_acc, test_attr_max),
+        "normal_exist_acc": _guarded_ratio(exist_acc, max_exist),
+        "normal_train_exist_acc": _guarded_ratio(train_exist_acc, max_train_exist),
+        "max_exist_acc": max_exist,
+        "test_max_acc": test_max,
+        "test_max_exist_acc": test_max_exist,
+    }
+    return train_loss, report, out, ell
+
+
+# ----------------------------------------------------------------------------
+# full forward
+# ----------------------------------------------------------------------------
+def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_answer"):
+    """Forward of model_vlmap_answer / model_standard.
+
+    batch: dict image_idx i64[B], q_intseq i32[B,T], q_intseq_len i32[B],
+           answer_target f[B,A]  (vqa/datasets/input_ops_vqa_tf_record_memft.py:47-71)
+    table f[N,R,D], nbox_table i[N]; masks: {'att': 0/1 [B,R,H], 'joint': 0/1 [B,2H]}.
+    Returns (loss, report, output, mid, tape).
+    """
+    sc = scope_names(model_type)
+    dt = table.dtype.type
+    idx = batch["image_idx"]
+    V = np.take(table, idx, axis=0)                                   # a1
+    nb = np.take(nbox_table, idx, axis=0)
+    v, t_v = fc_ln_relu_forward(V, params, sc["v_linear_v"])           # a2
+    e = params[sc["embed"]][batch["q_intseq"]]                          # a3
+    h, t_gru = gru_forward(e, batch["q_intseq_len"],                    # a4
+                           params[sc["gru_gates"] + "/kernel"], params[sc["gru_gates"] + "/bias"],
+                           params[sc["gru_cand"] + "/kernel"], params[sc["gru_cand"] + "/bias"])
+    qv, t_qv = fc_ln_relu_forward(h, params, sc["q_linear_v"])          # a5
+    att, feat = hadamard_attention_forward(                              # a6
+        v, nb, qv, params[sc["score"] + "/fc/weights"], params[sc["score"] + "/fc/biases"],
+        masks["att"])
+    p = np.einsum("br,brd->bd", att, V)                                  # a7
+    pl, t_pl = fc_ln_relu_forward(p, params, sc["pooled_linear_l"])      # a8
+    ll, t_ll = fc_ln_relu_forward(h, params, sc["q_linear_l"])
+    jin = pl * ll
+    j0, t_j = fc_ln_relu_forward(jin, params, sc["joint_fc"])            # a9
+    j = j0 * masks["joint"] * dt(1.0 / KEEP_JOINT)
+    z = fc_forward(j, params[sc["head"] + "/fc/weights"], params[sc["head"] + "/fc/biases"])  # a10
+    loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)  # a11
+    out["att_score"] = att
+    out["logit"] = z
+    mid = {"num_V_ft": nb, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
+           "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z,
+           "pred": out["pred"], "v_linear_v": v, "condition": h, "V_ft": V}
+    tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att,
+                feat=feat, p=p, pl=pl, t_pl=t_pl, ll=ll, t_ll=t_ll, jin=jin, j0=j0, t_j=t_j,
+                j=j, z=z)
+    return loss, report, out, mid, tape
+
+
+# ----------------------------------------------------------------------------
+# analytic backward
+# ----------------------------------------------------------------------------
+def _fc_ln_relu_backward(dy, tape, params, scope, grads, need_dx=True):
+    x, pre, xhat, rstd, ln = tape
+    gamma = params[scope + "/LayerNorm/gamma"]
+    dln = dy * (ln > 0)
+    red = tuple(range(dln.ndim - 1))
+    grads[scope + "/LayerNorm/beta"] = dln.sum(axis=red)
+    grads[scope + "/LayerNorm/gamma"] = (dln * xhat).sum(axis=red)
+    dxhat = dln * gamma
+    axes = tuple(range(1, dxhat.ndim))
+    m1 = dxhat.mean(axis=axes, keepdims=True)
+    m2 = (dxhat * xhat).mean(axis=axes, keepdims=True)
+    dpre = rstd * (dxhat - m1 - xhat * m2)
+    x2 = x.reshape(-1, x.shape[-1])
+    d2 = dpre.reshape(-1, dpre.shape[-1])
+    grads[scope + "/fc/weights"] = x2.T @ d2
+    grads[scope + "/fc/biases"] = d2.sum(axis=0)
+    if need_dx:
+        return dpre @ params[scope + "/fc/weights"].T
+    return None
+
+
+def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"):
+    """Gradients of the training loss wrt EVERY variable (frozen ones included;
+    the optimiser picks train vars).  Returns (grads, dx_embed_slices) where
+    dx_embed_slices [B,T,W] are the un-aggregated IndexedSlices values of the
+    embedding gradient."""
+    sc = scope_names(model_type)
+    dt = tape["z"].dtype.type
+    g = {}
+    z = tape["z"]
+    B = z.shape[0]
+    tgt = batch["answer_target"]
+    dz = (sigmoid(z) - tgt) / dt(B)
+    if model_type == "vlmap_answer":
+        dz = dz * answer_masks["train"]
+    Wh = params[sc["head"] + "/fc/weights"]
+    g[sc["head"] + "/fc/weights"] = tape["j"].T @ dz
+    g[sc["head"] + "/fc/biases"] = dz.sum(axis=0)
+    dj = dz @ Wh.T
+    dj0 = dj * masks["joint"] * dt(1.0 / KEEP_JOINT)
+    djin = _fc_ln_relu_backward(dj0, tape["t_j"], params, sc["joint_fc"], g)
+    dpl = djin * tape["ll"]
+    dll = djin * tape["pl"]
+    dp = _fc_ln_relu_backward(dpl, tape["t_pl"], params, sc["pooled_linear_l"], g)
+    dh = _fc_ln_relu_backward(dll, tape["t_ll"], params, sc["q_linear_l"], g)
+    # attention pooling: p = sum_r att * V   (V is an input: no dV)
+    V, att = tape["V"], tape["att"]
+    datt = np.einsum("bd,brd->br", dp, V)
+    ds = att * (datt - (att * datt).sum(axis=1, keepdims=True))      # softmax backward (masked rows: att=0)
+    w = params[sc["score"] + "/fc/weights"]
+    g[sc["score"] + "/fc/weights"] = np.einsum("br,brh->h", ds, tape["feat"])[:, None]
+    g[sc["score"] + "/fc/biases"] = np.array([ds.sum()], dtype=z.dtype)
+    dfeat = ds[:, :, None] * w[None, None, :, 0]
+    dfeat = dfeat * masks["att"] * dt(1.0 / KEEP_ATT)
+    dv = dfeat * tape["qv"][:, None, :]
+    dqv = (dfeat * tape["v"]).sum(axis=1)
+    _fc_ln_relu_backward(dv, tape["t_v"], params, sc["v_linear_v"], g, need_dx=False)
+    dh = dh + _fc_ln_relu_backward(dqv, tape["t_qv"], params, sc["q_linear_v"], g)
+    # GRU BPTT
+    Wg = params[sc["gru_gates"] + "/kernel"]
+    Wc = params[sc["gru_cand"] + "/kernel"]
+    Wd = tape["e"].shape[2]
+    H = Wc.shape[1]
+    dWg = np.zeros_like(Wg); dbg = np.zeros(2 * H, z.dtype)
+    dWc = np.zeros_like(Wc); dbc = np.zeros(H, z.dtype)
+    T = len(tape["t_gru"])
+    dx = np.zeros_like(tape["e"])
+    for t in range(T - 1, -1, -1):
+        xt, hp, r, u, c, live = tape["t_gru"][t]
+        dh_live = np.where(live, dh, 0)
+        dh_pass = np.where(live, 0, dh)
+        du = dh_live * (hp - c)
+        dc = dh_live * (1 - u)
+        dhp = dh_live * u
+        dc_pre = dc * (1 - c * c)
+        xin_c = np.concatenate([xt, r * hp], axis=1)
+        dWc += xin_c.T @ dc_pre
+        dbc += dc_pre.sum(axis=0)
+        dxin_c = dc_pre @ Wc.T
+        drh = dxin_c[:, Wd:]
+        dr = drh * hp
+        dhp = dhp + drh * r
+        dg_pre = np.concatenate([dr * r * (1 - r), du * u * (1 - u)], axis=1)
+        xin_g = np.concatenate([xt, hp], axis=1)
+        dWg += xin_g.T @ dg_pre
+        dbg += dg_pre.sum(axis=0)
+        dxin_g = dg_pre @ Wg.T
+        dhp = dhp + dxin_g[:, Wd:]
+        dx[:, t, :] = dxin_c[:, :Wd] + dxin_g[:, :Wd]
+        dh = dhp + dh_pass
+    g[sc["gru_gates"] + "/kernel"] = dWg
+    g[sc["gru_gates"] + "/bias"] = dbg
+    g[sc["gru_cand"] + "/kernel"] = dWc
+    g[sc["gru_cand"] + "/bias"] = dbc
+    dE = np.zeros_like(params[sc["embed"]])
+    np.add.at(dE, batch["q_intseq"].reshape(-1), dx.reshape(-1, Wd))
+    g[sc["embed"]] = dE
+    return g, dx
+
+
+# ----------------------------------------------------------------------------
+# optimiser: tf.contrib.layers.optimize_loss(Adam, clip_gradients=20.0)
+# ----------------------------------------------------------------------------
+def global_norm(grads, train_names, dx_embed, embed_name):
+    """clip_ops.global_norm over the train-var gradients; the embedding
+    gradient is an IndexedSlices whose norm is taken over the UN-AGGREGATED
+    slice values."""
+    acc = 0.0
+    for n in train_names:
+        if n == embed_name:
+            acc += float((dx_embed.astype(np.float64) ** 2).sum())
+        else:
+            acc += float((grads[n].astype(np.float64) ** 2).sum())
+    return np.sqrt(acc)
+
+
+def clip_adam_step(params, grads, train_names, state, lr, dx_embed, embed_name,
+                   clip=CLIP_NORM):
+    """One optimiser step in place.  state = {'step': int, 'm': {}, 'v': {}}.
+
+    clip_by_global_norm: g * clip / max(norm, clip).  Adam (TF1):
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); var -= lr_t*m/(sqrt(v)+eps).  Sparse Adam
+    after de-duplication == dense Adam with zero rows.
+    """
+    norm = global_norm(grads, train_names, dx_embed, embed_name)
+    scale = clip / max(norm, clip)
+    state["step"] += 1
+    t = state["step"]
+    for n in train_names:
+        dt = params[n].dtype.type
+        gsc = grads[n] * dt(scale)
+        m = state["m"].setdefault(n, np.zeros_like(params[n]))
+        v = state["v"].setdefault(n, np.zeros_like(params[n]))
+        m[...] = dt(ADAM_B1) * m + dt(1 - ADAM_B1) * gsc
+        v[...] = dt(ADAM_B2) * v + dt(1 - ADAM_B2) * gsc * gsc
+        lr_t = lr * np.sqrt(1 - ADAM_B2 ** t) / (1 - ADAM_B1 ** t)
+        params[n] -= dt(lr_t) * m / (np.sqrt(v) + dt(ADAM_EPS))
+    return norm
+
+
+def new_opt_state():
+    return {"step": 0, "m": {}, "v": {}}
+
+
+def train_step(params, batch, table, nbox_table, answer_masks, masks, state, lr=1e-3,
+               model_type="vlmap_answer"):
+    """Trainer.run_train_step restated: forward, backward, clip, Adam (vqa/trainer.py:275-287)."""
+    loss, report, out, mid, tape = forward(params, batch, table, nbox_table, answer_masks, masks, model_type)
+    grads, dx = backward(params, batch, answer_masks, masks, tape, model_type)
+    names = train_var_names(params, model_type)
+    norm = clip_adam_step(params, grads, names, state, lr, dx, scope_names(model_type)["embed"])
+    return loss, report, out, mid, grads, norm
+
+
+# ----------------------------------------------------------------------------
+# synthetic inputs
+# ----------------------------------------------------------------------------
+def make_answer_masks(rng, A, num_train_answer, dtype=np.float32, exist_all=True):
+    train = (np.arange(A) < num_train_answer).astype(dtype)
+    is_obj = (rng.random(A) < 0.5)
+    obj = is_obj.astype(dtype)
+    attr = (~is_obj).astype(dtype)
+    exist = np.ones(A, dtype) if exist_all else (rng.random(A) < 0.7).astype(dtype)
+    return {"train": train, "obj": obj, "attr": attr, "exist": exist}
+
+
+def make_batch(rng, B, T, Vq, A, N, dtype=np.float32, ragged=True, min_len=3):
+    idx = rng.integers(0, N, size=B).astype(np.int64)
+    lens = (rng.integers(min_len, T + 1, size=B) if ragged else np.full(B, T)).astype(np.int32)
+    q = rng.integers(0, max(Vq - 3, 1), size=(B, T)).astype(np.int32)
+    q[np.arange(T)[None, :] >= lens[:, None]] = 0          # zero padding
+    tgt = np.zeros((B, A), dtype)
+    for b in range(B):
+        k = int(rng.integers(1, 4))
+        ids = rng.choice(A, size=k, replace=False)
+        tgt[b, ids] = rng.choice(np.array([0.3, 0.6, 0.9, 1.0], dtype), size=k)
+    return {"image_idx": idx, "q_intseq": q, "q_intseq_len": lens, "answer_target": tgt}
+
+
+def make_table(rng, N, R, D, dtype=np.float32, full_boxes=True):
+    table = np.maximum(rng.standard_normal((N, R, D)), 0).astype(dtype)
+    nbox = np.full(N, R, np.int32) if full_boxes else rng.integers(1, R + 1, size=N).astype(np.int32)
+    return table, nbox
+
+
+def make_dropout_masks(rng, B, R, H, dtype=np.float32):
+    return {"att": (rng.random((B, R, H)) < KEEP_ATT).astype(dtype),
+            "joint": (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)}

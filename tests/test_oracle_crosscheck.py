@@ -1,0 +1,85 @@
+"""Oracle pins (SURVEY.md 8c i,iii): NumPy oracle vs the independently composed
+torch-autograd restatement (f64), and central finite differences."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_oracle as O
+from oracle import torch_ref as TR
+
+DIMS = dict(Vq=30, W=12, D=24, H=16, A=21)
+
+
+def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    p = O.perturb_ln_params(O.init_params(rng, model_type, dtype=dtype, **DIMS), rng)
+    table, nbox = O.make_table(rng, N, R, DIMS["D"], dtype, full_boxes=full_boxes)
+    batch = O.make_batch(rng, B, T, DIMS["Vq"], DIMS["A"], N, dtype)
+    am = O.make_answer_masks(rng, DIMS["A"], 15, dtype, exist_all=False)
+    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], dtype)
+    return p, table, nbox, batch, am, masks
+
+
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard"])
+def test_forward_and_grads_match_torch_autograd(model_type):
+    p, table, nbox, batch, am, masks = _case(11, model_type)
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
+    grads, dx = O.backward(p, batch, am, masks, tape, model_type)
+    tloss, tmid, tgrads, tdx = TR.loss_and_grads(p, batch, table, nbox, am, masks, model_type)
+    assert abs(loss - tloss) <= 1e-10 * max(1, abs(tloss))
+    for k in ("v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "pooled_linear_l",
+              "l_linear_l", "joint", "logit"):
+        np.testing.assert_allclose(mid[k], tmid[k], rtol=1e-9, atol=1e-11, err_msg=k)
+    for k in p:
+        np.testing.assert_allclose(grads[k], tgrads[k], rtol=1e-7, atol=1e-11, err_msg=k)
+    np.testing.assert_allclose(dx, tdx, rtol=1e-7, atol=1e-12)
+
+
+def test_finite_differences_on_selected_params():
+    p, table, nbox, batch, am, masks = _case(12, "vlmap_answer", B=3, R=4, T=5)
+    _, _, _, _, tape = O.forward(p, batch, table, nbox, am, masks)
+    grads, _ = O.backward(p, batch, am, masks, tape)
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    for name in p:
+        flat = p[name].reshape(-1)
+        for i in rng.choice(flat.size, size=min(3, flat.size), replace=False):
+            old = flat[i]
+            flat[i] = old + eps
+            lp = O.forward(p, batch, table, nbox, am, masks)[0]
+            flat[i] = old - eps
+            lm = O.forward(p, batch, table, nbox, am, masks)[0]
+            flat[i] = old
+            fd = (lp - lm) / (2 * eps)
+            an = grads[name].reshape(-1)[i]
+            assert abs(fd - an) <= 1e-6 + 1e-5 * abs(an), (name, i, fd, an)
+
+
+def test_f32_oracle_close_to_f64_oracle():
+    p, table, nbox, batch, am, masks = _case(13, "vlmap_answer")
+    l64, _, _, mid64, _ = O.forward(p, batch, table, nbox, am, masks)
+    c = lambda d: {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in d.items()}
+    l32, _, _, mid32, _ = O.forward(c(p), c(batch), table.astype(np.float32), nbox, c(am), c(masks))
+    assert mid32["logit"].dtype == np.float32
+    np.testing.assert_allclose(mid32["logit"], mid64["logit"], rtol=0, atol=5e-5)
+
+
+def test_train_step_matches_torch_cpu_baseline_port():
+    p, table, nbox, batch, am, masks = _case(14, "vlmap_answer", dtype=np.float32)
+    p_t = {k: v.copy() for k, v in p.items()}
+    stepper = TR.CpuTrainStep(p_t, table, nbox, am, "vlmap_answer", lr=1e-3)
+    st = O.new_opt_state()
+    for it in range(3):
+        loss, report, out, mid, grads, norm = O.train_step(p, batch, table, nbox, am, masks, st, 1e-3)
+        tl, tn = stepper(batch, masks)
+        assert abs(loss - tl) < 1e-4 * max(1, abs(tl))
+        assert abs(norm - tn) < 1e-4 * max(1, tn)
+    for k in O.train_var_names(p, "vlmap_answer"):
+        if k.endswith("score/fc/biases"):
+            # d(loss)/d(score bias) == 0 exactly (softmax shift invariance); in f32 it is
+            # rounding noise that Adam normalises to +-lr steps -> not comparable.
+            continue
+        np.testing.assert_allclose(p[k], stepper.P[k].detach().numpy(), rtol=0, atol=2e-4, err_msg=k)
+    for k in p:
+        if k.split("/")[0] in O.FROZEN_TOP_SCOPES_VLMAP:
+            np.testing.assert_array_equal(p[k], p_t[k])     # frozen vars never move
