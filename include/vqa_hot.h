@@ -1,0 +1,235 @@
+/* libvqahot.so -- C ABI of the MI355X-native VQA hot path.
+ *
+ * The reference (HyeonwooNoh/VQA-Transfer-ExternalData) has NO FFI/plugin
+ * boundary: its hot path is a Python class contract inside one TF-1.6 graph
+ * (SURVEY.md 8b).  Each entry point below therefore cites the reference graph
+ * code whose stock TF ops it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer
+ *     unless the name ends in _host.  No torch types.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued and the call
+ *     returns immediately.  No allocation, no synchronisation inside.
+ *   - Return 0 on success, a negative VQA_ERR_* otherwise; never throws.
+ *   - Row-major tensors exactly as in the reference (NHWC for images).
+ *   - fp32 everywhere the reference is fp32; matrix products run on the exact
+ *     f32-input MFMA (v_mfma_f32_32x32x2_f32).
+ */
+#ifndef VQA_HOT_H
+#define VQA_HOT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_HOT_ABI_VERSION 1
+
+enum {
+    VQA_OK = 0,
+    VQA_ERR_ARG = -1,     /* bad size / null pointer */
+    VQA_ERR_ALIGN = -2,   /* pointer or leading dimension not 16-byte aligned where required */
+    VQA_ERR_LAUNCH = -3,  /* hipGetLastError() after a launch */
+    VQA_ERR_UNSUPPORTED = -4,
+    VQA_ERR_WORKSPACE = -5 /* workspace too small */
+};
+
+int vqa_hot_version(void);
+const char* vqa_hot_error_string(int code);
+
+/* ---------------------------------------------------------------- a1 / K1
+ * V_ft = np.take(features, image_idx); num_V_ft = gather(num_boxes, image_idx)
+ * vqa/model_vlmap_answer.py:110-123 (tf.py_func on /cpu:0 + H2D copy).
+ * table [N,R,D] f32 resident in HBM, idx i64[B] -> V [B,R,D], nb i32[B]. */
+int vqa_gather_features(const float* table, const int32_t* nbox_table, const int64_t* idx,
+                        float* V, int32_t* nb, int B, int R, int D, int64_t N, void* stream);
+
+/* ---------------------------------------------------------------- a3 / K3
+ * tf.nn.embedding_lookup(glove_map, q_intseq)  vqa/model_vlmap_answer.py:134.
+ * q i32[B,T] (batch-major, zero padded) -> x [T,B,W] TIME-major (the GRU
+ * consumes one contiguous [B,W] slab per step). */
+int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, void* stream);
+/* backward: dE[q[b,t],:] += dx[t,b,:] (dE must be zeroed by the caller);
+ * the IndexedSlices gradient of the gather. */
+int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq, void* stream);
+
+/* ------------------------------------------------- GEMM (layers.fully_connected)
+ * C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ D[M,N]),  f32 MFMA.
+ *   transA = 0: A is [M,K] row-major (lda >= K);  1: A is [K,M] row-major (lda >= M)
+ *   transB = 0: B is [K,N] row-major (ldb >= N);  1: B is [N,K] row-major (ldb >= K)
+ * Supported: (0,0) forward FC, (0,1) dX = dY*W^T, (1,0) dW = X^T*dY.
+ * bias, D may be NULL; D may alias C.  split_k > 1 needs `workspace` of
+ * split_k*M*N floats (deterministic slab reduce); split_k = 0 lets the library
+ * choose.  Replaces tf.contrib.layers.fully_connected / its autodiff
+ * (vlmap/modules.py:635-641) and the GRUCell matmuls (vlmap/modules.py:129-135). */
+int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                 int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
+                 float* workspace, int64_t workspace_floats, void* stream);
+int64_t vqa_gemm_workspace_floats(int M, int N, int K, int split_k);
+
+/* ------------------------------------------- a2,a5,a8,a9 : LN + ReLU (+dropout)
+ * y = relu(layer_norm(pre)) [* keepmask / keep]  with statistics over groups of
+ * `rows` consecutive rows (rows = R for v_linear_v: LN over all 36x1024 values
+ * of a sample; rows = 1 otherwise), gamma/beta on the last axis, eps 1e-12.
+ * vlmap/modules.py:647-650 (layers.layer_norm + relu), vqa/model_vlmap_answer.py:180
+ * (tf.nn.dropout 0.5).  pre,y [G*rows,N]; mean,rstd [G]; keepmask u8 [G*rows,N] or NULL. */
+int vqa_ln_relu_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask,
+                    float keep_prob, float* y, float* mean, float* rstd, int G, int rows, int N, void* stream);
+/* backward.  dy [G*rows,N] -> dpre; per-group partial sums of d(gamma), d(beta),
+ * d(bias) are written to part_* [G,N] when non-NULL (reduce with vqa_colsum). */
+int vqa_ln_relu_bwd(const float* dy, const float* pre, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const uint8_t* keepmask, float keep_prob,
+                    float* dpre, float* part_dgamma, float* part_dbeta, float* part_dbias, int G, int rows,
+                    int N, void* stream);
+/* out[N] = sum_m X[m,:]  (deterministic two-stage; workspace >= vqa_colsum_workspace_floats). */
+int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace, int64_t workspace_floats,
+               void* stream);
+int64_t vqa_colsum_workspace_floats(int M, int N);
+/* z = a * b elementwise (pooled_linear_l * l_linear_l, vqa/model_vlmap_answer.py:177) */
+int vqa_mul(const float* a, const float* b, float* z, int64_t n, void* stream);
+/* da = dz*b ; db = dz*a */
+int vqa_mul_bwd(const float* dz, const float* a, const float* b, float* da, float* db, int64_t n, void* stream);
+int vqa_add_inplace(float* acc, const float* x, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- a4 / K4
+ * tf.contrib.rnn.GRUCell under tf.nn.dynamic_rnn(sequence_length)
+ * (vlmap/modules.py:124-140).  The matmuls go through vqa_gemm_f32; these are
+ * the fused gate kernels of one time step.
+ *  gates:  r,u = sigmoid(gpre[:, :H]), sigmoid(gpre[:, H:]);  rh = r*h_prev
+ *  cand :  c = tanh(cpre); h_new = (t < len) ? u*h_prev + (1-u)*c : h_prev   */
+int vqa_gru_gates_fwd(const float* gpre, int ldg, const float* h_prev, float* r, float* u, float* rh, int B,
+                      int H, void* stream);
+int vqa_gru_cand_fwd(const float* cpre, int ldc, const float* u, const float* h_prev, const int32_t* len, int t,
+                     float* c, float* h_new, int B, int H, void* stream);
+/* backward of one step, part 1: from dh (grad wrt h_t):
+ *  dc_pre = live ? dh*(1-u)*(1-c^2) : 0 ; du_pre = live ? dh*(h_prev-c)*u*(1-u) : 0
+ *  dh_acc = live ? dh*u : dh                                                      */
+int vqa_gru_bwd_a(const float* dh, const float* h_prev, const float* u, const float* c, const int32_t* len,
+                  int t, float* dc_pre, int ld_dc, float* du_pre, int ld_du, float* dh_acc, int B, int H,
+                  void* stream);
+/* part 2: from drh = dc_pre * Wc_h^T:  dr_pre = drh*h_prev*r*(1-r); dh_acc += drh*r */
+int vqa_gru_bwd_b(const float* drh, const float* h_prev, const float* r, float* dr_pre, int ld_dr,
+                  float* dh_acc, int B, int H, void* stream);
+
+/* ------------------------------------------------------------ a6+a7 / K6+K7
+ * hadamard_attention + attention_pooling fused (vlmap/modules.py:67-97, 23-39):
+ *  s[b,r] = sum_h v[b,r,h]*qv[b,h]*keep[b,r,h]/keep_prob*w[h] + bias
+ *  s[r >= nb[b]] = -inf ; att = softmax_R(s) ; pooled[b,:] = sum_r att[b,r]*V[b,r,:]
+ * keepmask u8 [B,R,H] (the explicit tf.nn.dropout(.,0.8) mask) or NULL. */
+int vqa_attn_pool_fwd(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
+                      const float* bias, const uint8_t* keepmask, float keep_prob, float* att, float* pooled,
+                      int B, int R, int H, int D, void* stream);
+/* backward: dpooled [B,D] -> dv [B,R,H], dqv [B,H], per-sample partials
+ * part_dw [B,H] and part_db [B] (reduce with vqa_colsum). */
+int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, const float* V, const float* att,
+                      const float* w, const uint8_t* keepmask, float keep_prob, float* dv, float* dqv,
+                      float* part_dw, float* part_db, int B, int R, int H, int D, void* stream);
+
+/* --------------------------------------------------------------- a11 / K11
+ * sigmoid-CE loss, argmax, VQA scores (vqa/model_vlmap_answer.py:192-288).
+ * Per sample stats[b, VQA_STAT_*]; dz = (sigmoid(z)-t)*(loss_mask?)/B_norm when
+ * dz != NULL.  masks are float [A]; loss_mask = train mask for vlmap_answer,
+ * NULL for model_standard (vqa/model_standard.py:285). */
+enum {
+    VQA_STAT_LOSS_TRAIN = 0, VQA_STAT_LOSS_REPORT, VQA_STAT_ALL_SCORE, VQA_STAT_EXIST_SCORE,
+    VQA_STAT_TEST_SCORE, VQA_STAT_TEST_OBJ_SCORE, VQA_STAT_TEST_ATTR_SCORE, VQA_STAT_TRAIN_EXIST_SCORE,
+    VQA_STAT_MAX_EXIST, VQA_STAT_MAX_TRAIN_EXIST, VQA_STAT_TEST_OBJ_MAX, VQA_STAT_TEST_ATTR_MAX,
+    VQA_STAT_TEST_MAX, VQA_STAT_TEST_MAX_EXIST, VQA_STAT_MAX_TRAIN, VQA_STAT_COUNT = 16
+};
+int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, const float* obj_mask,
+                 const float* attr_mask, const float* exist_mask, int use_train_mask_in_loss, float inv_batch,
+                 float* stats, int32_t* pred, float* dz, int B, int A, void* stream);
+/* report[13] in the order of vqa_report_key(i): means over B + guarded ratios. */
+int vqa_report_reduce(const float* stats, int B, float* report, void* stream);
+#define VQA_REPORT_COUNT 13
+const char* vqa_report_key(int i);
+
+/* --------------------------------------------------------------- a12 / K12
+ * tf.contrib.layers.optimize_loss(Adam, clip_gradients=20.0) (vqa/trainer.py:106-114)
+ * on FLAT parameter / gradient buffers.  norm_sq_out[0] = sum(g^2) over
+ * g[0..n) + extra_sq[0] (extra = un-aggregated embedding-slice sumsq, may be
+ * NULL).  partial needs >= vqa_sumsq_workspace_floats(n) floats. */
+int vqa_sumsq(const float* g, int64_t n, const float* extra_sq, float* norm_sq_out, float* partial,
+              int64_t partial_floats, void* stream);
+int64_t vqa_sumsq_workspace_floats(int64_t n);
+/* p,m,v updated in place: g' = g*clip/max(sqrt(norm_sq),clip); Adam(b1,b2,eps)
+ * with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host and passed in. */
+int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float clip,
+                  float lr_t, float beta1, float beta2, float eps, void* stream);
+
+/* explicit dropout keep-mask (counter-based, reproducible): out[i] = u(seed,i) < keep_prob */
+int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, float keep_prob, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Whole fusion model (vqa/model_vlmap_answer.py:102-288 / vqa/model_standard.py:193-374)
+ * and its backward, as one host call each.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t B, R, D, H, T, W, A, Vq;
+    int64_t N_img;
+    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard */
+    float keep_att;          /* 0.8  vlmap/modules.py:82 */
+    float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
+    float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
+} vqa_dims_t;
+
+/* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
+typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;
+
+typedef struct {
+    float* embed;                       /* LearnGloVe/embed_map [Vq,W] */
+    vqa_fc_t v_linear_v;                /* [D,H] */
+    float *gru_wg, *gru_bg;             /* encode_L/rnn/gru_cell/gates/{kernel,bias} [W+H,2H],[2H] */
+    float *gru_wc, *gru_bc;             /* .../candidate/{kernel,bias} [W+H,H],[H] */
+    vqa_fc_t q_linear_v;                /* [H,H] */
+    vqa_fc_t score;                     /* hadamard_attention/compute/score [H,1],[1] */
+    vqa_fc_t pooled_linear_l;           /* [D,H] */
+    vqa_fc_t q_linear_l;                /* [H,H] */
+    vqa_fc_t joint_fc;                  /* [H,2H] */
+    vqa_fc_t head;                      /* WordWeightAnswer | reasoning/classifier [2H,A] */
+} vqa_params_t;
+
+typedef struct {
+    const float* table;                 /* [N_img,R,D] */
+    const int32_t* nbox_table;          /* [N_img] */
+    const int64_t* image_idx;           /* [B] */
+    const int32_t* q_intseq;            /* [B,T] zero padded */
+    const int32_t* q_intseq_len;        /* [B] */
+    const float* answer_target;         /* [B,A] */
+    const float *train_mask, *obj_mask, *attr_mask, *exist_mask; /* [A] */
+    const uint8_t* keep_att;            /* [B,R,H] 0/1 or NULL (no dropout) */
+    const uint8_t* keep_joint;          /* [B,2H] 0/1 or NULL */
+} vqa_batch_t;
+
+int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims);
+/* Byte offset / element count of a named intermediate inside the workspace
+ * (names follow the reference's mid_result/output keys: V_ft, num_V_ft,
+ * v_linear_v, condition, q_linear_v, att_score, pooled_V_ft, pooled_linear_l,
+ * l_linear_l, joint, logit, pred, stats, report, dx_embed, ...). */
+int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64_t* offset_bytes, int64_t* n_elems);
+int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* params, const vqa_batch_t* batch,
+                       void* workspace, int64_t workspace_bytes, int want_dz, void* stream);
+/* grads: same layout as params; a NULL member skips that gradient (frozen
+ * variable).  Gradient buffers are OVERWRITTEN (embed must be pre-zeroed: it is
+ * scatter-added).  embed_slice_sq receives sum(dx^2) of the un-aggregated
+ * embedding IndexedSlices (for clip_by_global_norm). */
+int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* params, const vqa_params_t* grads,
+                        const vqa_batch_t* batch, void* workspace, int64_t workspace_bytes,
+                        float* embed_slice_sq, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement probe (bench.py): HIP events recorded by the library on the
+ * op's own stream around every launch group whose label matches.  Labels:
+ * "v_linear_v.fwd_gemm", "v_linear_v.dw_gemm", "gru.fwd", "gru.bwd",
+ * "attn_pool.fwd", "attn_pool.bwd", "head.fwd_gemm", "forward", "backward".
+ * vqa_probe_read synchronises the recorded events and returns the per-sample
+ * durations in milliseconds (at most max_samples). */
+int vqa_probe_enable(const char* label, int max_samples);
+int vqa_probe_read(float* ms_out, int capacity, int* n_out);
+int vqa_probe_disable(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_HOT_H */

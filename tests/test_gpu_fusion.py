@@ -1,0 +1,150 @@
+"""GPU parity of the whole fusion model (forward, backward, clip+Adam) against
+the CPU oracle, through the C ABI (vqa_fusion_forward / vqa_fusion_backward /
+vqa_sumsq / vqa_clip_adam).  Tolerances: logits 1e-3 abs (BASELINE north_star),
+argmax/pred bit-exact; gradients 5e-4 of the tensor's max-abs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_oracle as O
+from tests.gpu_util import dev, dev_batch, make_case, make_engine, to64
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(Vq=30, W=12, D=24, H=16, A=21)
+MED = dict(Vq=500, W=300, D=256, H=128, A=300)
+FULL = dict(Vq=2000, W=300, D=2048, H=1024, A=3000)
+
+MID_KEYS = ["v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "pooled_linear_l", "l_linear_l",
+            "joint", "logit"]
+
+
+def run_engine(eng, batch, masks, lr=None):
+    ka, kj = dev(masks["att"].astype(np.uint8)), dev(masks["joint"].astype(np.uint8))
+    db = dev_batch(batch)
+    eng.forward(db, ka, kj, want_dz=True)
+    eng.backward()
+    if lr is not None:
+        eng.optimizer_step(lr)
+    torch.cuda.synchronize()
+
+
+def grad_close(got, want, name, tol=5e-4):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    sc = max(np.abs(want).max(), 1e-12)
+    err = np.abs(got - want).max()
+    assert err <= tol * sc + 1e-9, "%s: max err %.3e vs scale %.3e" % (name, err, sc)
+
+
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard"])
+@pytest.mark.parametrize("cfg", [("small", SMALL, 5, 6, 7, 9), ("med", MED, 32, 36, 14, 64),
+                                 ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
+def test_forward_backward_match_oracle(model_type, cfg):
+    name, dims, B, R, T, N = cfg
+    p, table, nbox, batch, am, masks = make_case(21, model_type, B, R, T, N, dims)
+    eng = make_engine(model_type, p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    # oracle in float64 on the same f32 inputs
+    p64 = to64(p)
+    loss, report, out, mid, tape = O.forward(p64, to64(batch), table.astype(np.float64), nbox, to64(am), to64(masks),
+                                             model_type)
+    grads, dx = O.backward(p64, to64(batch), to64(am), to64(masks), tape, model_type)
+    shapes = {"v_linear_v": (B, R, dims["H"]), "att_score": (B, R), "logit": (B, dims["A"])}
+    for k in MID_KEYS:
+        got = eng.tensor(k).cpu().numpy().reshape(mid[k].shape)
+        tol = 1e-3 if k == "logit" else 2e-4 * max(1.0, np.abs(mid[k]).max())
+        assert np.abs(got - mid[k]).max() <= tol, (k, np.abs(got - mid[k]).max())
+    np.testing.assert_array_equal(eng.tensor("pred").cpu().numpy(), out["pred"])          # bit-exact argmax
+    np.testing.assert_array_equal(eng.tensor("num_V_ft").cpu().numpy(), mid["num_V_ft"])
+    rep = eng.report()
+    for k in O.REPORT_KEYS:
+        assert abs(rep[k] - report[k]) <= 1e-4 * max(1.0, abs(report[k])), (k, rep[k], report[k])
+    for n in eng.train_names:
+        grad_close(eng.grads[n], grads[n], n)
+    grad_close(eng.tensor("dx_embed").view(T, B, dims["W"]).transpose(0, 1), dx, "dx_embed")
+    sq = float(eng.grad_flat[eng.n_train])
+    assert abs(sq - (dx ** 2).sum()) <= 1e-3 * (dx ** 2).sum() + 1e-12
+
+
+def test_train_steps_match_oracle_f32():
+    dims, B, R, T, N = MED, 32, 36, 14, 64
+    p, table, nbox, batch, am, masks = make_case(22, "vlmap_answer", B, R, T, N, dims)
+    eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    frozen_before = {n: eng.params[n].clone() for n in eng.frozen_names}
+    st = O.new_opt_state()
+    for it in range(3):
+        run_engine(eng, batch, masks, lr=1e-3)
+        loss, report, out, mid, grads, norm = O.train_step(p, batch, table, nbox, am, masks, st, 1e-3)
+        assert abs(float(eng.norm_sq[0]) ** 0.5 - norm) <= 1e-3 * norm
+        assert abs(eng.report()["answer_train_loss"] - loss) <= 2e-4 * max(1, abs(loss))
+    for n in eng.train_names:
+        if n.endswith("score/fc/biases"):
+            continue       # exact-zero gradient -> Adam amplifies rounding noise (see tests/test_oracle_crosscheck.py)
+        got = eng.params[n].cpu().numpy()
+        # Adam moves each weight by ~lr per step; allow 15 % of the 3-step travel on sign-ambiguous entries
+        assert np.abs(got - p[n]).max() <= 4.5e-4 + 1e-4 * np.abs(p[n]).max(), n
+        assert np.mean(np.abs(got - p[n]) > 1e-4) < 0.02, n
+    for n in eng.frozen_names:
+        assert torch.equal(eng.params[n], frozen_before[n])                        # filter_train_vars honoured
+
+
+def test_untrained_head_known_answer():
+    # WordWeightAnswer with word_weight_dir=None: weights 0, bias -100 -> logits -100, pred 0
+    dims, B, R, T, N = MED, 8, 36, 14, 16
+    p, table, nbox, batch, am, masks = make_case(23, "vlmap_answer", B, R, T, N, dims, head="untrained")
+    eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    z = eng.tensor("logit").cpu().numpy()
+    assert np.all(z == -100.0)
+    assert np.all(eng.tensor("pred").cpu().numpy() == 0)
+    tgt = batch["answer_target"].astype(np.float64)
+    want = (tgt * 100.0).sum(1).mean() + dims["A"] * np.log1p(np.exp(-100.0))
+    assert abs(eng.report()["answer_report_loss"] - want) <= 1e-5 * want
+
+
+def test_ragged_lengths_including_zero_and_short_boxes():
+    dims, B, R, T, N = MED, 16, 36, 14, 32
+    p, table, nbox, batch, am, masks = make_case(24, "vlmap_answer", B, R, T, N, dims)
+    batch["q_intseq_len"][:3] = [0, 1, 14]
+    batch["q_intseq"][0, :] = 0
+    nbox[batch["image_idx"][1]] = 1
+    eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
+                                             to64(masks))
+    h = eng.tensor("condition").view(B, dims["H"]).cpu().numpy()
+    assert np.all(h[0] == 0)                                                        # len 0 -> zero state
+    assert np.abs(h - mid["condition"]).max() < 1e-5
+    att = eng.tensor("att_score").view(B, R).cpu().numpy()
+    np.testing.assert_array_equal(att[1], np.eye(R, dtype=np.float32)[0])           # one box -> [1,0,...]
+    assert np.abs(eng.tensor("logit").view(B, -1).cpu().numpy() - mid["logit"]).max() < 1e-3
+
+
+def test_full_size_properties_bs512():
+    """BASELINE config 2 sizes: size-independent properties instead of an oracle run."""
+    dims = dict(Vq=16384, W=300, D=2048, H=1024, A=3000)
+    B, R, T, N = 512, 36, 14, 1024
+    p, table, nbox, batch, am, masks = make_case(25, "vlmap_answer", B, R, T, N, dims, full_boxes=True)
+    eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    att = eng.tensor("att_score").view(B, R)
+    assert torch.allclose(att.sum(1), torch.ones(B, device="cuda"), atol=1e-5)       # softmax rows sum to 1
+    assert bool((att >= 0).all())
+    z = eng.tensor("logit").view(B, dims["A"])
+    assert torch.equal(eng.tensor("pred").long(), z.argmax(1))                       # argmax consistent
+    assert bool(torch.isfinite(eng.grad_flat).all())
+    # sample independence (LN is per sample): a sub-batch of the first 8 samples gives the same logits
+    sub = {k: v[:8].copy() for k, v in batch.items()}
+    eng8 = make_engine("vlmap_answer", p, table, nbox, am, 8, R, T, dims)
+    m8 = {"att": masks["att"][:8], "joint": masks["joint"][:8]}
+    eng8.forward(dev_batch(sub), dev(m8["att"].astype(np.uint8)), dev(m8["joint"].astype(np.uint8)))
+    torch.cuda.synchronize()
+    assert (eng8.tensor("logit").view(8, -1) - z[:8]).abs().max() < 1e-4
+    # linearity of the backward in dlogit: gradient of the score weights scales with 1/global_batch
+    g1 = eng.grads["v_linear_v/fc/weights"].clone()
+    eng2 = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims, global_batch=2 * B)
+    run_engine(eng2, batch, masks)
+    assert (eng2.grads["v_linear_v/fc/weights"] * 2 - g1).abs().max() <= 1e-5 * g1.abs().max()
+    # and the embedding scatter-add preserves mass: sum(dE) == sum(dx)
+    dE, dx = eng.grads["LearnGloVe/embed_map"], eng.tensor("dx_embed")
+    assert abs(float(dE.double().sum()) - float(dx.double().sum())) <= 1e-6 * float(dx.double().abs().sum()) + 1e-9

@@ -1,0 +1,239 @@
+"""GPU parity of each C-ABI op against the CPU oracle (bit-exact for integer
+outputs, stated float tolerances otherwise).  Runs only on the MI355X box."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _load():
+    global ops
+    import vqa_transfer_externaldata_amd  # noqa: F401
+    from vqa_transfer_externaldata_amd import ops as _ops
+    ops = _ops
+    assert torch.cuda.is_available()
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def close(got, want, rtol, atol, msg=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=msg)
+
+
+GEMM_SHAPES = [
+    # (M, N, K) incl. ragged / unaligned / tiny / split-k / big-tile shapes
+    (1, 1, 1), (5, 21, 12), (7, 20, 300), (64, 64, 16), (130, 70, 33), (512, 1024, 1024), (96, 3000, 2048),
+    (300, 2048, 1000), (18432 // 8, 1024, 2048), (2048, 1024, 4608), (37, 41, 53),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_gemm_matches_f64(M, N, K, layout):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    D = rng.standard_normal((M, N)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64) + bias + D
+    if layout == "nn":
+        got = ops.gemm(dev(A), dev(B), bias=dev(bias), addend=dev(D))
+    elif layout == "nt":
+        got = ops.gemm(dev(A), dev(B.T), transB=True, bias=dev(bias), addend=dev(D))
+    else:
+        got = ops.gemm(dev(A.T), dev(B), transA=True, bias=dev(bias), addend=dev(D))
+    scale = np.sqrt(K) + 1
+    close(got, want, rtol=1e-5, atol=2e-6 * scale * 4, msg=layout)
+
+
+def test_gemm_identity_asymmetric_and_inplace_addend():
+    # A = I with an asymmetric B catches a transposed C write; addend aliasing C (GRU in-place form)
+    n = 96
+    B = np.arange(n * n, dtype=np.float32).reshape(n, n) / 7.0
+    got = ops.gemm(dev(np.eye(n, dtype=np.float32)), dev(B))
+    np.testing.assert_array_equal(got.cpu().numpy(), B)
+    Cbuf = dev(np.ones((n, n), np.float32))
+    ops.gemm(dev(np.eye(n, dtype=np.float32)), dev(B), addend=Cbuf, out=Cbuf)
+    np.testing.assert_array_equal(Cbuf.cpu().numpy(), B + 1)
+
+
+def test_gemm_strided_views_like_gru():
+    # C and addend are column slices of a wider buffer (xp[:, :2H] with ld = 3H)
+    rng = np.random.default_rng(0)
+    M, H = 40, 32
+    xp = rng.standard_normal((M, 3 * H)).astype(np.float32)
+    h = rng.standard_normal((M, H)).astype(np.float32)
+    W = rng.standard_normal((H, 2 * H)).astype(np.float32)
+    xpd = dev(xp)
+    ops.gemm(dev(h), dev(W), addend=xpd[:, :2 * H], out=xpd[:, :2 * H])
+    want = xp.copy()
+    want[:, :2 * H] += h @ W
+    close(xpd, want, 1e-5, 1e-5)
+
+
+def test_gemm_split_k_deterministic():
+    rng = np.random.default_rng(1)
+    A = dev(rng.standard_normal((4096, 300)).astype(np.float32))
+    B = dev(rng.standard_normal((4096, 256)).astype(np.float32))
+    c1 = ops.gemm(A, B, transA=True, split_k=8)
+    c2 = ops.gemm(A, B, transA=True, split_k=8)
+    assert torch.equal(c1, c2)
+    close(c1, A.cpu().numpy().astype(np.float64).T @ B.cpu().numpy().astype(np.float64), 1e-5, 2e-3)
+
+
+def test_gather_features_bit_exact():
+    rng = np.random.default_rng(2)
+    table, nbox = O.make_table(rng, 50, 36, 64, full_boxes=False)
+    idx = rng.integers(0, 50, size=17).astype(np.int64)
+    V, nb = ops.gather_features(dev(table), dev(nbox), dev(idx))
+    np.testing.assert_array_equal(V.cpu().numpy(), table[idx])
+    np.testing.assert_array_equal(nb.cpu().numpy(), nbox[idx])
+
+
+def test_embedding_gather_and_scatter():
+    rng = np.random.default_rng(3)
+    Vq, W, B, T = 40, 300, 9, 14
+    E = rng.standard_normal((Vq, W)).astype(np.float32)
+    q = rng.integers(0, Vq, size=(B, T)).astype(np.int32)
+    x = ops.embed_fwd(dev(E), dev(q))
+    np.testing.assert_array_equal(x.cpu().numpy(), E[q].transpose(1, 0, 2))
+    dx = rng.standard_normal((T, B, W)).astype(np.float32)
+    dE = ops.embed_bwd(dev(dx), dev(q), Vq)
+    want = np.zeros((Vq, W), np.float64)
+    np.add.at(want, q.T.reshape(-1), dx.reshape(-1, W).astype(np.float64))
+    close(dE, want, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("G,rows,N", [(7, 1, 1024), (5, 36, 1024), (3, 1, 2048), (4, 6, 16), (3, 5, 21), (2, 36, 128)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_ln_relu_fwd_bwd(G, rows, N, drop):
+    rng = np.random.default_rng(G * 100 + rows * 10 + N)
+    pre = (rng.standard_normal((G, rows, N)) * 2 + 0.5)
+    gamma = 1 + 0.2 * rng.standard_normal(N); beta = 0.2 * rng.standard_normal(N)
+    keep = (rng.random((G, rows, N)) < 0.5) if drop else None
+    y64, xhat, rstd = O.layer_norm_forward(pre, gamma, beta)
+    ln = y64
+    y64 = np.maximum(y64, 0) * (keep / 0.5 if drop else 1.0)
+    f = lambda a: dev(a.astype(np.float32))
+    km = dev(keep.astype(np.uint8).reshape(G * rows, N)) if drop else None
+    y, mean, rs = ops.ln_relu_fwd(f(pre.reshape(G * rows, N)), f(gamma), f(beta), rows, km, 0.5)
+    close(y, y64.reshape(G * rows, N), 1e-4, 2e-5)
+    close(rs, rstd.reshape(G), 1e-5, 0)
+    dy = rng.standard_normal((G, rows, N))
+    dln = dy * (keep / 0.5 if drop else 1.0) * (ln > 0)
+    dxhat = dln * gamma
+    m1 = dxhat.mean(axis=(1, 2), keepdims=True); m2 = (dxhat * xhat).mean(axis=(1, 2), keepdims=True)
+    dpre64 = rstd * (dxhat - m1 - xhat * m2)
+    dpre, dg, db, dbias = ops.ln_relu_bwd(f(dy.reshape(G * rows, N)), f(pre.reshape(G * rows, N)), mean, rs, f(gamma),
+                                          f(beta), rows, km, 0.5)
+    sc = np.abs(dpre64).max()
+    close(dpre, dpre64.reshape(G * rows, N), 1e-3, 2e-4 * sc)
+    close(dg, (dln * xhat).sum(axis=(0, 1)), 1e-3, 1e-3)
+    close(db, dln.sum(axis=(0, 1)), 1e-3, 1e-3)
+    close(dbias, dpre64.sum(axis=(0, 1)), 1e-3, 2e-3 * max(sc, 1))
+
+
+@pytest.mark.parametrize("B,R,H,D", [(3, 36, 1024, 2048), (4, 5, 16, 24), (2, 100, 64, 32)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_attention_pool_fwd_bwd(B, R, H, D, drop):
+    rng = np.random.default_rng(B + R + H)
+    v = np.maximum(rng.standard_normal((B, R, H)), 0); qv = np.maximum(rng.standard_normal((B, H)), 0)
+    V = np.maximum(rng.standard_normal((B, R, D)), 0)
+    w = rng.standard_normal((H, 1)) * 0.1; bias = np.array([0.2])
+    nb = rng.integers(1, R + 1, size=B).astype(np.int32); nb[0] = R
+    keep = (rng.random((B, R, H)) < 0.8).astype(np.float64) if drop else np.ones((B, R, H))
+    att64, feat = O.hadamard_attention_forward(v, nb, qv, w, bias, keep if drop else np.ones_like(keep) * 0.8)
+    p64 = np.einsum("br,brd->bd", att64, V)
+    f = lambda a: dev(a.astype(np.float32))
+    km = dev(keep.astype(np.uint8)) if drop else None
+    # without dropout the oracle call above used mask = keep_prob so that mask/keep == 1
+    att, pooled = ops.attn_pool_fwd(f(v), f(qv), f(V), dev(nb), f(w[:, 0]), f(bias), km, 0.8)
+    close(att, att64, 1e-4, 1e-6)
+    close(pooled, p64, 1e-4, 1e-5)
+    assert np.all(att.cpu().numpy()[np.arange(R)[None, :] >= nb[:, None]] == 0)     # masked regions exactly 0
+    dp = rng.standard_normal((B, D))
+    datt = np.einsum("bd,brd->br", dp, V)
+    ds = att64 * (datt - (att64 * datt).sum(1, keepdims=True))
+    m = keep / 0.8 if drop else np.ones_like(keep)
+    dfeat = ds[:, :, None] * w[None, None, :, 0] * m
+    dv64 = dfeat * qv[:, None, :]; dqv64 = (dfeat * v).sum(1)
+    dw64 = np.einsum("br,brh->h", ds, v * qv[:, None, :] * m); db64 = ds.sum()
+    dv, dqv, dw, db = ops.attn_pool_bwd(f(dp), f(v), f(qv), f(V), att, f(w[:, 0]), km, 0.8)
+    close(dv, dv64, 1e-3, 1e-4 * np.abs(dv64).max())
+    close(dqv, dqv64, 1e-3, 1e-4 * np.abs(dqv64).max())
+    close(dw, dw64, 1e-3, 1e-4 * np.abs(dw64).max())
+    assert abs(float(db[0]) - db64) < 1e-4
+
+
+def test_attention_num_box_one_and_zero():
+    rng = np.random.default_rng(9)
+    B, R, H, D = 2, 36, 64, 32
+    f = lambda a: dev(a.astype(np.float32))
+    v = rng.standard_normal((B, R, H)); qv = rng.standard_normal((B, H)); V = rng.standard_normal((B, R, D))
+    att, pooled = ops.attn_pool_fwd(f(v), f(qv), f(V), dev(np.array([1, 0], np.int32)), f(np.ones(H)), f(np.zeros(1)))
+    a = att.cpu().numpy()
+    np.testing.assert_array_equal(a[0], np.eye(R, dtype=np.float32)[0])          # num_box = 1 -> [1,0,...]
+    np.testing.assert_array_equal(pooled.cpu().numpy()[0], V[0, 0].astype(np.float32))
+    assert np.all(np.isnan(a[1]))                                                  # num_box = 0 -> NaN row, as TF
+
+
+@pytest.mark.parametrize("B,A", [(6, 3000), (5, 21), (300, 257)])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard"])
+def test_loss_report_pred_bit_exact_and_dz(B, A, model_type):
+    rng = np.random.default_rng(A)
+    z = rng.standard_normal((B, A)).astype(np.float32) * 3
+    z[0, :] = -100.0                               # all-tie row -> argmax 0
+    if A > 10:
+        z[1, 5] = z[1, 9] = 50.0                   # tie -> first index
+    batch = O.make_batch(rng, B, 4, 10, A, 5)
+    am = O.make_answer_masks(rng, A, int(A * 0.75), exist_all=False)
+    loss, report, out, ell = O.loss_and_report(z.astype(np.float64), batch["answer_target"].astype(np.float64),
+                                               {k: v.astype(np.float64) for k, v in am.items()}, model_type)
+    dm = {k: dev(v) for k, v in am.items()}
+    stats, pred, dz, rep = ops.loss_fwd(dev(z), dev(batch["answer_target"]), dm, model_type == "vlmap_answer")
+    np.testing.assert_array_equal(pred.cpu().numpy(), out["pred"])               # integer: bit exact
+    assert pred.cpu().numpy()[0] == 0
+    for k in O.REPORT_KEYS:
+        assert abs(rep[k] - report[k]) <= 2e-5 * max(1.0, abs(report[k])), (k, rep[k], report[k])
+    dz64 = (O.sigmoid(z.astype(np.float64)) - batch["answer_target"]) / B
+    if model_type == "vlmap_answer":
+        dz64 = dz64 * am["train"]
+    close(dz, dz64, 1e-5, 1e-8)
+    st = stats.cpu().numpy()
+    np.testing.assert_allclose(st[:, 2], out["all_score"], rtol=0, atol=0)
+    np.testing.assert_allclose(st[:, 14], out["max_train_score"], rtol=0, atol=0)
+
+
+def test_colsum_and_sumsq_and_mask():
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((7168, 96)).astype(np.float32)
+    close(ops.colsum(dev(X)), X.astype(np.float64).sum(0), 1e-4, 1e-3)
+    g = rng.standard_normal(1000003).astype(np.float32)
+    buf = torch.zeros(1000004, device="cuda")[:1000003]
+    buf.copy_(dev(g))
+    assert abs(float(ops.sumsq(buf)) / float((g.astype(np.float64) ** 2).sum()) - 1) < 1e-5
+    m1 = ops.dropout_mask(1 << 20, 123, 0, 0.8, "cuda")
+    m2 = ops.dropout_mask(1 << 20, 123, 0, 0.8, "cuda")
+    m3 = ops.dropout_mask(1 << 19, 123, 1 << 19, 0.8, "cuda")
+    assert torch.equal(m1, m2) and torch.equal(m1[1 << 19:], m3)                  # counter based
+    assert abs(float(m1.float().mean()) - 0.8) < 5e-3
+
+
+def test_errors_are_reported_not_swallowed():
+    from vqa_transfer_externaldata_amd import VqaHotError
+    a = torch.zeros(4, 4, device="cuda")
+    with pytest.raises(VqaHotError):
+        ops.gemm(a.t().contiguous(), a, transA=True, transB=True)                 # unsupported layout
+    with pytest.raises(VqaHotError):
+        ops.attn_pool_fwd(torch.zeros(1, 2, 6, device="cuda"), torch.zeros(1, 6, device="cuda"),
+                          torch.zeros(1, 2, 8, device="cuda"), torch.ones(1, dtype=torch.int32, device="cuda"),
+                          torch.zeros(6, device="cuda"), torch.zeros(1, device="cuda"))   # H % 4 != 0

@@ -1,0 +1,112 @@
+"""ctypes binding of libvqahot.so (include/vqa_hot.h).  Fails loudly when the
+library is absent: the product path has no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvqahot.so")
+
+
+class VqaHotError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+class Dims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
+                ("W", C.c_int32), ("A", C.c_int32), ("Vq", C.c_int32), ("N_img", C.c_int64),
+                ("model_type", C.c_int32), ("keep_att", C.c_float), ("keep_joint", C.c_float),
+                ("inv_global_batch", C.c_float)]
+
+
+class Fc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("beta", C.c_void_p), ("gamma", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("embed", C.c_void_p), ("v_linear_v", Fc),
+                ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
+                ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
+                ("joint_fc", Fc), ("head", Fc)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("nbox_table", C.c_void_p), ("image_idx", C.c_void_p),
+                ("q_intseq", C.c_void_p), ("q_intseq_len", C.c_void_p), ("answer_target", C.c_void_p),
+                ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
+                ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/vqa_hot.h
+SIGNATURES = {
+    "vqa_hot_version": (_I, []),
+    "vqa_hot_error_string": (C.c_char_p, [_I]),
+    "vqa_gather_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
+    "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _P]),
+    "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "vqa_ln_relu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
+    "vqa_colsum_workspace_floats": (_L, [_I, _I]),
+    "vqa_mul": (_I, [_P, _P, _P, _L, _P]),
+    "vqa_mul_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "vqa_add_inplace": (_I, [_P, _P, _L, _P]),
+    "vqa_gru_gates_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    "vqa_gru_cand_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "vqa_gru_bwd_a": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
+    "vqa_gru_bwd_b": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "vqa_attn_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_attn_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _P]),
+    "vqa_report_reduce": (_I, [_P, _I, _P, _P]),
+    "vqa_report_key": (C.c_char_p, [_I]),
+    "vqa_sumsq": (_I, [_P, _L, _P, _P, _P, _L, _P]),
+    "vqa_sumsq_workspace_floats": (_L, [_L]),
+    "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
+    "vqa_probe_enable": (_I, [C.c_char_p, _I]),
+    "vqa_probe_read": (_I, [C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]),
+    "vqa_probe_disable": (_I, []),
+    "vqa_fusion_workspace_bytes": (_L, [C.POINTER(Dims)]),
+    "vqa_fusion_tensor": (_I, [C.POINTER(Dims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vqa_fusion_forward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _P, _L, _I, _P]),
+    "vqa_fusion_backward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
+                                 _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded CDLL with typed signatures; raises VqaHotError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise VqaHotError(
+            "libvqahot.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the hot path)" % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the ABI and the header drift apart
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vqa_hot_version() != 1:
+        raise VqaHotError("libvqahot.so ABI version %d != 1" % lib.vqa_hot_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vqa_hot_error_string(rc)
+        raise VqaHotError("%s failed: %s (%d)" % (what, msg.decode() if msg else "?", rc))

@@ -1,0 +1,195 @@
+// Fused Hadamard attention + attention pooling for gfx950 (SURVEY rows a6+a7).
+//
+// Reference: modules.hadamard_attention (vlmap/modules.py:67-97) followed by
+// modules.attention_pooling (vlmap/modules.py:23-39):
+//   s[b,r]   = sum_h (v[b,r,h] * qv[b,h]) * keep[b,r,h]/keep_prob * w[h] + bias
+//   s[r>=nb] = -inf ; att = softmax_R(s) ; pooled[b,:] = sum_r att[b,r] * V[b,r,:]
+//
+// HBM-bound.  One workgroup (4 waves) per sample keeps s/att for the <= 36
+// regions in LDS, so v (147 KB), the keep mask (37 KB) and the raw features V
+// (295 KB) are each read exactly once with 16-byte-per-lane coalesced loads and
+// the scores never leave the CU.  Row dot products use wavefront (64-lane)
+// shuffles; the softmax over R runs in one wave.
+#include "vqa_common.h"
+
+namespace {
+
+constexpr int MAX_R = 1024;
+
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
+    const float* __restrict__ v, const float* __restrict__ qv, const float* __restrict__ V,
+    const int32_t* __restrict__ nb, const float* __restrict__ w, const float* __restrict__ bias,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ att_out, float* __restrict__ pooled, int R,
+    int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // qw[H] | s[R]
+    float* qw = lds;
+    float* s = lds + H;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* vb = v + (int64_t)b * R * H;
+    const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
+    const float* Vb = V + (int64_t)b * R * D;
+
+    for (int h = threadIdx.x; h < H; h += 256) qw[h] = qv[(int64_t)b * H + h] * w[h];
+    __syncthreads();
+
+    const int H4 = H / 4;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        const float* vr = vb + (int64_t)r * H;
+        for (int hu = lane; hu < H4; hu += 64) {
+            const float4 x = reinterpret_cast<const float4*>(vr)[hu];
+            const float4 q = reinterpret_cast<const float4*>(qw)[hu];
+            if (mb != nullptr) {
+                const uchar4 m = reinterpret_cast<const uchar4*>(mb + (int64_t)r * H)[hu];
+                acc += (x.x * q.x * m.x + x.y * q.y * m.y + x.z * q.z * m.z + x.w * q.w * m.w) * inv_keep;
+            } else {
+                acc += x.x * q.x + x.y * q.y + x.z * q.z + x.w * q.w;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s[r] = acc + bias[0];
+    }
+    __syncthreads();
+
+    if (wave == 0) {
+        const int n_valid = nb[b];
+        float mx = -INFINITY;
+        for (int r = lane; r < R; r += 64) {
+            const float x = (r < n_valid) ? s[r] : -INFINITY;
+            s[r] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int r = lane; r < R; r += 64) {
+            const float e = expf(s[r] - mx);  // all -inf (nb == 0) -> NaN, like TF
+            s[r] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        for (int r = lane; r < R; r += 64) {
+            const float a = s[r] / sum;
+            s[r] = a;
+            att_out[(int64_t)b * R + r] = a;
+        }
+    }
+    __syncthreads();
+
+    const int D4 = D / 4;
+    for (int du = threadIdx.x; du < D4; du += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) {
+            const float a = s[r];
+            const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
+            acc.x += a * x.x; acc.y += a * x.y; acc.z += a * x.z; acc.w += a * x.w;
+        }
+        reinterpret_cast<float4*>(pooled + (int64_t)b * D)[du] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
+    const float* __restrict__ dpooled, const float* __restrict__ v, const float* __restrict__ qv,
+    const float* __restrict__ V, const float* __restrict__ att, const float* __restrict__ w,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dv, float* __restrict__ dqv,
+    float* __restrict__ part_dw, float* __restrict__ part_db, int R, int H, int D) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[D] | ds[R]
+    float* dp = lds;
+    float* ds = lds + D;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* vb = v + (int64_t)b * R * H;
+    const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
+    const float* Vb = V + (int64_t)b * R * D;
+
+    for (int d = threadIdx.x; d < D; d += 256) dp[d] = dpooled[(int64_t)b * D + d];
+    __syncthreads();
+
+    // datt[r] = <dpooled[b], V[b,r]>
+    const int D4 = D / 4;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int du = lane; du < D4; du += 64) {
+            const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
+            const float4 g = reinterpret_cast<const float4*>(dp)[du];
+            acc += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) ds[r] = acc;
+    }
+    __syncthreads();
+    // softmax backward: ds = att * (datt - sum(att*datt))
+    if (wave == 0) {
+        float dot = 0.f;
+        for (int r = lane; r < R; r += 64) dot += att[(int64_t)b * R + r] * ds[r];
+        dot = wave_sum(dot);
+        float tot = 0.f;
+        for (int r = lane; r < R; r += 64) {
+            const float g = att[(int64_t)b * R + r] * (ds[r] - dot);
+            ds[r] = g;
+            tot += g;
+        }
+        tot = wave_sum(tot);
+        if (lane == 0) part_db[b] = tot;
+    }
+    __syncthreads();
+
+    const int H4 = H / 4;
+    for (int hu = threadIdx.x; hu < H4; hu += 256) {
+        const float4 q = reinterpret_cast<const float4*>(qv + (int64_t)b * H)[hu];
+        const float4 ww = reinterpret_cast<const float4*>(w)[hu];
+        const float4 qw = make_float4(q.x * ww.x, q.y * ww.y, q.z * ww.z, q.w * ww.w);
+        float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) {
+            float4 g = make_float4(ds[r], ds[r], ds[r], ds[r]);
+            if (mb != nullptr) {
+                const uchar4 m = reinterpret_cast<const uchar4*>(mb + (int64_t)r * H)[hu];
+                g.x *= m.x * inv_keep; g.y *= m.y * inv_keep; g.z *= m.z * inv_keep; g.w *= m.w * inv_keep;
+            }
+            const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
+            S.x += g.x * x.x; S.y += g.y * x.y; S.z += g.z * x.z; S.w += g.w * x.w;
+            reinterpret_cast<float4*>(dv + ((int64_t)b * R + r) * H)[hu] =
+                make_float4(g.x * qw.x, g.y * qw.y, g.z * qw.z, g.w * qw.w);
+        }
+        reinterpret_cast<float4*>(dqv + (int64_t)b * H)[hu] = make_float4(S.x * ww.x, S.y * ww.y, S.z * ww.z, S.w * ww.w);
+        reinterpret_cast<float4*>(part_dw + (int64_t)b * H)[hu] = make_float4(S.x * q.x, S.y * q.y, S.z * q.z, S.w * q.w);
+    }
+}
+
+}  // namespace
+
+extern "C" int vqa_attn_pool_fwd(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
+                                 const float* bias, const uint8_t* keepmask, float keep_prob, float* att,
+                                 float* pooled, int B, int R, int H, int D, void* stream) {
+    VQA_REQUIRE(v && qv && V && nb && w && bias && att && pooled, VQA_ERR_ARG);
+    VQA_REQUIRE(B >= 0 && R > 0 && R <= MAX_R && H > 0 && D > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0 && D % 4 == 0, VQA_ERR_ALIGN);
+    VQA_REQUIRE(vqa_aligned16(v) && vqa_aligned16(V) && vqa_aligned16(pooled), VQA_ERR_ALIGN);
+    VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
+    if (B == 0) return VQA_OK;
+    const size_t lds = (size_t)(H + R) * sizeof(float);
+    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, v, qv, V, nb, w, bias,
+                       keepmask, keepmask ? 1.f / keep_prob : 1.f, att, pooled, R, H, D);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, const float* V,
+                                 const float* att, const float* w, const uint8_t* keepmask, float keep_prob, float* dv,
+                                 float* dqv, float* part_dw, float* part_db, int B, int R, int H, int D, void* stream) {
+    VQA_REQUIRE(dpooled && v && qv && V && att && w && dv && dqv && part_dw && part_db, VQA_ERR_ARG);
+    VQA_REQUIRE(B >= 0 && R > 0 && R <= MAX_R && H > 0 && D > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0 && D % 4 == 0, VQA_ERR_ALIGN);
+    VQA_REQUIRE(vqa_aligned16(v) && vqa_aligned16(V) && vqa_aligned16(dv) && vqa_aligned16(dqv) &&
+                    vqa_aligned16(part_dw) && vqa_aligned16(qv) && vqa_aligned16(w),
+                VQA_ERR_ALIGN);
+    VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
+    if (B == 0) return VQA_OK;
+    const size_t lds = (size_t)(D + R) * sizeof(float);
+    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dpooled, v, qv, V, att, w,
+                       keepmask, keepmask ? 1.f / keep_prob : 1.f, dv, dqv, part_dw, part_db, R, H, D);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}

@@ -1,0 +1,419 @@
+// Host-side composition of the fusion model's forward and backward passes:
+// one call enqueues every kernel of a step on the caller's stream.
+//
+// Forward  = vqa/model_vlmap_answer.py:102-288 (model_standard.py:193-374):
+//   feature gather -> v_linear_v -> embedding -> GRU -> q_linear_v -> Hadamard
+//   attention + pooling -> pooled_linear_l / q_linear_l -> joint_fc (+dropout) ->
+//   answer head -> sigmoid-CE loss, argmax, report.
+// Backward = the autodiff that tf.contrib.layers.optimize_loss builds
+//   (vqa/trainer.py:106-114), hand-derived; frozen variables of model_vlmap_answer
+//   (filter_train_vars, model_vlmap_answer.py:81-89) still propagate dX.
+//
+// Workspace layout is computed from the dims alone, so the host can view named
+// intermediates (mid_result / output of the reference Model) without copies.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "vqa_common.h"
+
+namespace {
+
+struct Entry { const char* name; int64_t off; int64_t n; int esz; };
+
+struct Layout {
+    std::vector<Entry> e;
+    int64_t total = 0;
+    int64_t add(const char* name, int64_t n, int esz = 4) {
+        const int64_t off = total;
+        e.push_back({name, off, n, esz});
+        total += ((n * esz + 255) / 256) * 256;  // 256-B aligned carve
+        return off;
+    }
+    const Entry* find(const char* name) const {
+        for (const auto& x : e)
+            if (strcmp(x.name, name) == 0) return &x;
+        return nullptr;
+    }
+};
+
+int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+Layout make_layout(const vqa_dims_t& d) {
+    Layout L;
+    const int64_t B = d.B, R = d.R, D = d.D, H = d.H, T = d.T, W = d.W, A = d.A;
+    L.add("V_ft", B * R * D);
+    L.add("num_V_ft", B);
+    L.add("pre_v", B * R * H);
+    L.add("v_linear_v", B * R * H);
+    L.add("mean_v", B); L.add("rstd_v", B);
+    L.add("x_tm", T * B * W);
+    L.add("xp", T * B * 3 * H);
+    L.add("hs", (T + 1) * B * H);
+    L.add("gru_r", T * B * H); L.add("gru_u", T * B * H); L.add("gru_c", T * B * H); L.add("gru_rh", T * B * H);
+    L.add("pre_qv", B * H); L.add("q_linear_v", B * H); L.add("mean_qv", B); L.add("rstd_qv", B);
+    L.add("att_score", B * R);
+    L.add("pooled_V_ft", B * D);
+    L.add("pre_pl", B * H); L.add("pooled_linear_l", B * H); L.add("mean_pl", B); L.add("rstd_pl", B);
+    L.add("pre_ll", B * H); L.add("l_linear_l", B * H); L.add("mean_ll", B); L.add("rstd_ll", B);
+    L.add("joint_in", B * H);
+    L.add("pre_j", B * 2 * H); L.add("joint", B * 2 * H); L.add("mean_j", B); L.add("rstd_j", B);
+    L.add("logit", B * A);
+    L.add("stats", B * VQA_STAT_COUNT);
+    L.add("pred", B);
+    L.add("report", 16);
+    L.add("dlogit", B * A);
+    // backward scratch
+    L.add("d_joint", B * 2 * H); L.add("d_pre_j", B * 2 * H);
+    L.add("d_joint_in", B * H);
+    L.add("d_pl", B * H); L.add("d_ll", B * H); L.add("d_pre_pl", B * H); L.add("d_pre_ll", B * H);
+    L.add("d_pooled", B * D);
+    L.add("d_h0", B * H); L.add("d_h1", B * H);
+    L.add("d_v", B * R * H); L.add("d_pre_v", B * R * H);
+    L.add("d_qv", B * H); L.add("d_pre_qv", B * H);
+    L.add("part_a", B * 2 * H); L.add("part_b", B * 2 * H); L.add("part_c", B * 2 * H);
+    L.add("part_dw", B * H); L.add("part_db", B);
+    L.add("dxp", T * B * 3 * H);
+    L.add("d_rh", B * H);
+    L.add("dx_embed", T * B * W);
+    // shared scratch: split-k slabs, colsum partials, sumsq partials
+    int64_t gw = 0;
+    auto g = [&](int64_t M, int64_t N, int64_t K) { gw = max64(gw, vqa_gemm_workspace_floats((int)M, (int)N, (int)K, 0)); };
+    g(B * R, H, D); g(T * B, 2 * H, W); g(T * B, H, W); g(B, 2 * H, H); g(B, H, H); g(B, H, D); g(B, 2 * H, H);
+    g(B, A, 2 * H);                                        // forward
+    g(B, 2 * H, A); g(2 * H, A, B); g(B, H, 2 * H); g(H, 2 * H, B); g(B, D, H); g(D, H, B); g(H, H, B);
+    g(D, H, B * R); g(W, 2 * H, T * B); g(H, 2 * H, T * B); g(W, H, T * B); g(H, H, T * B); g(T * B, W, 2 * H);
+    g(T * B, W, H);                                        // backward
+    L.add("gemm_ws", max64(gw, 4));
+    int64_t cw = 0;
+    cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)(T * B), (int)(3 * H)));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
+    L.add("colsum_ws", max64(cw, 4));
+    L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * B * W), 4));
+    return L;
+}
+
+struct Ctx {
+    const vqa_dims_t& d;
+    Layout L;
+    char* ws;
+    hipStream_t st;
+    float* f(const char* name) const { return reinterpret_cast<float*>(ws + L.find(name)->off); }
+    int32_t* i32(const char* name) const { return reinterpret_cast<int32_t*>(ws + L.find(name)->off); }
+    int64_t gemm_ws_floats() const { return L.find("gemm_ws")->n; }
+    int64_t colsum_ws_floats() const { return L.find("colsum_ws")->n; }
+};
+
+// ---- measurement probe -----------------------------------------------------
+struct Probe {
+    std::string label;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    int used = 0, cap = 0;
+    bool on = false;
+} g_probe;
+
+struct ProbeScope {
+    bool active = false;
+    hipStream_t st;
+    ProbeScope(const char* label, hipStream_t s) : st(s) {
+        if (g_probe.on && g_probe.used < g_probe.cap && g_probe.label == label) {
+            active = true;
+            (void)hipEventRecord(g_probe.ev[2 * g_probe.used], st);
+        }
+    }
+    ~ProbeScope() {
+        if (active) {
+            (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], st);
+            g_probe.used++;
+        }
+    }
+};
+
+#define TRY(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != VQA_OK) return rc__; \
+    } while (0)
+
+int gemm(const Ctx& c, int tA, int tB, int64_t M, int64_t N, int64_t K, const float* A, int lda, const float* B,
+         int ldb, float* C, int ldc, const float* bias = nullptr, const float* D = nullptr, int ldd = 0) {
+    return vqa_gemm_f32(tA, tB, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, bias, D, ldd, 0, c.f("gemm_ws"),
+                        c.gemm_ws_floats(), c.st);
+}
+int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* out) {
+    return vqa_colsum(X, (int)M, (int)N, ldx, out, c.f("colsum_ws"), c.colsum_ws_floats(), c.st);
+}
+
+bool dims_ok(const vqa_dims_t* d) {
+    return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
+           d->N_img > 0 && (d->model_type == 0 || d->model_type == 1);
+}
+
+// FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
+int fc_ln_relu_fwd(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N, const vqa_fc_t& p, int rows,
+                   const char* pre, const char* y, const char* mean, const char* rstd, const uint8_t* keep,
+                   float keep_prob) {
+    {
+        ProbeScope ps(rows > 1 ? "v_linear_v.fwd_gemm" : "fc.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, M, N, K, x, (int)K, p.w, (int)N, c.f(pre), (int)N, p.b));
+    }
+    return vqa_ln_relu_fwd(c.f(pre), p.gamma, p.beta, keep, keep_prob, c.f(y), c.f(mean), c.f(rstd), (int)(M / rows),
+                           rows, (int)N, c.st);
+}
+
+// backward of the same block.  dy -> d_pre (named buffer); optional parameter
+// grads (g.w == NULL => frozen layer); optional dx = d_pre * W^T (+ dx_add).
+int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int64_t K, int64_t N, const vqa_fc_t& p,
+                   const vqa_fc_t* g, int rows, const char* pre, const char* mean, const char* rstd,
+                   const uint8_t* keep, float keep_prob, const char* d_pre, float* dx, bool dx_accumulate) {
+    const bool train = g != nullptr && g->w != nullptr;
+    const int64_t G = M / rows;
+    TRY(vqa_ln_relu_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma, p.beta, keep, keep_prob, c.f(d_pre),
+                        train ? c.f("part_a") : nullptr, train ? c.f("part_b") : nullptr,
+                        train ? c.f("part_c") : nullptr, (int)G, rows, (int)N, c.st));
+    if (train) {
+        TRY(colsum(c, c.f("part_a"), G, N, (int)N, g->gamma));
+        TRY(colsum(c, c.f("part_b"), G, N, (int)N, g->beta));
+        TRY(colsum(c, c.f("part_c"), G, N, (int)N, g->b));
+        ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
+        TRY(gemm(c, 1, 0, K, N, M, x, (int)K, c.f(d_pre), (int)N, g->w, (int)N));  // dW = x^T * d_pre
+    }
+    if (dx != nullptr)
+        TRY(gemm(c, 0, 1, M, K, N, c.f(d_pre), (int)N, p.w, (int)N, dx, (int)K, nullptr,
+                 dx_accumulate ? dx : nullptr, (int)K));
+    return VQA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims) {
+    if (!dims_ok(dims)) return VQA_ERR_ARG;
+    return make_layout(*dims).total;
+}
+
+extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64_t* offset_bytes, int64_t* n_elems) {
+    if (!dims_ok(dims) || name == nullptr) return VQA_ERR_ARG;
+    const Layout L = make_layout(*dims);
+    const char* key = name;
+    if (strcmp(name, "condition") == 0) {  // heavy_output['condition'] = final GRU state = hs[T]
+        const Entry* h = L.find("hs");
+        if (offset_bytes) *offset_bytes = h->off + (int64_t)dims->T * dims->B * dims->H * 4;
+        if (n_elems) *n_elems = (int64_t)dims->B * dims->H;
+        return VQA_OK;
+    }
+    const Entry* e = L.find(key);
+    if (e == nullptr) return VQA_ERR_ARG;
+    if (offset_bytes) *offset_bytes = e->off;
+    if (n_elems) *n_elems = e->n;
+    return VQA_OK;
+}
+
+extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_batch_t* bt,
+                                  void* workspace, int64_t workspace_bytes, int want_dz, void* stream) {
+    VQA_REQUIRE(dims_ok(dims) && P && bt && workspace, VQA_ERR_ARG);
+    Ctx c{*dims, make_layout(*dims), static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
+    VQA_REQUIRE(vqa_aligned16(workspace), VQA_ERR_ALIGN);
+    ProbeScope ps_all("forward", c.st);
+    const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
+
+    // a1: V_ft = features[image_idx]
+    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, c.f("V_ft"), c.i32("num_V_ft"), (int)B, (int)R,
+                            (int)D, dims->N_img, c.st));
+    // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
+    TRY(fc_ln_relu_fwd(c, c.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
+                       nullptr, 1.f));
+    // a3: embedding lookup, time-major
+    TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
+    // a4: GRU.  Input projections of all steps as two big GEMMs ...
+    float* xp = c.f("xp");
+    TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
+    TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+    float* hs = c.f("hs");
+    if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+    const float* Wg_h = P->gru_wg + W * 2 * H;
+    const float* Wc_h = P->gru_wc + W * H;
+    ProbeScope* ps_gru = new ProbeScope("gru.fwd", c.st);
+    struct Del { ProbeScope*& p; ~Del() { delete p; p = nullptr; } } del_gru{ps_gru};
+    for (int64_t t = 0; t < T; ++t) {
+        float* xpt = xp + t * B * 3 * H;
+        const float* hp = hs + t * B * H;
+        float* r = c.f("gru_r") + t * B * H;
+        float* u = c.f("gru_u") + t * B * H;
+        float* cc = c.f("gru_c") + t * B * H;
+        float* rh = c.f("gru_rh") + t * B * H;
+        // ... then per step: gates += h*Wg_h ; r,u = sigmoid ; cand += (r*h)*Wc_h ; blend
+        TRY(gemm(c, 0, 0, B, 2 * H, H, hp, (int)H, Wg_h, (int)(2 * H), xpt, (int)(3 * H), nullptr, xpt, (int)(3 * H)));
+        TRY(vqa_gru_gates_fwd(xpt, (int)(3 * H), hp, r, u, rh, (int)B, (int)H, c.st));
+        TRY(gemm(c, 0, 0, B, H, H, rh, (int)H, Wc_h, (int)H, xpt + 2 * H, (int)(3 * H), nullptr, xpt + 2 * H,
+                 (int)(3 * H)));
+        TRY(vqa_gru_cand_fwd(xpt + 2 * H, (int)(3 * H), u, hp, bt->q_intseq_len, (int)t, cc, hs + (t + 1) * B * H,
+                             (int)B, (int)H, c.st));
+    }
+    delete ps_gru; ps_gru = nullptr;
+    const float* h = hs + T * B * H;
+    // a5
+    TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
+    // a6 + a7
+    {
+    ProbeScope ps("attn_pool.fwd", c.st);
+    TRY(vqa_attn_pool_fwd(c.f("v_linear_v"), c.f("q_linear_v"), c.f("V_ft"), c.i32("num_V_ft"), P->score.w, P->score.b,
+                          bt->keep_att, dims->keep_att, c.f("att_score"), c.f("pooled_V_ft"), (int)B, (int)R, (int)H,
+                          (int)D, c.st));
+    }
+    // a8
+    TRY(fc_ln_relu_fwd(c, c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, 1, "pre_pl", "pooled_linear_l", "mean_pl",
+                       "rstd_pl", nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
+    // a9
+    TRY(vqa_mul(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), B * H, c.st));
+    TRY(fc_ln_relu_fwd(c, c.f("joint_in"), B, H, 2 * H, P->joint_fc, 1, "pre_j", "joint", "mean_j", "rstd_j",
+                       bt->keep_joint, dims->keep_joint));
+    // a10
+    {
+        ProbeScope ps("head.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
+    }
+    // a11
+    TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
+                     dims->model_type == 0 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
+                     want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
+    TRY(vqa_report_reduce(c.f("stats"), (int)B, c.f("report"), c.st));
+    return VQA_OK;
+}
+
+extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_params_t* G,
+                                   const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
+                                   float* embed_slice_sq, void* stream) {
+    VQA_REQUIRE(dims_ok(dims) && P && G && bt && workspace, VQA_ERR_ARG);
+    Ctx c{*dims, make_layout(*dims), static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
+    ProbeScope ps_all("backward", c.st);
+    const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
+    const float* hs = c.f("hs");
+    const float* h = hs + T * B * H;
+
+    // head: logit = joint*W + b
+    if (G->head.w != nullptr) {
+        TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit"), (int)A, G->head.w, (int)A));
+        TRY(colsum(c, c.f("dlogit"), B, A, (int)A, G->head.b));
+    }
+    TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head.w, (int)A, c.f("d_joint"), (int)(2 * H)));
+    // joint_fc (dropout mask folded into the LN/ReLU backward)
+    TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("joint_in"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j", "mean_j",
+                       "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_joint_in"), false));
+    TRY(vqa_mul_bwd(c.f("d_joint_in"), c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("d_pl"), c.f("d_ll"), B * H,
+                    c.st));
+    TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
+                       "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));
+    float* dh = c.f("d_h0");
+    TRY(fc_ln_relu_bwd(c, c.f("d_ll"), h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll",
+                       nullptr, 1.f, "d_pre_ll", dh, false));
+    // attention + pooling
+    {
+    ProbeScope ps("attn_pool.bwd", c.st);
+    TRY(vqa_attn_pool_bwd(c.f("d_pooled"), c.f("v_linear_v"), c.f("q_linear_v"), c.f("V_ft"), c.f("att_score"),
+                          P->score.w, bt->keep_att, dims->keep_att, c.f("d_v"), c.f("d_qv"), c.f("part_dw"),
+                          c.f("part_db"), (int)B, (int)R, (int)H, (int)D, c.st));
+    }
+    if (G->score.w != nullptr) {
+        TRY(colsum(c, c.f("part_dw"), B, H, (int)H, G->score.w));
+        TRY(colsum(c, c.f("part_db"), B, 1, 1, G->score.b));
+    }
+    // v_linear_v: parameters only (V_ft is an input)
+    TRY(fc_ln_relu_bwd(c, c.f("d_v"), c.f("V_ft"), B * R, D, H, P->v_linear_v, &G->v_linear_v, (int)R, "pre_v", "mean_v",
+                       "rstd_v", nullptr, 1.f, "d_pre_v", nullptr, false));
+    // q_linear_v: dh += ...
+    TRY(fc_ln_relu_bwd(c, c.f("d_qv"), h, B, H, H, P->q_linear_v, &G->q_linear_v, 1, "pre_qv", "mean_qv", "rstd_qv",
+                       nullptr, 1.f, "d_pre_qv", dh, true));
+
+    // GRU back-propagation through time
+    float* dxp = c.f("dxp");
+    float* dh_cur = dh;
+    float* dh_nxt = c.f("d_h1");
+    const float* Wg_h = P->gru_wg + W * 2 * H;
+    const float* Wc_h = P->gru_wc + W * H;
+    ProbeScope* ps_gru = new ProbeScope("gru.bwd", c.st);
+    struct Del { ProbeScope*& p; ~Del() { delete p; p = nullptr; } } del_gru{ps_gru};
+    for (int64_t t = T - 1; t >= 0; --t) {
+        float* dxpt = dxp + t * B * 3 * H;
+        const float* hp = hs + t * B * H;
+        const float* r = c.f("gru_r") + t * B * H;
+        const float* u = c.f("gru_u") + t * B * H;
+        const float* cc = c.f("gru_c") + t * B * H;
+        TRY(vqa_gru_bwd_a(dh_cur, hp, u, cc, bt->q_intseq_len, (int)t, dxpt + 2 * H, (int)(3 * H), dxpt + H,
+                          (int)(3 * H), dh_nxt, (int)B, (int)H, c.st));
+        TRY(gemm(c, 0, 1, B, H, H, dxpt + 2 * H, (int)(3 * H), Wc_h, (int)H, c.f("d_rh"), (int)H));
+        TRY(vqa_gru_bwd_b(c.f("d_rh"), hp, r, dxpt, (int)(3 * H), dh_nxt, (int)B, (int)H, c.st));
+        TRY(gemm(c, 0, 1, B, H, 2 * H, dxpt, (int)(3 * H), Wg_h, (int)(2 * H), dh_nxt, (int)H, nullptr, dh_nxt,
+                 (int)H));
+        float* tmp = dh_cur; dh_cur = dh_nxt; dh_nxt = tmp;
+    }
+    delete ps_gru; ps_gru = nullptr;
+    if (G->gru_wg != nullptr) {
+        TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
+        TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
+        TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)W, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
+        TRY(gemm(c, 1, 0, H, H, T * B, c.f("gru_rh"), (int)H, dxp + 2 * H, (int)(3 * H), G->gru_wc + W * H, (int)H));
+        TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
+        TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
+    }
+    // embedding: un-aggregated slices dx [T,B,W], then scatter-add
+    float* dx = c.f("dx_embed");
+    TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
+    TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+    if (G->embed != nullptr) TRY(vqa_embed_bwd(dx, bt->q_intseq, G->embed, (int)B, (int)T, (int)W, dims->Vq, c.st));
+    if (embed_slice_sq != nullptr)
+        TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
+    return VQA_OK;
+}
+
+extern "C" int vqa_probe_enable(const char* label, int max_samples) {
+    VQA_REQUIRE(label != nullptr && max_samples > 0 && max_samples <= 4096, VQA_ERR_ARG);
+    vqa_probe_disable();
+    g_probe.ev.resize(2 * (size_t)max_samples);
+    for (auto& e : g_probe.ev)
+        if (hipEventCreate(&e) != hipSuccess) return VQA_ERR_LAUNCH;
+    g_probe.label = label;
+    g_probe.cap = max_samples;
+    g_probe.used = 0;
+    g_probe.on = true;
+    return VQA_OK;
+}
+
+extern "C" int vqa_probe_read(float* ms_out, int capacity, int* n_out) {
+    VQA_REQUIRE(ms_out != nullptr && n_out != nullptr && capacity >= 0, VQA_ERR_ARG);
+    int n = 0;
+    for (int i = 0; i < g_probe.used && n < capacity; ++i) {
+        if (hipEventSynchronize(g_probe.ev[2 * i + 1]) != hipSuccess) return VQA_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) return VQA_ERR_LAUNCH;
+        ms_out[n++] = ms;
+    }
+    *n_out = n;
+    return VQA_OK;
+}
+
+extern "C" int vqa_probe_disable(void) {
+    for (auto& e : g_probe.ev) (void)hipEventDestroy(e);
+    g_probe.ev.clear();
+    g_probe.on = false;
+    g_probe.used = g_probe.cap = 0;
+    return VQA_OK;
+}
+
+extern "C" int vqa_hot_version(void) { return VQA_HOT_ABI_VERSION; }
+
+extern "C" const char* vqa_hot_error_string(int code) {
+    switch (code) {
+        case VQA_OK: return "ok";
+        case VQA_ERR_ARG: return "bad argument (size or null pointer)";
+        case VQA_ERR_ALIGN: return "pointer / leading dimension not aligned";
+        case VQA_ERR_LAUNCH: return "kernel launch failed";
+        case VQA_ERR_UNSUPPORTED: return "unsupported configuration";
+        case VQA_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,265 @@
+// Loss / metrics and the optimiser (row a12) for gfx950.
+//
+// Loss: tf.nn.sigmoid_cross_entropy_with_logits x train mask, argmax (first
+// maximum on ties), one-hot VQA scores and the masked max-scores that feed the 13
+// report scalars -- vqa/model_vlmap_answer.py:192-288 (model_standard.py:281-374).
+// One workgroup per sample streams logits+targets once (HBM-bound, 24 KB/sample)
+// and optionally emits dz = (sigmoid(z)-t)*mask/B for the backward pass in the
+// same sweep.
+//
+// Optimiser: tf.contrib.layers.optimize_loss(Adam, clip_gradients=20.0)
+// (vqa/trainer.py:106-114) = clip_by_global_norm then Adam, on flat buffers.
+#include "vqa_common.h"
+
+namespace {
+
+struct ArgMax { float v; int i; };
+
+__device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b) {
+    // larger value wins; on ties the LOWER index (tf.argmax returns the first maximum)
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tgt,
+                                                       const float* __restrict__ train_m,
+                                                       const float* __restrict__ obj_m,
+                                                       const float* __restrict__ attr_m,
+                                                       const float* __restrict__ exist_m, int use_train_mask,
+                                                       float inv_batch, float* __restrict__ stats,
+                                                       int32_t* __restrict__ pred, float* __restrict__ dz, int A) {
+    __shared__ float red[16];
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* zb = z + (int64_t)b * A;
+    const float* tb = tgt + (int64_t)b * A;
+
+    float l_train = 0.f, l_all = 0.f;
+    // masked maxima start at the value of a fully masked row: max(tgt*0) = 0 only if A > 0
+    float mx_exist = -INFINITY, mx_train_exist = -INFINITY, mx_tobj = -INFINITY, mx_tattr = -INFINITY,
+          mx_test = -INFINITY, mx_test_exist = -INFINITY, mx_train = -INFINITY;
+    ArgMax am{-INFINITY, 0x7fffffff};
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float x = zb[a], t = tb[a];
+        const float tr = train_m[a], te = 1.f - tr, ob = obj_m[a], at = attr_m[a], ex = exist_m[a];
+        const float ell = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        l_all += ell;
+        l_train += ell * tr;
+        if (dz != nullptr) {
+            float g = (sigmoidf_stable(x) - t) * inv_batch;
+            if (use_train_mask) g *= tr;
+            dz[(int64_t)b * A + a] = g;
+        }
+        if (x > am.v) { am.v = x; am.i = a; }  // strided ascending a per thread: first max kept
+        mx_exist = fmaxf(mx_exist, t * ex);
+        mx_train_exist = fmaxf(mx_train_exist, t * ex * tr);
+        mx_tobj = fmaxf(mx_tobj, t * te * ob);
+        mx_tattr = fmaxf(mx_tattr, t * te * at);
+        mx_test = fmaxf(mx_test, t * te);
+        mx_test_exist = fmaxf(mx_test_exist, t * ex * te);
+        mx_train = fmaxf(mx_train, t * tr);
+    }
+    // argmax: wave shuffle reduce then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax other{__shfl_xor(am.v, o, 64), __shfl_xor(am.i, o, 64)};
+        am = argmax_combine(am, other);
+    }
+    if (lane == 0) { redv[wave] = am.v; redi[wave] = am.i; }
+    l_all = block_sum(l_all, red);       // (contains __syncthreads: redv/redi visible after it)
+    l_train = block_sum(l_train, red);
+    ArgMax best{redv[0], redi[0]};
+    for (int k = 1; k < 4; ++k) best = argmax_combine(best, ArgMax{redv[k], redi[k]});
+    int p = best.i;
+    if (p < 0 || p >= A) p = 0;  // all-NaN row: tf.argmax returns 0
+    auto bmax = [&](float x) {
+        x = wave_max(x);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    mx_exist = bmax(mx_exist);
+    mx_train_exist = bmax(mx_train_exist);
+    mx_tobj = bmax(mx_tobj);
+    mx_tattr = bmax(mx_tattr);
+    mx_test = bmax(mx_test);
+    mx_test_exist = bmax(mx_test_exist);
+    mx_train = bmax(mx_train);
+    if (threadIdx.x == 0) {
+        const float tp = tb[p];
+        const float tr = train_m[p], te = 1.f - tr, ob = obj_m[p], at = attr_m[p], ex = exist_m[p];
+        float* s = stats + (int64_t)b * VQA_STAT_COUNT;
+        s[VQA_STAT_LOSS_TRAIN] = use_train_mask ? l_train : l_all;
+        s[VQA_STAT_LOSS_REPORT] = l_all;
+        s[VQA_STAT_ALL_SCORE] = tp;
+        s[VQA_STAT_EXIST_SCORE] = tp * ex;
+        s[VQA_STAT_TEST_SCORE] = tp * te;
+        s[VQA_STAT_TEST_OBJ_SCORE] = tp * te * ob;
+        s[VQA_STAT_TEST_ATTR_SCORE] = tp * te * at;
+        s[VQA_STAT_TRAIN_EXIST_SCORE] = tp * ex * tr;
+        s[VQA_STAT_MAX_EXIST] = mx_exist;
+        s[VQA_STAT_MAX_TRAIN_EXIST] = mx_train_exist;
+        s[VQA_STAT_TEST_OBJ_MAX] = mx_tobj;
+        s[VQA_STAT_TEST_ATTR_MAX] = mx_tattr;
+        s[VQA_STAT_TEST_MAX] = mx_test;
+        s[VQA_STAT_TEST_MAX_EXIST] = mx_test_exist;
+        s[VQA_STAT_MAX_TRAIN] = mx_train;
+        s[15] = 0.f;
+        pred[b] = p;
+    }
+}
+
+// report[13]: means over the batch + guarded ratios  where(den == 0, den, num/den)
+__global__ __launch_bounds__(256) void report_reduce_kernel(const float* __restrict__ stats, int B,
+                                                            float* __restrict__ report) {
+    __shared__ float red[16];
+    __shared__ float mean[VQA_STAT_COUNT];
+    for (int k = 0; k < VQA_STAT_COUNT; ++k) {
+        float s = 0.f;
+        for (int b = threadIdx.x; b < B; b += 256) s += stats[(int64_t)b * VQA_STAT_COUNT + k];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) mean[k] = s / (float)B;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        auto ratio = [](float num, float den) { return den == 0.f ? den : num / den; };
+        report[0] = mean[VQA_STAT_LOSS_TRAIN];
+        report[1] = mean[VQA_STAT_LOSS_REPORT];
+        report[2] = mean[VQA_STAT_ALL_SCORE];
+        report[3] = mean[VQA_STAT_EXIST_SCORE];
+        report[4] = mean[VQA_STAT_TEST_SCORE];
+        report[5] = ratio(mean[VQA_STAT_TEST_SCORE], mean[VQA_STAT_TEST_MAX]);
+        report[6] = ratio(mean[VQA_STAT_TEST_OBJ_SCORE], mean[VQA_STAT_TEST_OBJ_MAX]);
+        report[7] = ratio(mean[VQA_STAT_TEST_ATTR_SCORE], mean[VQA_STAT_TEST_ATTR_MAX]);
+        report[8] = ratio(mean[VQA_STAT_EXIST_SCORE], mean[VQA_STAT_MAX_EXIST]);
+        report[9] = ratio(mean[VQA_STAT_TRAIN_EXIST_SCORE], mean[VQA_STAT_MAX_TRAIN_EXIST]);
+        report[10] = mean[VQA_STAT_MAX_EXIST];
+        report[11] = mean[VQA_STAT_TEST_MAX];
+        report[12] = mean[VQA_STAT_TEST_MAX_EXIST];
+    }
+}
+
+// ------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = reinterpret_cast<const float4*>(g)[i];
+        s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int nparts,
+                                                          const float* __restrict__ extra, float* __restrict__ out) {
+    __shared__ double redd[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = redd[0] + redd[1] + redd[2] + redd[3];
+        if (extra != nullptr) t += (double)extra[0];
+        out[0] = (float)t;
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        const float* __restrict__ norm_sq, float clip, float lr_t,
+                                                        float b1, float b2, float eps) {
+    // clip_by_global_norm: g * clip / max(norm, clip)
+    const float scale = (norm_sq != nullptr) ? clip / fmaxf(sqrtf(norm_sq[0]), clip) : 1.f;
+    const int64_t n4 = n / 4;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* Vv = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gs = G[j] * scale;
+            M[j] = b1 * M[j] + (1.f - b1) * gs;
+            Vv[j] = b2 * Vv[j] + (1.f - b2) * gs * gs;
+            P[j] -= lr_t * M[j] / (sqrtf(Vv[j]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float gs = g[i] * scale;
+            m[i] = b1 * m[i] + (1.f - b1) * gs;
+            v[i] = b2 * v[i] + (1.f - b2) * gs * gs;
+            p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+        }
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int sumsq_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256 * 4), 1024)); }
+
+const char* const kReportKeys[VQA_REPORT_COUNT] = {
+    "answer_train_loss", "answer_report_loss", "answer_acc", "exist_acc", "test_acc", "normal_test_acc",
+    "normal_test_object_acc", "normal_test_attribute_acc", "normal_exist_acc", "normal_train_exist_acc",
+    "max_exist_acc", "test_max_acc", "test_max_exist_acc"};
+
+}  // namespace
+
+extern "C" const char* vqa_report_key(int i) { return (i >= 0 && i < VQA_REPORT_COUNT) ? kReportKeys[i] : nullptr; }
+
+extern "C" int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, const float* obj_mask,
+                            const float* attr_mask, const float* exist_mask, int use_train_mask_in_loss,
+                            float inv_batch, float* stats, int32_t* pred, float* dz, int B, int A, void* stream) {
+    VQA_REQUIRE(z && target && train_mask && obj_mask && attr_mask && exist_mask && stats && pred, VQA_ERR_ARG);
+    VQA_REQUIRE(B >= 0 && A > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z, target, train_mask, obj_mask,
+                       attr_mask, exist_mask, use_train_mask_in_loss, inv_batch, stats, pred, dz, A);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_report_reduce(const float* stats, int B, float* report, void* stream) {
+    VQA_REQUIRE(stats && report && B > 0, VQA_ERR_ARG);
+    hipLaunchKernelGGL(report_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, B, report);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int64_t vqa_sumsq_workspace_floats(int64_t n) { return sumsq_blocks(n); }
+
+extern "C" int vqa_sumsq(const float* g, int64_t n, const float* extra_sq, float* norm_sq_out, float* partial,
+                         int64_t partial_floats, void* stream) {
+    VQA_REQUIRE(g && norm_sq_out && partial && n >= 0, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_aligned16(g), VQA_ERR_ALIGN);
+    const int nb = sumsq_blocks(n);
+    VQA_REQUIRE(partial_floats >= nb, VQA_ERR_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, partial);
+    VQA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, extra_sq, norm_sq_out);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
+                             float clip, float lr_t, float beta1, float beta2, float eps, void* stream) {
+    VQA_REQUIRE(p && g && m && v && n >= 0, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_aligned16(p) && vqa_aligned16(g) && vqa_aligned16(m) && vqa_aligned16(v), VQA_ERR_ALIGN);
+    if (n == 0) return VQA_OK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4 + 1, 256), 4096));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm_sq, clip,
+                       lr_t, beta1, beta2, eps);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}

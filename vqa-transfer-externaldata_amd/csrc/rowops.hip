@@ -1,0 +1,308 @@
+// HBM-bound row / elementwise kernels of the fusion model (gfx950):
+// feature-table gather (a1), embedding gather + scatter-add (a3), Hadamard
+// products, GRU gate math (a4), column sums for bias / LN-parameter gradients,
+// and the reproducible dropout keep-mask.
+// All loads/stores are 16 B per lane where the row length allows it.
+#include "vqa_common.h"
+
+namespace {
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int grid_for(int64_t work_items, int cap = 4096) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(work_items, 256), cap));
+}
+
+// ------------------------------------------------------------------ a1
+// One workgroup per (sample, region-chunk): rows of D floats are copied with
+// float4 loads; the table row index is wave-uniform.
+__global__ __launch_bounds__(256) void gather_features_kernel(const float* __restrict__ table,
+                                                              const int32_t* __restrict__ nbox_table,
+                                                              const int64_t* __restrict__ idx, float* __restrict__ V,
+                                                              int32_t* __restrict__ nb, int B, int64_t row_floats,
+                                                              int64_t N) {
+    const int b = blockIdx.x;
+    int64_t src = idx[b];
+    if (src < 0) src = 0;
+    if (src >= N) src = N - 1;  // np.take would raise; clamp instead of faulting
+    if (blockIdx.y == 0 && threadIdx.x == 0 && nb != nullptr) nb[b] = nbox_table[src];
+    const float* s = table + src * row_floats;
+    float* d = V + (int64_t)b * row_floats;
+    const int64_t n4 = row_floats / 4;
+    for (int64_t i = blockIdx.y * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.y * 256)
+        reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+    if (blockIdx.y == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < row_floats; i += 256) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------ a3
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ q,
+                                                        float* __restrict__ x, int B, int T, int W, int Vq) {
+    // one wave per token; x is time-major [T,B,W]
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= B * T) return;
+    const int t = tok / B, b = tok % B;
+    int id = q[b * T + t];
+    id = min(max(id, 0), Vq - 1);
+    const float* s = E + (int64_t)id * W;
+    float* d = x + (int64_t)tok * W;
+    for (int i = threadIdx.x & 63; i < W; i += 64) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ q,
+                                                        float* __restrict__ dE, int B, int T, int W, int Vq) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= B * T) return;
+    const int t = tok / B, b = tok % B;
+    int id = q[b * T + t];
+    id = min(max(id, 0), Vq - 1);
+    const float* s = dx + (int64_t)tok * W;
+    float* d = dE + (int64_t)id * W;
+    for (int i = threadIdx.x & 63; i < W; i += 64) atomicAdd(d + i, s[i]);
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ z, int64_t n) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) z[i] = a[i] * b[i];
+}
+__global__ __launch_bounds__(256) void mul_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ a,
+                                                      const float* __restrict__ b, float* __restrict__ da,
+                                                      float* __restrict__ db, int64_t n) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float g = dz[i], av = a[i], bv = b[i];
+        da[i] = g * bv;
+        db[i] = g * av;
+    }
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ acc, const float* __restrict__ x,
+                                                          int64_t n) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc[i] += x[i];
+}
+
+// ------------------------------------------------------------------ a4 (GRU gate math)
+__global__ __launch_bounds__(256) void gru_gates_fwd_kernel(const float* __restrict__ gpre, int ldg,
+                                                            const float* __restrict__ h_prev, float* __restrict__ r,
+                                                            float* __restrict__ u, float* __restrict__ rh, int B,
+                                                            int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), k = (int)(i % H);
+        const float rv = sigmoidf_stable(gpre[(int64_t)b * ldg + k]);
+        const float uv = sigmoidf_stable(gpre[(int64_t)b * ldg + H + k]);
+        r[i] = rv;
+        u[i] = uv;
+        rh[i] = rv * h_prev[i];
+    }
+}
+__global__ __launch_bounds__(256) void gru_cand_fwd_kernel(const float* __restrict__ cpre, int ldc,
+                                                           const float* __restrict__ u,
+                                                           const float* __restrict__ h_prev,
+                                                           const int32_t* __restrict__ len, int t,
+                                                           float* __restrict__ c, float* __restrict__ h_new, int B,
+                                                           int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), k = (int)(i % H);
+        const float cv = tanhf(cpre[(int64_t)b * ldc + k]);
+        const float hp = h_prev[i], uv = u[i];
+        c[i] = cv;
+        h_new[i] = (t < len[b]) ? (uv * hp + (1.f - uv) * cv) : hp;
+    }
+}
+__global__ __launch_bounds__(256) void gru_bwd_a_kernel(const float* __restrict__ dh, const float* __restrict__ h_prev,
+                                                        const float* __restrict__ u, const float* __restrict__ c,
+                                                        const int32_t* __restrict__ len, int t,
+                                                        float* __restrict__ dc_pre, int ld_dc,
+                                                        float* __restrict__ du_pre, int ld_du,
+                                                        float* __restrict__ dh_acc, int B, int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), k = (int)(i % H);
+        const bool live = t < len[b];
+        const float g = dh[i], uv = u[i], cv = c[i], hp = h_prev[i];
+        dc_pre[(int64_t)b * ld_dc + k] = live ? g * (1.f - uv) * (1.f - cv * cv) : 0.f;
+        du_pre[(int64_t)b * ld_du + k] = live ? g * (hp - cv) * uv * (1.f - uv) : 0.f;
+        dh_acc[i] = live ? g * uv : g;
+    }
+}
+__global__ __launch_bounds__(256) void gru_bwd_b_kernel(const float* __restrict__ drh, const float* __restrict__ h_prev,
+                                                        const float* __restrict__ r, float* __restrict__ dr_pre,
+                                                        int ld_dr, float* __restrict__ dh_acc, int B, int H) {
+    const int64_t n = (int64_t)B * H;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / H), k = (int)(i % H);
+        const float g = drh[i], rv = r[i];
+        dr_pre[(int64_t)b * ld_dr + k] = g * h_prev[i] * rv * (1.f - rv);
+        dh_acc[i] += g * rv;
+    }
+}
+
+// ------------------------------------------------------------------ column sums
+// partial[y][n] = sum over the rows of chunk y.  Block = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                     float* __restrict__ out, int rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+    float s = 0.f;
+    if (col < N)
+        for (int m = m0 + ry; m < m1; m += 4) s += X[(int64_t)m * ldx + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < N) out[(int64_t)blockIdx.y * N + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+// ------------------------------------------------------------------ dropout keep-mask
+// Counter-based generator (splitmix64 finaliser on seed ^ counter): the mask of
+// element i depends only on (seed, offset + i), so forward, backward and the test
+// harness regenerate identical masks.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint64_t seed,
+                                                           uint64_t offset, float keep) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t r = mix64(mix64(seed) ^ (offset + (uint64_t)i));
+        const float uni = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24-bit uniform in [0,1)
+        out[i] = uni < keep ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int vqa_gather_features(const float* table, const int32_t* nbox_table, const int64_t* idx, float* V,
+                                   int32_t* nb, int B, int R, int D, int64_t N, void* stream) {
+    VQA_REQUIRE(table && idx && V && B >= 0 && R > 0 && D > 0 && N > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(nb == nullptr || nbox_table != nullptr, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_aligned16(table) && vqa_aligned16(V) && ((int64_t)R * D) % 4 == 0, VQA_ERR_ALIGN);
+    if (B == 0) return VQA_OK;
+    const int64_t row = (int64_t)R * D;
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(row / 4, 256 * 4), 16));
+    hipLaunchKernelGGL(gather_features_kernel, dim3(B, chunks), dim3(256), 0, (hipStream_t)stream, table, nbox_table,
+                       idx, V, nb, B, row, N);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq,
+                             void* stream) {
+    VQA_REQUIRE(E && q && x_tm && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
+    if (B * T == 0) return VQA_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, E, q, x_tm, B, T,
+                       W, Vq);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq,
+                             void* stream) {
+    VQA_REQUIRE(dx_tm && q && dE && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
+    if (B * T == 0) return VQA_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx_tm, q, dE, B, T,
+                       W, Vq);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_mul(const float* a, const float* b, float* z, int64_t n, void* stream) {
+    VQA_REQUIRE(a && b && z && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, z, n);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_mul_bwd(const float* dz, const float* a, const float* b, float* da, float* db, int64_t n,
+                           void* stream) {
+    VQA_REQUIRE(dz && a && b && da && db && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(mul_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dz, a, b, da, db, n);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_add_inplace(float* acc, const float* x, int64_t n, void* stream) {
+    VQA_REQUIRE(acc && x && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, acc, x, n);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gru_gates_fwd(const float* gpre, int ldg, const float* h_prev, float* r, float* u, float* rh,
+                                 int B, int H, void* stream) {
+    VQA_REQUIRE(gpre && h_prev && r && u && rh && ldg >= 2 * H && B >= 0 && H > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(grid_for((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, gpre,
+                       ldg, h_prev, r, u, rh, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_gru_cand_fwd(const float* cpre, int ldc, const float* u, const float* h_prev, const int32_t* len,
+                                int t, float* c, float* h_new, int B, int H, void* stream) {
+    VQA_REQUIRE(cpre && u && h_prev && len && c && h_new && ldc >= H && B >= 0 && H > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_cand_fwd_kernel, dim3(grid_for((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, cpre,
+                       ldc, u, h_prev, len, t, c, h_new, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_gru_bwd_a(const float* dh, const float* h_prev, const float* u, const float* c,
+                             const int32_t* len, int t, float* dc_pre, int ld_dc, float* du_pre, int ld_du,
+                             float* dh_acc, int B, int H, void* stream) {
+    VQA_REQUIRE(dh && h_prev && u && c && len && dc_pre && du_pre && dh_acc && ld_dc >= H && ld_du >= H && B >= 0 &&
+                    H > 0,
+                VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, dh, h_prev,
+                       u, c, len, t, dc_pre, ld_dc, du_pre, ld_du, dh_acc, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_gru_bwd_b(const float* drh, const float* h_prev, const float* r, float* dr_pre, int ld_dr,
+                             float* dh_acc, int B, int H, void* stream) {
+    VQA_REQUIRE(drh && h_prev && r && dr_pre && dh_acc && ld_dr >= H && B >= 0 && H > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_bwd_b_kernel, dim3(grid_for((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, drh,
+                       h_prev, r, dr_pre, ld_dr, dh_acc, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+namespace {
+int colsum_chunks(int M) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(M, 64), 64)); }
+}
+extern "C" int64_t vqa_colsum_workspace_floats(int M, int N) {
+    const int ch = colsum_chunks(M);
+    return ch > 1 ? (int64_t)ch * N : 0;
+}
+extern "C" int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+                          int64_t workspace_floats, void* stream) {
+    VQA_REQUIRE(X && out && M >= 0 && N > 0 && ldx >= N, VQA_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const int ch = colsum_chunks(std::max(M, 1));
+    const int gx = (N + 63) / 64;
+    if (ch == 1 || workspace == nullptr) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, X, M, N, ldx, out, std::max(M, 1));
+        VQA_CHECK_LAUNCH();
+        return VQA_OK;
+    }
+    VQA_REQUIRE(workspace_floats >= (int64_t)ch * N, VQA_ERR_WORKSPACE);
+    const int rpc = (int)cdiv(M, ch);
+    const int ch2 = (int)cdiv(M, rpc);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, ch2), dim3(256), 0, st, X, M, N, ldx, workspace, rpc);
+    VQA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, ch2, N, N, out, ch2);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, float keep_prob,
+                                void* stream) {
+    VQA_REQUIRE(out && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset,
+                       keep_prob);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}

@@ -1,0 +1,318 @@
+"""Device-side engine of the fusion model: owns the flat parameter / gradient /
+Adam-state buffers and the kernel workspace, and drives libvqahot.so.
+
+Replaces what `session.run([loss, report, optimizer])` does in the reference
+(vqa/trainer.py:275-287): forward + backward + clip_by_global_norm(20) + Adam of
+vqa/model_vlmap_answer.py / vqa/model_standard.py.  Variable names are the
+reference's TF variable names -- they are the checkpoint and
+transfer contract.
+
+Memory layout in HBM (all fp32):
+  train_flat  = [LearnGloVe/embed_map | every other trainable var, name order]
+  grad_flat   = same layout + 4 trailing floats; slot 0 of the tail carries the
+                un-aggregated embedding-slice sum of squares so that ONE
+                all-reduce moves gradients and that scalar under data parallel
+  m_flat, v_flat = Adam moments, same layout as train_flat
+  frozen_flat = variables excluded by filter_train_vars (vlmap_answer only)
+  workspace   = activations + backward scratch, carved by the library
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8     # tf.train.AdamOptimizer defaults
+CLIP_NORM = 20.0                                   # vqa/trainer.py:111
+
+FROZEN_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer")
+TRANSFER_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc")
+
+_INT_TENSORS = {"num_V_ft", "pred"}
+
+
+def scope_names(model_type):
+    """logical layer -> TF variable scope (vqa/model_vlmap_answer.py:126-185,
+    vqa/model_standard.py:223-275)."""
+    if model_type == "vlmap_answer":
+        pre, head = "", "WordWeightAnswer"
+    elif model_type == "standard":
+        pre, head = "reasoning/", "reasoning/classifier"
+    else:
+        raise ValueError("unknown model_type %r" % (model_type,))
+    return {"embed": "LearnGloVe/embed_map", "v_linear_v": "v_linear_v",
+            "gru_gates": "encode_L/rnn/gru_cell/gates", "gru_cand": "encode_L/rnn/gru_cell/candidate",
+            "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
+            "pooled_linear_l": pre + "pooled_linear_l", "q_linear_l": pre + "q_linear_l",
+            "joint_fc": pre + "joint_fc", "head": head}
+
+
+def variable_shapes(model_type, Vq, W, D, H, A):
+    """name -> shape for every variable of the model."""
+    sc = scope_names(model_type)
+    s = {sc["embed"]: (Vq, W)}
+
+    def fc(scope, fin, fout, ln):
+        s[scope + "/fc/weights"] = (fin, fout)
+        s[scope + "/fc/biases"] = (fout,)
+        if ln:
+            s[scope + "/LayerNorm/beta"] = (fout,)
+            s[scope + "/LayerNorm/gamma"] = (fout,)
+
+    fc(sc["v_linear_v"], D, H, True)
+    s[sc["gru_gates"] + "/kernel"] = (W + H, 2 * H)
+    s[sc["gru_gates"] + "/bias"] = (2 * H,)
+    s[sc["gru_cand"] + "/kernel"] = (W + H, H)
+    s[sc["gru_cand"] + "/bias"] = (H,)
+    fc(sc["q_linear_v"], H, H, True)
+    fc(sc["score"], H, 1, False)
+    fc(sc["pooled_linear_l"], D, H, True)
+    fc(sc["q_linear_l"], H, H, True)
+    fc(sc["joint_fc"], H, 2 * H, True)
+    fc(sc["head"], 2 * H, A, False)
+    return s
+
+
+def filter_train_vars(names, model_type):
+    """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
+    if model_type == "standard":
+        return list(names)
+    return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
+
+
+def filter_transfer_vars(names, model_type):
+    """vqa/model_vlmap_answer.py:91-100 / vqa/model_standard.py:86-93."""
+    if model_type == "standard":
+        return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
+    return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class FusionEngine:
+    def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
+                 keep_att=0.8, keep_joint=0.5, global_batch=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
+        self.device = torch.device(device)
+        self.model_type = model_type
+        self.sc = scope_names(model_type)
+        self.dims = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N_img,
+                              model_type=0 if model_type == "vlmap_answer" else 1,
+                              keep_att=keep_att, keep_joint=keep_joint,
+                              inv_global_batch=1.0 / float(global_batch or B))
+        self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
+        names = sorted(self.shapes)
+        embed = self.sc["embed"]
+        train = filter_train_vars(names, model_type)
+        self.train_names = [embed] + [n for n in train if n != embed]
+        self.frozen_names = [n for n in names if n not in train]
+
+        def carve(name_list):
+            off, table = 0, {}
+            for n in name_list:
+                cnt = int(np.prod(self.shapes[n]))
+                table[n] = (off, cnt)
+                off += _pad4(cnt)
+            return table, off
+
+        self._train_tab, self.n_train = carve(self.train_names)
+        self._frozen_tab, self.n_frozen = carve(self.frozen_names)
+        self.embed_floats = _pad4(int(np.prod(self.shapes[embed])))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.train_flat = torch.zeros(self.n_train, **f32)
+        self.frozen_flat = torch.zeros(max(self.n_frozen, 4), **f32)
+        self.grad_flat = torch.zeros(self.n_train + 4, **f32)
+        self.m_flat = torch.zeros(self.n_train, **f32)
+        self.v_flat = torch.zeros(self.n_train, **f32)
+        self.norm_sq = torch.zeros(4, **f32)
+        self.sumsq_ws = torch.zeros(int(self.lib.vqa_sumsq_workspace_floats(self.n_train)) + 4, **f32)
+        self.step_count = 0
+
+        self.params, self.grads = {}, {}
+        for n, (off, cnt) in self._train_tab.items():
+            self.params[n] = self.train_flat[off:off + cnt].view(self.shapes[n])
+            self.grads[n] = self.grad_flat[off:off + cnt].view(self.shapes[n])
+        for n, (off, cnt) in self._frozen_tab.items():
+            self.params[n] = self.frozen_flat[off:off + cnt].view(self.shapes[n])
+        self.load_params(params)
+
+        ws_bytes = int(self.lib.vqa_fusion_workspace_bytes(C.byref(self.dims)))
+        if ws_bytes <= 0:
+            raise _lib.VqaHotError("vqa_fusion_workspace_bytes rejected the dims")
+        self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
+        self._p_struct = self._make_struct(self.params, all_required=True)
+        self._g_struct = self._make_struct(self.grads, all_required=False)
+        self._tensor_cache = {}
+        self._batch_keepalive = None
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, params, strict=True):
+        for n in self.shapes:
+            if n not in params:
+                if strict:
+                    raise KeyError("missing variable %s" % n)
+                continue
+            src = params[n]
+            t = torch.as_tensor(np.asarray(src) if not torch.is_tensor(src) else src)
+            if tuple(t.shape) != tuple(self.shapes[n]):
+                raise ValueError("variable %s has shape %s, expected %s" % (n, tuple(t.shape), self.shapes[n]))
+            self.params[n].copy_(t.to(torch.float32))
+
+    def state_dict(self):
+        """Flat name -> CPU tensor archive with the reference's variable names
+        (+ Adam slots and global_step), the analogue of tf.train.Saver's checkpoint."""
+        out = {n: p.detach().cpu().clone() for n, p in self.params.items()}
+        for n, (off, cnt) in self._train_tab.items():
+            out[n + "/Adam"] = self.m_flat[off:off + cnt].view(self.shapes[n]).cpu().clone()
+            out[n + "/Adam_1"] = self.v_flat[off:off + cnt].view(self.shapes[n]).cpu().clone()
+        out["global_step"] = torch.tensor(self.step_count, dtype=torch.int64)
+        return out
+
+    def load_state_dict(self, sd, var_names=None):
+        names = var_names if var_names is not None else list(self.shapes)
+        self.load_params({n: sd[n] for n in names}, strict=False)
+        if var_names is None:
+            for n, (off, cnt) in self._train_tab.items():
+                if n + "/Adam" in sd:
+                    self.m_flat[off:off + cnt].copy_(sd[n + "/Adam"].reshape(-1))
+                    self.v_flat[off:off + cnt].copy_(sd[n + "/Adam_1"].reshape(-1))
+            if "global_step" in sd:
+                self.step_count = int(sd["global_step"])
+
+    def _make_struct(self, table, all_required):
+        sc = self.sc
+
+        def ptr(name):
+            t = table.get(name)
+            if t is None:
+                if all_required:
+                    raise KeyError(name)
+                return None
+            return t.data_ptr()
+
+        def fc(scope, ln):
+            return _lib.Fc(w=ptr(scope + "/fc/weights"), b=ptr(scope + "/fc/biases"),
+                           beta=ptr(scope + "/LayerNorm/beta") if ln else None,
+                           gamma=ptr(scope + "/LayerNorm/gamma") if ln else None)
+
+        return _lib.Params(
+            embed=ptr(sc["embed"]), v_linear_v=fc(sc["v_linear_v"], True),
+            gru_wg=ptr(sc["gru_gates"] + "/kernel"), gru_bg=ptr(sc["gru_gates"] + "/bias"),
+            gru_wc=ptr(sc["gru_cand"] + "/kernel"), gru_bc=ptr(sc["gru_cand"] + "/bias"),
+            q_linear_v=fc(sc["q_linear_v"], True), score=fc(sc["score"], False),
+            pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
+            joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False))
+
+    # ------------------------------------------------------------------ workspace views
+    def tensor(self, name):
+        """Named intermediate (reference mid_result / output key) as a torch view."""
+        if name in self._tensor_cache:
+            return self._tensor_cache[name]
+        off, n = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.vqa_fusion_tensor(C.byref(self.dims), name.encode(), C.byref(off), C.byref(n)),
+                   "vqa_fusion_tensor(%s)" % name)
+        raw = self.workspace[off.value:off.value + 4 * n.value]
+        t = raw.view(torch.int32 if name in _INT_TENSORS else torch.float32)
+        self._tensor_cache[name] = t
+        return t
+
+    # ------------------------------------------------------------------ step pieces
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def bind_inputs(self, *, table, nbox_table, answer_masks):
+        """Device-resident feature table [N,R,D] f32, num_boxes i32 [N], float [A] masks."""
+        self._table, self._nbox = table, nbox_table
+        self._amask = answer_masks
+
+    def _batch_struct(self, batch, keep_att, keep_joint):
+        d = self.dims
+        assert batch["image_idx"].dtype == torch.int64 and batch["image_idx"].numel() == d.B
+        assert batch["q_intseq"].dtype == torch.int32 and tuple(batch["q_intseq"].shape) == (d.B, d.T)
+        assert batch["q_intseq_len"].dtype == torch.int32
+        assert tuple(batch["answer_target"].shape) == (d.B, d.A)
+        if keep_att is not None:
+            assert keep_att.dtype == torch.uint8 and keep_att.numel() == d.B * d.R * d.H
+        if keep_joint is not None:
+            assert keep_joint.dtype == torch.uint8 and keep_joint.numel() == d.B * 2 * d.H
+        self._batch_keepalive = (batch, keep_att, keep_joint)
+        am = self._amask
+        return _lib.Batch(
+            table=self._table.data_ptr(), nbox_table=self._nbox.data_ptr(),
+            image_idx=batch["image_idx"].data_ptr(), q_intseq=batch["q_intseq"].data_ptr(),
+            q_intseq_len=batch["q_intseq_len"].data_ptr(), answer_target=batch["answer_target"].data_ptr(),
+            train_mask=am["train"].data_ptr(), obj_mask=am["obj"].data_ptr(), attr_mask=am["attr"].data_ptr(),
+            exist_mask=am["exist"].data_ptr(),
+            keep_att=keep_att.data_ptr() if keep_att is not None else None,
+            keep_joint=keep_joint.data_ptr() if keep_joint is not None else None)
+
+    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True):
+        self._bs = self._batch_struct(batch, keep_att, keep_joint)
+        _lib.check(self.lib.vqa_fusion_forward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._bs),
+                                               C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
+                                               1 if want_dz else 0, self._stream()), "vqa_fusion_forward")
+
+    def backward(self):
+        # only the embedding gradient is scatter-added; everything else is overwritten
+        self.grad_flat[:self.embed_floats].zero_()
+        tail = self.grad_flat[self.n_train:]
+        _lib.check(self.lib.vqa_fusion_backward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct),
+                                                C.byref(self._bs), C.c_void_p(self.workspace.data_ptr()),
+                                                self.workspace.numel(), C.c_void_p(tail.data_ptr()),
+                                                self._stream()), "vqa_fusion_backward")
+
+    def optimizer_step(self, lr):
+        """clip_by_global_norm(20) + Adam on the flat buffers.  The norm uses the
+        dense gradients of every non-embedding train var plus the un-aggregated
+        embedding slices (tail slot), as tf.clip_by_global_norm does for IndexedSlices."""
+        e = self.embed_floats
+        dense = self.grad_flat[e:self.n_train]
+        tail = self.grad_flat[self.n_train:]
+        _lib.check(self.lib.vqa_sumsq(C.c_void_p(dense.data_ptr()), dense.numel(), C.c_void_p(tail.data_ptr()),
+                                      C.c_void_p(self.norm_sq.data_ptr()), C.c_void_p(self.sumsq_ws.data_ptr()),
+                                      self.sumsq_ws.numel(), self._stream()), "vqa_sumsq")
+        self.step_count += 1
+        t = self.step_count
+        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        _lib.check(self.lib.vqa_clip_adam(C.c_void_p(self.train_flat.data_ptr()), C.c_void_p(self.grad_flat.data_ptr()),
+                                          C.c_void_p(self.m_flat.data_ptr()), C.c_void_p(self.v_flat.data_ptr()),
+                                          self.n_train, C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, lr_t,
+                                          ADAM_B1, ADAM_B2, ADAM_EPS, self._stream()), "vqa_clip_adam")
+
+    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None):
+        self.forward(batch, keep_att, keep_joint, want_dz=True)
+        self.backward()
+        if allreduce is not None:
+            allreduce(self.grad_flat)
+        self.optimizer_step(lr)
+
+    # ------------------------------------------------------------------ results
+    def report(self):
+        r = self.tensor("report")[:13].cpu().numpy()
+        return {self.lib.vqa_report_key(i).decode(): float(r[i]) for i in range(13)}
+
+    def loss(self):
+        return self.tensor("report")[0]
+
+    def make_keep_masks(self, seed, step):
+        """Reproducible dropout keep-masks for (seed, step) -- the explicit stand-in for
+        tf.nn.dropout's internal RNG (vlmap/modules.py:82, model_vlmap_answer.py:180)."""
+        d = self.dims
+        n_att, n_j = d.B * d.R * d.H, d.B * 2 * d.H
+        if not hasattr(self, "_keep_att"):
+            self._keep_att = torch.empty(n_att, dtype=torch.uint8, device=self.device)
+            self._keep_joint = torch.empty(n_j, dtype=torch.uint8, device=self.device)
+        off = step * (n_att + n_j)
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_att.data_ptr()), n_att, seed, off,
+                                             d.keep_att, self._stream()), "vqa_dropout_mask")
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_joint.data_ptr()), n_j, seed, off + n_att,
+                                             d.keep_joint, self._stream()), "vqa_dropout_mask")
+        return self._keep_att, self._keep_joint

@@ -1,0 +1,156 @@
+"""Op-level host wrappers over the C ABI (torch tensors in, torch tensors out).
+
+Mirrors vlmap/modules.py's free functions at op granularity so the parity tests
+read like tests of the reference's modules.  Every function enqueues on the
+current torch stream and raises VqaHotError on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def gemm(A, B, transA=False, transB=False, bias=None, addend=None, split_k=0, out=None):
+    """C = op(A) @ op(B) (+bias) (+addend)  on the f32 MFMA (layers.fully_connected and its grads)."""
+    lib = _lib.load()
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(-1) == 1 and B.stride(-1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if transB else B.shape[1]
+    assert (B.shape[1] if transB else B.shape[0]) == K
+    Cm = out if out is not None else _f32(M, N, like=A)
+    nws = int(lib.vqa_gemm_workspace_floats(M, N, K, split_k))
+    ws = _f32(max(nws, 4), like=A)
+    _lib.check(lib.vqa_gemm_f32(int(transA), int(transB), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(Cm),
+                                Cm.stride(0), _p(bias), _p(addend), addend.stride(0) if addend is not None else 0,
+                                split_k, _p(ws), ws.numel(), _st(A)), "vqa_gemm_f32")
+    return Cm
+
+
+def gather_features(table, nbox_table, idx):
+    lib = _lib.load()
+    N, R, D = table.shape
+    B = idx.numel()
+    V = _f32(B, R, D, like=table)
+    nb = torch.empty(B, dtype=torch.int32, device=table.device)
+    _lib.check(lib.vqa_gather_features(_p(table), _p(nbox_table), _p(idx), _p(V), _p(nb), B, R, D, N, _st(table)),
+               "vqa_gather_features")
+    return V, nb
+
+
+def embed_fwd(E, q):
+    lib = _lib.load()
+    B, T = q.shape
+    Vq, W = E.shape
+    x = _f32(T, B, W, like=E)
+    _lib.check(lib.vqa_embed_fwd(_p(E), _p(q), _p(x), B, T, W, Vq, _st(E)), "vqa_embed_fwd")
+    return x
+
+
+def embed_bwd(dx_tm, q, Vq):
+    lib = _lib.load()
+    T, B, W = dx_tm.shape
+    dE = torch.zeros(Vq, W, dtype=torch.float32, device=dx_tm.device)
+    _lib.check(lib.vqa_embed_bwd(_p(dx_tm), _p(q), _p(dE), B, T, W, Vq, _st(dx_tm)), "vqa_embed_bwd")
+    return dE
+
+
+def ln_relu_fwd(pre, gamma, beta, rows=1, keepmask=None, keep_prob=1.0):
+    lib = _lib.load()
+    M, N = pre.shape
+    G = M // rows
+    y = torch.empty_like(pre)
+    mean, rstd = _f32(G, like=pre), _f32(G, like=pre)
+    _lib.check(lib.vqa_ln_relu_fwd(_p(pre), _p(gamma), _p(beta), _p(keepmask), keep_prob, _p(y), _p(mean), _p(rstd),
+                                   G, rows, N, _st(pre)), "vqa_ln_relu_fwd")
+    return y, mean, rstd
+
+
+def colsum(X):
+    lib = _lib.load()
+    M, N = X.shape
+    out = _f32(N, like=X)
+    ws = _f32(max(int(lib.vqa_colsum_workspace_floats(M, N)), 4), like=X)
+    _lib.check(lib.vqa_colsum(_p(X), M, N, X.stride(0), _p(out), _p(ws), ws.numel(), _st(X)), "vqa_colsum")
+    return out
+
+
+def ln_relu_bwd(dy, pre, mean, rstd, gamma, beta, rows=1, keepmask=None, keep_prob=1.0, want_params=True):
+    lib = _lib.load()
+    M, N = pre.shape
+    G = M // rows
+    dpre = torch.empty_like(pre)
+    pg = _f32(G, N, like=pre) if want_params else None
+    pb = _f32(G, N, like=pre) if want_params else None
+    pbias = _f32(G, N, like=pre) if want_params else None
+    _lib.check(lib.vqa_ln_relu_bwd(_p(dy), _p(pre), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(keepmask), keep_prob,
+                                   _p(dpre), _p(pg), _p(pb), _p(pbias), G, rows, N, _st(pre)), "vqa_ln_relu_bwd")
+    if not want_params:
+        return dpre, None, None, None
+    return dpre, colsum(pg), colsum(pb), colsum(pbias)
+
+
+def attn_pool_fwd(v, qv, V, nb, w, bias, keepmask=None, keep_prob=1.0):
+    """modules.hadamard_attention + modules.attention_pooling."""
+    lib = _lib.load()
+    B, R, H = v.shape
+    D = V.shape[2]
+    att, pooled = _f32(B, R, like=v), _f32(B, D, like=v)
+    _lib.check(lib.vqa_attn_pool_fwd(_p(v), _p(qv), _p(V), _p(nb), _p(w), _p(bias), _p(keepmask), keep_prob, _p(att),
+                                     _p(pooled), B, R, H, D, _st(v)), "vqa_attn_pool_fwd")
+    return att, pooled
+
+
+def attn_pool_bwd(dpooled, v, qv, V, att, w, keepmask=None, keep_prob=1.0):
+    lib = _lib.load()
+    B, R, H = v.shape
+    D = V.shape[2]
+    dv, dqv = torch.empty_like(v), torch.empty_like(qv)
+    pdw, pdb = _f32(B, H, like=v), _f32(B, 1, like=v)
+    _lib.check(lib.vqa_attn_pool_bwd(_p(dpooled), _p(v), _p(qv), _p(V), _p(att), _p(w), _p(keepmask), keep_prob,
+                                     _p(dv), _p(dqv), _p(pdw), _p(pdb), B, R, H, D, _st(v)), "vqa_attn_pool_bwd")
+    return dv, dqv, colsum(pdw), colsum(pdb)
+
+
+def loss_fwd(z, target, masks, use_train_mask=True, inv_batch=None, want_dz=True):
+    lib = _lib.load()
+    B, A = z.shape
+    stats = _f32(B, 16, like=z)
+    pred = torch.empty(B, dtype=torch.int32, device=z.device)
+    dz = torch.empty_like(z) if want_dz else None
+    _lib.check(lib.vqa_loss_fwd(_p(z), _p(target), _p(masks["train"]), _p(masks["obj"]), _p(masks["attr"]),
+                                _p(masks["exist"]), int(use_train_mask), inv_batch if inv_batch else 1.0 / B,
+                                _p(stats), _p(pred), _p(dz), B, A, _st(z)), "vqa_loss_fwd")
+    report = _f32(16, like=z)
+    _lib.check(lib.vqa_report_reduce(_p(stats), B, _p(report), _st(z)), "vqa_report_reduce")
+    keys = [lib.vqa_report_key(i).decode() for i in range(13)]
+    return stats, pred, dz, dict(zip(keys, report[:13].cpu().tolist()))
+
+
+def dropout_mask(n, seed, offset, keep_prob, device):
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    _lib.check(lib.vqa_dropout_mask(_p(out), n, seed, offset, keep_prob, _st(out)), "vqa_dropout_mask")
+    return out
+
+
+def sumsq(g, extra=None):
+    lib = _lib.load()
+    out = _f32(4, like=g)
+    ws = _f32(int(lib.vqa_sumsq_workspace_floats(g.numel())) + 4, like=g)
+    _lib.check(lib.vqa_sumsq(_p(g), g.numel(), _p(extra), _p(out), _p(ws), ws.numel(), _st(g)), "vqa_sumsq")
+    return out[0]
