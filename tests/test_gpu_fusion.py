@@ -60,6 +60,10 @@ def test_forward_backward_match_oracle(model_type, cfg):
     for k in O.REPORT_KEYS:
         assert abs(rep[k] - report[k]) <= 1e-4 * max(1.0, abs(report[k])), (k, rep[k], report[k])
     for n in eng.train_names:
+        if n.endswith("score/fc/biases"):
+            # analytically zero (softmax shift invariance): only rounding noise on both sides
+            assert abs(float(eng.grads[n][0])) <= 1e-6
+            continue
         grad_close(eng.grads[n], grads[n], n)
     grad_close(eng.tensor("dx_embed").view(T, B, dims["W"]).transpose(0, 1), dx, "dx_embed")
     sq = float(eng.grad_flat[eng.n_train])
