@@ -138,6 +138,8 @@ def main():
     eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
     reducer = PAR.GradAllReduce(eng) if world > 1 else None
     lib = _lib.load()
+    if os.environ.get("VQA_GRU_CFG"):
+        _lib.check(lib.vqa_gemm_set_gru_config(int(os.environ["VQA_GRU_CFG"])), "vqa_gemm_set_gru_config")
 
     def step(i):
         ka, kj = eng.make_keep_masks(seed=99 + rank, step=i)       # fresh dropout masks every step
@@ -188,7 +190,8 @@ def main():
                                    "3000 answers (BASELINE configs[1])",
                        "global_batch": cfg["B"] * world, "Vq": cfg["Vq"], "table_images": cfg["N_img"],
                        "parallelism": "dp%d" % world if world > 1 else "single"},
-            "roofline": {"kernel": "gemm_f32_kernel<128,128,64,64,NN> (v_linear_v forward, M=18432 N=1024 K=2048)",
+            "roofline": {"kernel": "gemm_f32_kernel<64,128,32,64,1,32,false,true,false,0> (v_linear_v forward GEMM, "
+                                   "M=18432 N=1024 K=2048, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "kernel_ms": kern_ms, "samples": n.value},

@@ -66,7 +66,19 @@ int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T,
 int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                  int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
                  float* workspace, int64_t workspace_floats, void* stream);
-int64_t vqa_gemm_workspace_floats(int M, int N, int K, int split_k);
+/* Same, launched with at most max_blocks workgroups that walk the tiles persistently
+ * (0 = one workgroup per tile).  Used for the big GEMMs on the side stream: one
+ * workgroup per CU leaves LDS and wave slots for the latency-bound GRU recurrence. */
+int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                    int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
+                    float* workspace, int64_t workspace_floats, int max_blocks, void* stream);
+int vqa_gemm_set_max_blocks(int n);
+int vqa_gemm_set_order(int order);   /* tuning: 0 n-fastest, 1 m-fastest, -1 automatic */
+int64_t vqa_gemm_workspace_floats(int transA, int transB, int M, int N, int K, int split_k);
+/* tuning hooks: force tile configuration `cfg` (0..9) for every later GEMM, -1 = automatic;
+ * tile configuration (4, 7, 8 or 9) of the fused GRU-step GEMMs */
+int vqa_gemm_set_config(int cfg);
+int vqa_gemm_set_gru_config(int cfg);
 
 /* ------------------------------------------- a2,a5,a8,a9 : LN + ReLU (+dropout)
  * y = relu(layer_norm(pre)) [* keepmask / keep]  with statistics over groups of
@@ -111,6 +123,25 @@ int vqa_gru_bwd_a(const float* dh, const float* h_prev, const float* u, const fl
 /* part 2: from drh = dc_pre * Wc_h^T:  dr_pre = drh*h_prev*r*(1-r); dh_acc += drh*r */
 int vqa_gru_bwd_b(const float* drh, const float* h_prev, const float* r, float* dr_pre, int ld_dr,
                   float* dh_acc, int B, int H, void* stream);
+
+/* Whole recurrence with the gate math fused into the GEMM epilogues (2 launches per
+ * step).  xp [T,B,3H] holds x_t*W_x + b for (r|u|c) and is read only; hs [T+1,B,H]
+ * with hs[0] = initial state (zeros); tape r,u,c,rh [T,B,H]. */
+int vqa_gru_seq_fwd(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,
+                    float* u, float* c, float* rh, int T, int B, int H, void* stream);
+/* BPTT.  dh_T [B,H] = gradient wrt hs[T] (used as scratch afterwards); dxp [T,B,3H]
+ * receives (dr_pre | du_pre | dc_pre); dh_scratch [B,H]. */
+int vqa_gru_seq_bwd(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len, const float* hs,
+                    const float* r, const float* u, const float* c, float* dxp, float* dh_scratch, int T, int B,
+                    int H, void* stream);
+
+/* The same restricted to batch rows [row0, row0+rows): samples are independent, so disjoint
+ * row windows may run concurrently on different streams. */
+int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,
+                         float* u, float* c, float* rh, int T, int B, int H, int row0, int rows, void* stream);
+int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len, const float* hs,
+                         const float* r, const float* u, const float* c, float* dxp, float* dh_scratch, int T, int B,
+                         int H, int row0, int rows, void* stream);
 
 /* ------------------------------------------------------------ a6+a7 / K6+K7
  * hadamard_attention + attention_pooling fused (vlmap/modules.py:67-97, 23-39):

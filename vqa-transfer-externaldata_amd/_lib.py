@@ -52,7 +52,16 @@ SIGNATURES = {
     "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _P]),
-    "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
+    "vqa_gemm_f32_ex": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _I, _P]),
+    "vqa_gemm_set_max_blocks": (_I, [_I]),
+    "vqa_gemm_set_order": (_I, [_I]),
+    "vqa_gemm_set_config": (_I, [_I]),
+    "vqa_gemm_set_gru_config": (_I, [_I]),
+    "vqa_gru_seq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_seq_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vqa_gru_seq_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vqa_gru_seq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),

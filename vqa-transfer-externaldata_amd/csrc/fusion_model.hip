@@ -11,6 +11,7 @@
 //
 // Workspace layout is computed from the dims alone, so the host can view named
 // intermediates (mid_result / output of the reference Model) without copies.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -79,32 +80,106 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("dx_embed", T * B * W);
     // shared scratch: split-k slabs, colsum partials, sumsq partials
     int64_t gw = 0;
-    auto g = [&](int64_t M, int64_t N, int64_t K) { gw = max64(gw, vqa_gemm_workspace_floats((int)M, (int)N, (int)K, 0)); };
-    g(B * R, H, D); g(T * B, 2 * H, W); g(T * B, H, W); g(B, 2 * H, H); g(B, H, H); g(B, H, D); g(B, 2 * H, H);
-    g(B, A, 2 * H);                                        // forward
-    g(B, 2 * H, A); g(2 * H, A, B); g(B, H, 2 * H); g(H, 2 * H, B); g(B, D, H); g(D, H, B); g(H, H, B);
-    g(D, H, B * R); g(W, 2 * H, T * B); g(H, 2 * H, T * B); g(W, H, T * B); g(H, H, T * B); g(T * B, W, 2 * H);
-    g(T * B, W, H);                                        // backward
+    auto g = [&](int tA, int tB, int64_t M, int64_t N, int64_t K) {
+        gw = max64(gw, vqa_gemm_workspace_floats(tA, tB, (int)M, (int)N, (int)K, 0));
+    };
+    g(0, 0, B * R, H, D); g(0, 0, T * B, 2 * H, W); g(0, 0, T * B, H, W); g(0, 0, B, H, H); g(0, 0, B, H, D);
+    g(0, 0, B, 2 * H, H); g(0, 0, B, A, 2 * H);                                   // forward
+    g(0, 1, B, 2 * H, A); g(1, 0, 2 * H, A, B); g(0, 1, B, H, 2 * H); g(1, 0, H, 2 * H, B); g(0, 1, B, D, H);
+    g(1, 0, D, H, B); g(1, 0, H, H, B); g(0, 1, B, H, H); g(1, 0, D, H, B * R); g(1, 0, W, 2 * H, T * B);
+    g(1, 0, H, 2 * H, T * B); g(1, 0, W, H, T * B); g(1, 0, H, H, T * B); g(0, 1, T * B, W, 2 * H);
+    g(0, 1, T * B, W, H);                                                         // backward
     L.add("gemm_ws", max64(gw, 4));
+    L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
     int64_t cw = 0;
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * B), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
     L.add("colsum_ws", max64(cw, 4));
+    L.add("colsum_ws1", max64(cw, 4));
+    L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
     L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * B * W), 4));
     return L;
 }
 
 struct Ctx {
     const vqa_dims_t& d;
-    Layout L;
+    const Layout& L;
     char* ws;
     hipStream_t st;
+    int lane;   // 0 = caller's stream, 1 = side stream (own scratch so the two never share a buffer)
     float* f(const char* name) const { return reinterpret_cast<float*>(ws + L.find(name)->off); }
     int32_t* i32(const char* name) const { return reinterpret_cast<int32_t*>(ws + L.find(name)->off); }
+    float* gemm_ws() const { return f(lane ? "gemm_ws1" : "gemm_ws"); }
+    float* colsum_ws() const { return f(lane ? "colsum_ws1" : "colsum_ws"); }
+    float* part(int i) const {
+        static const char* const n0[3] = {"part_a", "part_b", "part_c"};
+        static const char* const n1[3] = {"part_a1", "part_b1", "part_c1"};
+        return f(lane ? n1[i] : n0[i]);
+    }
     int64_t gemm_ws_floats() const { return L.find("gemm_ws")->n; }
     int64_t colsum_ws_floats() const { return L.find("colsum_ws")->n; }
 };
+
+// ---- side stream: the v_linear_v branch (one big GEMM) runs beside the latency-bound GRU
+// recurrence so its workgroups fill the CUs the small per-step GEMMs leave idle.  Fork/join
+// with events keeps everything ordered with respect to the caller's stream (capture-safe).
+struct Side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false, tried = false;
+};
+Side& side_stream() {
+    static Side sd[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Side& x = sd[dev & 63];
+    if (!x.tried) {
+        x.tried = true;
+        const char* env = getenv("VQA_HOT_NO_OVERLAP");
+        if (env == nullptr || env[0] == '0') {
+            x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    return x;
+}
+int side_max_blocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("VQA_HOT_SIDE_BLOCKS");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+// The recurrence is latency-bound (M = batch rows only); its two batch halves are independent
+// chains (LayerNorm and the GRU are per sample), so they run on two streams and fill each
+// other's launch / prologue / epilogue gaps.
+Side& gru_stream() {
+    static Side sd[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Side& x = sd[dev & 63];
+    if (!x.tried) {
+        x.tried = true;
+        const char* env = getenv("VQA_HOT_GRU_SPLIT");
+        if (env != nullptr && env[0] == '1') {
+            x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    return x;
+}
+bool fork_side(const Ctx& c, Side& sd) {
+    if (!sd.ok) return false;
+    return hipEventRecord(sd.fork, c.st) == hipSuccess && hipStreamWaitEvent(sd.s, sd.fork, 0) == hipSuccess;
+}
+bool join_side_record(Side& sd) { return hipEventRecord(sd.join, sd.s) == hipSuccess; }
+bool join_side(const Ctx& c, Side& sd) {
+    return join_side_record(sd) && hipStreamWaitEvent(c.st, sd.join, 0) == hipSuccess;
+}
 
 // ---- measurement probe -----------------------------------------------------
 struct Probe {
@@ -139,11 +214,13 @@ struct ProbeScope {
 
 int gemm(const Ctx& c, int tA, int tB, int64_t M, int64_t N, int64_t K, const float* A, int lda, const float* B,
          int ldb, float* C, int ldc, const float* bias = nullptr, const float* D = nullptr, int ldd = 0) {
-    return vqa_gemm_f32(tA, tB, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, bias, D, ldd, 0, c.f("gemm_ws"),
-                        c.gemm_ws_floats(), c.st);
+    // side-stream GEMMs: one workgroup per CU (persistent), so the recurrence on the caller's
+    // stream keeps finding free LDS / wave slots on every CU
+    return vqa_gemm_f32_ex(tA, tB, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, bias, D, ldd, 0, c.gemm_ws(),
+                           c.gemm_ws_floats(), c.lane ? side_max_blocks() : 0, c.st);
 }
 int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* out) {
-    return vqa_colsum(X, (int)M, (int)N, ldx, out, c.f("colsum_ws"), c.colsum_ws_floats(), c.st);
+    return vqa_colsum(X, (int)M, (int)N, ldx, out, c.colsum_ws(), c.colsum_ws_floats(), c.st);
 }
 
 bool dims_ok(const vqa_dims_t* d) {
@@ -171,12 +248,12 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
     const bool train = g != nullptr && g->w != nullptr;
     const int64_t G = M / rows;
     TRY(vqa_ln_relu_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma, p.beta, keep, keep_prob, c.f(d_pre),
-                        train ? c.f("part_a") : nullptr, train ? c.f("part_b") : nullptr,
-                        train ? c.f("part_c") : nullptr, (int)G, rows, (int)N, c.st));
+                        train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
+                        train ? c.part(2) : nullptr, (int)G, rows, (int)N, c.st));
     if (train) {
-        TRY(colsum(c, c.f("part_a"), G, N, (int)N, g->gamma));
-        TRY(colsum(c, c.f("part_b"), G, N, (int)N, g->beta));
-        TRY(colsum(c, c.f("part_c"), G, N, (int)N, g->b));
+        TRY(colsum(c, c.part(0), G, N, (int)N, g->gamma));
+        TRY(colsum(c, c.part(1), G, N, (int)N, g->beta));
+        TRY(colsum(c, c.part(2), G, N, (int)N, g->b));
         ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
         TRY(gemm(c, 1, 0, K, N, M, x, (int)K, c.f(d_pre), (int)N, g->w, (int)N));  // dW = x^T * d_pre
     }
@@ -213,18 +290,24 @@ extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64
 extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_batch_t* bt,
                                   void* workspace, int64_t workspace_bytes, int want_dz, void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && bt && workspace, VQA_ERR_ARG);
-    Ctx c{*dims, make_layout(*dims), static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    const Layout L = make_layout(*dims);
+    Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream), 0};
     VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
     VQA_REQUIRE(vqa_aligned16(workspace), VQA_ERR_ALIGN);
     ProbeScope ps_all("forward", c.st);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
 
+    // visual branch (a1 + a2) on the side stream, question branch (a3-a5) on the caller's
+    Side& sd = side_stream();
+    const bool forked = fork_side(c, sd);
+    Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
     // a1: V_ft = features[image_idx]
-    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, c.f("V_ft"), c.i32("num_V_ft"), (int)B, (int)R,
-                            (int)D, dims->N_img, c.st));
+    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, cv.f("V_ft"), cv.i32("num_V_ft"), (int)B,
+                            (int)R, (int)D, dims->N_img, cv.st));
     // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
-    TRY(fc_ln_relu_fwd(c, c.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
-                       nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v",
+                       "rstd_v", nullptr, 1.f));
+    if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
     // a4: GRU.  Input projections of all steps as two big GEMMs ...
@@ -235,27 +318,25 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
     const float* Wg_h = P->gru_wg + W * 2 * H;
     const float* Wc_h = P->gru_wc + W * H;
-    ProbeScope* ps_gru = new ProbeScope("gru.fwd", c.st);
-    struct Del { ProbeScope*& p; ~Del() { delete p; p = nullptr; } } del_gru{ps_gru};
-    for (int64_t t = 0; t < T; ++t) {
-        float* xpt = xp + t * B * 3 * H;
-        const float* hp = hs + t * B * H;
-        float* r = c.f("gru_r") + t * B * H;
-        float* u = c.f("gru_u") + t * B * H;
-        float* cc = c.f("gru_c") + t * B * H;
-        float* rh = c.f("gru_rh") + t * B * H;
-        // ... then per step: gates += h*Wg_h ; r,u = sigmoid ; cand += (r*h)*Wc_h ; blend
-        TRY(gemm(c, 0, 0, B, 2 * H, H, hp, (int)H, Wg_h, (int)(2 * H), xpt, (int)(3 * H), nullptr, xpt, (int)(3 * H)));
-        TRY(vqa_gru_gates_fwd(xpt, (int)(3 * H), hp, r, u, rh, (int)B, (int)H, c.st));
-        TRY(gemm(c, 0, 0, B, H, H, rh, (int)H, Wc_h, (int)H, xpt + 2 * H, (int)(3 * H), nullptr, xpt + 2 * H,
-                 (int)(3 * H)));
-        TRY(vqa_gru_cand_fwd(xpt + 2 * H, (int)(3 * H), u, hp, bt->q_intseq_len, (int)t, cc, hs + (t + 1) * B * H,
-                             (int)B, (int)H, c.st));
+    {
+        ProbeScope ps("gru.fwd", c.st);
+        Side& g2 = gru_stream();
+        const int64_t B0 = (B / 2 / 64) * 64;   // first half (multiple of the 64-row tile)
+        if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
+            TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
+                                     c.f("gru_rh"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
+            TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
+                                     c.f("gru_rh"), (int)T, (int)B, (int)H, (int)B0, (int)(B - B0), g2.s));
+            if (!join_side(c, g2)) return VQA_ERR_LAUNCH;
+        } else {
+            TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
+                                c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
+        }
     }
-    delete ps_gru; ps_gru = nullptr;
     const float* h = hs + T * B * H;
     // a5
     TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
+    if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
     // a6 + a7
     {
     ProbeScope ps("attn_pool.fwd", c.st);
@@ -288,7 +369,8 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
                                    const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
                                    float* embed_slice_sq, void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && G && bt && workspace, VQA_ERR_ARG);
-    Ctx c{*dims, make_layout(*dims), static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    const Layout L = make_layout(*dims);
+    Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream), 0};
     VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
     ProbeScope ps_all("backward", c.st);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
@@ -322,36 +404,39 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
         TRY(colsum(c, c.f("part_dw"), B, H, (int)H, G->score.w));
         TRY(colsum(c, c.f("part_db"), B, 1, 1, G->score.b));
     }
-    // v_linear_v: parameters only (V_ft is an input)
-    TRY(fc_ln_relu_bwd(c, c.f("d_v"), c.f("V_ft"), B * R, D, H, P->v_linear_v, &G->v_linear_v, (int)R, "pre_v", "mean_v",
-                       "rstd_v", nullptr, 1.f, "d_pre_v", nullptr, false));
+    // v_linear_v: parameters only (V_ft is an input).  77 GFLOP of dW on the side stream, beside
+    // the latency-bound back-propagation through time below.
+    Side& sd = side_stream();
+    const bool forked = fork_side(c, sd);
+    {
+        Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
+        TRY(fc_ln_relu_bwd(cv, cv.f("d_v"), cv.f("V_ft"), B * R, D, H, P->v_linear_v, &G->v_linear_v, (int)R, "pre_v",
+                           "mean_v", "rstd_v", nullptr, 1.f, "d_pre_v", nullptr, false));
+        if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
+    }
     // q_linear_v: dh += ...
     TRY(fc_ln_relu_bwd(c, c.f("d_qv"), h, B, H, H, P->q_linear_v, &G->q_linear_v, 1, "pre_qv", "mean_qv", "rstd_qv",
                        nullptr, 1.f, "d_pre_qv", dh, true));
 
-    // GRU back-propagation through time
+    // GRU back-propagation through time (gate math fused into the GEMM epilogues)
     float* dxp = c.f("dxp");
-    float* dh_cur = dh;
-    float* dh_nxt = c.f("d_h1");
     const float* Wg_h = P->gru_wg + W * 2 * H;
     const float* Wc_h = P->gru_wc + W * H;
-    ProbeScope* ps_gru = new ProbeScope("gru.bwd", c.st);
-    struct Del { ProbeScope*& p; ~Del() { delete p; p = nullptr; } } del_gru{ps_gru};
-    for (int64_t t = T - 1; t >= 0; --t) {
-        float* dxpt = dxp + t * B * 3 * H;
-        const float* hp = hs + t * B * H;
-        const float* r = c.f("gru_r") + t * B * H;
-        const float* u = c.f("gru_u") + t * B * H;
-        const float* cc = c.f("gru_c") + t * B * H;
-        TRY(vqa_gru_bwd_a(dh_cur, hp, u, cc, bt->q_intseq_len, (int)t, dxpt + 2 * H, (int)(3 * H), dxpt + H,
-                          (int)(3 * H), dh_nxt, (int)B, (int)H, c.st));
-        TRY(gemm(c, 0, 1, B, H, H, dxpt + 2 * H, (int)(3 * H), Wc_h, (int)H, c.f("d_rh"), (int)H));
-        TRY(vqa_gru_bwd_b(c.f("d_rh"), hp, r, dxpt, (int)(3 * H), dh_nxt, (int)B, (int)H, c.st));
-        TRY(gemm(c, 0, 1, B, H, 2 * H, dxpt, (int)(3 * H), Wg_h, (int)(2 * H), dh_nxt, (int)H, nullptr, dh_nxt,
-                 (int)H));
-        float* tmp = dh_cur; dh_cur = dh_nxt; dh_nxt = tmp;
+    {
+        ProbeScope ps("gru.bwd", c.st);
+        Side& g2 = gru_stream();
+        const int64_t B0 = (B / 2 / 64) * 64;
+        if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
+            TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
+                                     dxp, c.f("d_h1"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
+            TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
+                                     dxp, c.f("d_h1"), (int)T, (int)B, (int)H, (int)B0, (int)(B - B0), g2.s));
+            if (!join_side(c, g2)) return VQA_ERR_LAUNCH;
+        } else {
+            TRY(vqa_gru_seq_bwd(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), dxp,
+                                c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
+        }
     }
-    delete ps_gru; ps_gru = nullptr;
     if (G->gru_wg != nullptr) {
         TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
@@ -367,6 +452,7 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
     if (G->embed != nullptr) TRY(vqa_embed_bwd(dx, bt->q_intseq, G->embed, (int)B, (int)T, (int)W, dims->Vq, c.st));
     if (embed_slice_sq != nullptr)
         TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
+    if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
     return VQA_OK;
 }
 

@@ -23,8 +23,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int KC_LD = BK + 4;  // padded row of a k-contiguous tile (80 B: 16-B aligned, conflict-free b128)
+// A k-contiguous tile is staged as [row][BK + 4]: rows stay 16-B aligned and the 16 rows of a
+// ds_read_b128 lane group land on 16 distinct 16-B bank groups for BK = 16, 32 and 64.
 
 struct GemmArgs {
     int M, N, K;
@@ -33,10 +33,41 @@ struct GemmArgs {
     float* C; int ldc;
     const float* bias;
     const float* D; int ldd;
-    int k_per_split;      // multiple of BK
+    int k_per_split;      // multiple of 64 (>= every BK)
     int64_t slab_stride;  // floats between split-k slabs of C (0 when split_k == 1)
     int vecA, vecB;       // 16-byte global loads allowed for A / B
+    int tiles_m, tiles_n, nsplit;   // 1-D grid: workgroups walk the (split, m, n) tiles
+    int m_fastest;                  // tile order inside a split: m fastest (1) or n fastest (0)
 };
+
+// XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
+// that share an XCD (same id % 8) get a CONTIGUOUS range of logical tiles, n fastest, so the tiles
+// that re-read one A row panel hit the same L2.  Bijective for any total.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = lin & 7, idx = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Fused epilogues of the GRU recurrence (tf.contrib.rnn.GRUCell, vlmap/modules.py:129-135):
+//  EPI_GATES  g = acc + D ; s = sigmoid(g) ; col <  H: r = s, rh = s*h_prev ; col >= H: u = s
+//  EPI_CAND   c = tanh(acc + D) ; h_new = (t < len) ? u*h_prev + (1-u)*c : h_prev
+//  EPI_BWD_RH drh = acc ; dr_pre = drh*h_prev*r*(1-r) -> o0[row*ldo + col] ; dh_acc += drh*r
+//  EPI_BWD_DH dh = acc + dh_acc (the gradient wrt h of step t-1) and, fused, the first half of
+//             step t-1's backward: dc_pre, du_pre, dh_acc' (see vqa_gru_bwd_a)
+enum { EPI_PLAIN = 0, EPI_GATES = 1, EPI_CAND = 2, EPI_BWD_RH = 3, EPI_BWD_DH = 4 };
+struct EpiArgs {
+    int H, t, ldo;
+    const int32_t* len;
+    const float* h_prev;   // [B,H]
+    const float* i0;       // GATES: -      CAND: u        BWD_RH: r        BWD_DH: u (step t-1)
+    const float* i1;       //                                               BWD_DH: c (step t-1)
+    float* o0;             // GATES: r      CAND: c        BWD_RH: dr_pre   BWD_DH: dc_pre (ld ldo)
+    float* o1;             // GATES: u      CAND: h_new    BWD_RH: dh_acc   BWD_DH: du_pre (ld ldo)
+    float* o2;             // GATES: rh                                      BWD_DH: dh_acc
+};
+
+int g_force_order = -1;  // tuning override of the tile order (vqa_gemm_set_order): 0 n-fastest, 1 m-fastest
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int n_ok, bool vec) {
     // n_ok = number of valid elements at p (<=0: none).  vec => p is 16-B aligned.
@@ -53,8 +84,10 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int n_ok, bool vec) 
 }
 
 // Stage one BR x 16 (k-contiguous, KC) or 16 x BR (row-contiguous, RC) operand tile.
-template <int BR, bool KC>
+template <int BR, int BK, bool KC>
 struct Stager {
+    static constexpr int KC_LD = BK + 4;
+    static constexpr int KQ = BK / 4;                      // float4 per k-contiguous row
     static constexpr int NV = (BR * BK / 4 + 255) / 256;  // float4 per thread
     float4 reg[NV];
 
@@ -65,9 +98,9 @@ struct Stager {
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * 256;
             if (KC) {
-                const int row = idx >> 2, kq = (idx & 3) * 4;
+                const int row = idx / KQ, kq = (idx % KQ) * 4;
                 const int gr = r0 + row, gk = k0 + kq;
-                const bool in = (idx < BR * 4) && (gr < RLIM);
+                const bool in = (idx < BR * KQ) && (gr < RLIM);
                 reg[i] = in ? ld4_guard(g + (int64_t)gr * ld + gk, KLIM - gk, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 constexpr int QPR = BR / 4;  // float4 per k row
@@ -83,8 +116,8 @@ struct Stager {
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * 256;
             if (KC) {
-                if (idx < BR * 4) {
-                    const int row = idx >> 2, kq = (idx & 3) * 4;
+                if (idx < BR * KQ) {
+                    const int row = idx / KQ, kq = (idx % KQ) * 4;
                     *reinterpret_cast<float4*>(s + row * KC_LD + kq) = reg[i];
                 }
             } else {
@@ -98,34 +131,47 @@ struct Stager {
     }
 };
 
-template <int BR, bool KC>
-constexpr int tile_floats() { return KC ? BR * KC_LD : BK * BR; }
+template <int BR, int BK, bool KC>
+constexpr int tile_floats() { return KC ? BR * (BK + 4) : BK * BR; }
 
-// fragment of 4 consecutive MFMA k-steps (chunk c of the 16-deep tile) for the 32 rows at r0
-template <int BR, bool KC>
+// fragment of 4 consecutive MFMA k-steps (8-wide chunk c of the BK-deep tile) for the 32 rows at r0
+template <int BR, int BK, bool KC>
 __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane) {
     const int i = lane & 31, h = lane >> 5;
     if (KC) {
-        return *reinterpret_cast<const float4*>(s + (r0 + i) * KC_LD + c * 8 + h * 4);
+        return *reinterpret_cast<const float4*>(s + (r0 + i) * (BK + 4) + c * 8 + h * 4);
     } else {
         const float* p = s + (c * 8 + h * 4) * BR + r0 + i;
         return make_float4(p[0], p[BR], p[2 * BR], p[3 * BR]);
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    constexpr int A_FL = tile_floats<BM, A_KC>();
-    constexpr int B_FL = tile_floats<BN, B_KC>();
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FL + B_FL)];
+    constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+    static_assert(WAVES_M * WAVES_N * WGK == 4, "4 waves per block");
+    static_assert((BK / 8) % WGK == 0, "k chunks split evenly over the k wave groups");
+    constexpr int A_FL = tile_floats<BM, BK, A_KC>();
+    constexpr int B_FL = tile_floats<BN, BK, B_KC>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x (A tile | B tile)
 
+    // The fused GRU-step kernels sit on the step's critical path and run beside a big GEMM on the
+    // side stream: raise their wave priority so they win MFMA/VALU arbitration on a shared SIMD.
+    if (EPI != EPI_PLAIN) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int wk = wave / (WAVES_M * WAVES_N);
+    const int wm = (wave / WAVES_N) % WAVES_M, wn = wave % WAVES_N;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int total = tiles_mn * p.nsplit;
+    // persistent walk: a launch limited to fewer workgroups than tiles (side-stream GEMMs keep
+    // to one workgroup per CU so the latency-bound kernels beside them still find LDS/waves)
+    for (int lin = blockIdx.x; lin < total; lin += gridDim.x) {
+    const int tile = xcd_remap(lin, total);
+    const int bz = tile / tiles_mn, bmn = tile - bz * tiles_mn;
+    const int m0 = (p.m_fastest ? bmn % p.tiles_m : bmn / p.tiles_n) * BM;
+    const int n0 = (p.m_fastest ? bmn / p.tiles_m : bmn % p.tiles_n) * BN;
+    const int kbeg = bz * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
@@ -137,32 +183,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    Stager<BM, A_KC> sa;
-    Stager<BN, B_KC> sb;
     const bool va = p.vecA, vb = p.vecB;
-
-    if (nt > 0) {
-        sa.load(p.A, p.lda, m0, kbeg, p.M, kend, va);
-        sb.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
-        sa.store(smem);
-        sb.store(smem + A_FL);
-    }
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const float* As = smem + (t & 1) * (A_FL + B_FL);
-        const float* Bs = As + A_FL;
-        if (t + 1 < nt) {
-            sa.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, va);
-            sb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, vb);
-        }
+    auto compute_tile = [&](const float* As, const float* Bs) {
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
+        for (int cc = 0; cc < BK / 8 / WGK; ++cc) {
+            const int c = cc * WGK + wk;   // the k wave groups interleave over the 8-wide chunks
             float4 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = frag4<BM, A_KC>(As, wm * WM + a * 32, c, lane);
+            for (int a = 0; a < TM; ++a) af[a] = frag4<BM, BK, A_KC>(As, wm * WM + a * 32, c, lane);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = frag4<BN, B_KC>(Bs, wn * WN + b * 32, c, lane);
+            for (int b = 0; b < TN; ++b) bf[b] = frag4<BN, BK, B_KC>(Bs, wn * WN + b * 32, c, lane);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -173,36 +203,236 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if (t + 1 < nt) {
-            float* An = smem + ((t + 1) & 1) * (A_FL + B_FL);
-            sa.store(An);
-            sb.store(An + A_FL);
+    };
+    float* L0 = smem;
+    float* L1 = smem + (A_FL + B_FL);
+
+    if (!DEEP) {
+        // one tile of register prefetch: enough when >= 2-3 workgroups share a CU
+        Stager<BM, BK, A_KC> sa;
+        Stager<BN, BK, B_KC> sb;
+        if (nt > 0) {
+            sa.load(p.A, p.lda, m0, kbeg, p.M, kend, va);
+            sb.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
+            sa.store(L0);
+            sb.store(L0 + A_FL);
         }
         __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            float* cur = (t & 1) ? L1 : L0;
+            float* nxt = (t & 1) ? L0 : L1;
+            if (t + 1 < nt) {
+                sa.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, va);
+                sb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, vb);
+            }
+            compute_tile(cur, cur + A_FL);
+            if (t + 1 < nt) {
+                sa.store(nxt);
+                sb.store(nxt + A_FL);
+            }
+            __syncthreads();
+        }
+    } else {
+        // two tiles of register prefetch (two stager sets, loop unrolled by 2 so every register
+        // index is static): with one workgroup per CU a tile's MFMA time (~0.5 us) is shorter than
+        // the global-load latency, so the loads need two phases of cover.
+        Stager<BM, BK, A_KC> sa0, sa1;
+        Stager<BN, BK, B_KC> sb0, sb1;
+        if (nt > 0) {
+            sa0.load(p.A, p.lda, m0, kbeg, p.M, kend, va);
+            sb0.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
+        }
+        if (nt > 1) {
+            sa1.load(p.A, p.lda, m0, kbeg + BK, p.M, kend, va);
+            sb1.load(p.B, p.ldb, n0, kbeg + BK, p.N, kend, vb);
+        }
+        if (nt > 0) {
+            sa0.store(L0);
+            sb0.store(L0 + A_FL);
+        }
+        __syncthreads();
+        for (int t = 0; t < nt; t += 2) {
+            // even phase: L0 holds tile t, set 1 holds tile t+1
+            if (t + 2 < nt) {
+                sa0.load(p.A, p.lda, m0, kbeg + (t + 2) * BK, p.M, kend, va);
+                sb0.load(p.B, p.ldb, n0, kbeg + (t + 2) * BK, p.N, kend, vb);
+            }
+            compute_tile(L0, L0 + A_FL);
+            if (t + 1 < nt) {
+                sa1.store(L1);
+                sb1.store(L1 + A_FL);
+            }
+            __syncthreads();
+            if (t + 1 >= nt) break;
+            // odd phase: L1 holds tile t+1, set 0 holds tile t+2
+            if (t + 3 < nt) {
+                sa1.load(p.A, p.lda, m0, kbeg + (t + 3) * BK, p.M, kend, va);
+                sb1.load(p.B, p.ldb, n0, kbeg + (t + 3) * BK, p.N, kend, vb);
+            }
+            compute_tile(L1, L1 + A_FL);
+            if (t + 2 < nt) {
+                sa0.store(L0);
+                sb0.store(L0 + A_FL);
+            }
+            __syncthreads();
+        }
     }
 
-    // epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* Cz = p.C + (int64_t)blockIdx.z * p.slab_stride;
-    const bool first = (blockIdx.z == 0);
+    if (WGK > 1) {
+        // in-block split-k: groups 1..WGK-1 park their partial tiles in LDS (the operand tiles are
+        // dead after the loop's last barrier), group 0 sums them.  Lane-contiguous => conflict-free.
+        constexpr int PER_WAVE = TM * TN * 16 * 64;
+        float* red = smem;
+        if (wk > 0) {
+            float* dst = red + ((wk - 1) * (WAVES_M * WAVES_N) + wm * WAVES_N + wn) * PER_WAVE + lane;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((a * TN + b) * 16 + r) * 64] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;   // fused-epilogue / in-block split-k launches are never persistent
+#pragma unroll
+        for (int g = 1; g < WGK; ++g) {
+            const float* src = red + ((g - 1) * (WAVES_M * WAVES_N) + wm * WAVES_N + wn) * PER_WAVE + lane;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * TN + b) * 16 + r) * 64];
+        }
+    }
+
+    // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (EPI == EPI_PLAIN) {
+        // All global loads of a tile are issued BEFORE its first store: D may alias C (in-place
+        // accumulate), so interleaving them would serialise 16 round trips.
+        float* Cz = p.C + (int64_t)bz * p.slab_stride;
+        const bool first = (bz == 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn * WN + b * 32 + (lane & 31);
+                const int rbase = m0 + wm * WM + a * 32 + 4 * (lane >> 5);
+                if (col >= p.N) continue;
+                const float bv = (p.bias != nullptr && first) ? p.bias[col] : 0.f;
+                float dv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    dv[r] = (p.D != nullptr && first && row < p.M) ? p.D[(int64_t)row * p.ldd + col] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) Cz[(int64_t)row * p.ldc + col] = acc[a][b][r] + bv + dv[r];
+                }
+            }
+        continue;   // next tile (the loop's last barrier already fenced the LDS tiles)
+    }
+
+    // Fused GRU epilogues: the accumulator tile is transposed through LDS (own 32 x 36 region per
+    // wave, no barrier needed) so every lane owns 4 consecutive columns of a row: all side inputs
+    // and outputs move as 16-byte, line-contiguous accesses, loads first, then math, then stores.
+    constexpr int STG_LD = 36;
+    constexpr int RED_FL = (WGK - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64;
+    float* stg = smem + RED_FL + (wm * WAVES_N + wn) * 32 * STG_LD;
+    const int H = ep.H;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int col = n0 + wn * WN + b * 32 + (lane & 31);
-            const int rbase = m0 + wm * WM + a * 32 + 4 * (lane >> 5);
-            if (col < p.N) {
-                const float bv = (p.bias != nullptr && first) ? p.bias[col] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) {
-                        float v = acc[a][b][r] + bv;
-                        if (p.D != nullptr && first) v += p.D[(int64_t)row * p.ldd + col];
-                        Cz[(int64_t)row * p.ldc + col] = v;
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (lane & 31)] = acc[a][b][r];
+            const int c4 = (lane & 7) * 4;
+            const int gcol = n0 + wn * WN + b * 32 + c4;
+            const int grow0 = m0 + wm * WM + a * 32 + (lane >> 3);
+            float4 v[4], d[4], x0[4], x1[4], x2[4];
+            int lim[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int grow = grow0 + 8 * i;
+                ok[i] = (grow < p.M) && (gcol < p.N);
+                v[i] = *reinterpret_cast<const float4*>(stg + ((lane >> 3) + 8 * i) * STG_LD + c4);
+                d[i] = x0[i] = x1[i] = x2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                lim[i] = 0;
+                if (!ok[i]) continue;
+                if (p.D != nullptr) d[i] = *reinterpret_cast<const float4*>(p.D + (int64_t)grow * p.ldd + gcol);
+                const int64_t o = (int64_t)grow * H + gcol;
+                if (EPI == EPI_GATES) {
+                    if (gcol < H) x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                } else if (EPI == EPI_CAND) {
+                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                    lim[i] = ep.len[grow];
+                } else if (EPI == EPI_BWD_RH) {
+                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                    x2[i] = *reinterpret_cast<const float4*>(ep.o1 + o);
+                } else {
+                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                    x2[i] = *reinterpret_cast<const float4*>(ep.i1 + o);
+                    lim[i] = ep.len[grow];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!ok[i]) continue;
+                const int grow = grow0 + 8 * i;
+                const int64_t o = (int64_t)grow * H + gcol;
+                const float vv[4] = {v[i].x + d[i].x, v[i].y + d[i].y, v[i].z + d[i].z, v[i].w + d[i].w};
+                const float a0[4] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w};
+                const float a1[4] = {x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+                const float a2[4] = {x2[i].x, x2[i].y, x2[i].z, x2[i].w};
+                float r0[4], r1[4], r2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (EPI == EPI_GATES) {
+                        r0[j] = sigmoidf_stable(vv[j]);
+                        r1[j] = r0[j] * a0[j];
+                    } else if (EPI == EPI_CAND) {
+                        r0[j] = tanhf(vv[j]);
+                        r1[j] = (ep.t < lim[i]) ? (a1[j] * a0[j] + (1.f - a1[j]) * r0[j]) : a0[j];
+                    } else if (EPI == EPI_BWD_RH) {
+                        r0[j] = vv[j] * a0[j] * a1[j] * (1.f - a1[j]);
+                        r1[j] = a2[j] + vv[j] * a1[j];
+                    } else {
+                        const bool live = ep.t < lim[i];
+                        r0[j] = live ? vv[j] * (1.f - a1[j]) * (1.f - a2[j] * a2[j]) : 0.f;
+                        r1[j] = live ? vv[j] * (a0[j] - a2[j]) * a1[j] * (1.f - a1[j]) : 0.f;
+                        r2[j] = live ? vv[j] * a1[j] : vv[j];
                     }
+                }
+                const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]);
+                const float4 q1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
+                if (EPI == EPI_GATES) {
+                    if (gcol < H) {
+                        *reinterpret_cast<float4*>(ep.o0 + o) = q0;       // r
+                        *reinterpret_cast<float4*>(ep.o2 + o) = q1;       // r * h_prev
+                    } else {
+                        *reinterpret_cast<float4*>(ep.o1 + o - H) = q0;   // u
+                    }
+                } else if (EPI == EPI_CAND) {
+                    *reinterpret_cast<float4*>(ep.o0 + o) = q0;           // c
+                    *reinterpret_cast<float4*>(ep.o1 + o) = q1;           // h_new
+                } else if (EPI == EPI_BWD_RH) {
+                    *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dr_pre
+                    *reinterpret_cast<float4*>(ep.o1 + o) = q1;                                // dh_acc
+                } else {
+                    *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dc_pre
+                    *reinterpret_cast<float4*>(ep.o1 + (int64_t)grow * ep.ldo + gcol) = q1;   // du_pre
+                    *reinterpret_cast<float4*>(ep.o2 + o) = make_float4(r2[0], r2[1], r2[2], r2[3]);
                 }
             }
         }
+    }   // tile loop
 }
 
 // C[m, n] = sum_z slab[z][m, n]   (slabs are dense M x N with ld = N)
@@ -222,46 +452,176 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, split);
-    if (tA == 0 && tB == 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
-    else if (tA == 0 && tB == 1)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI>
+int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
+    constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
+    constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
+    constexpr size_t stage = (EPI == EPI_PLAIN) ? 0 : (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
+    constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI>;
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {   // MI355X has 160 KiB of LDS per CU; > 64 KiB needs the opt-in
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return VQA_ERR_LAUNCH;
+        attr_done = true;
+    }
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.nsplit = split;
+    {
+        // Each XCD (private 4 MiB L2) walks a contiguous run of tiles.  Pick the tile order whose
+        // run touches fewer operand bytes: n fastest re-uses an A row panel across the run (tall
+        // activations), m fastest keeps a B column panel resident (batch-sized M against big
+        // weights: the GRU / head GEMMs, whose weights then stay partitioned over the 8 L2s).
+        const double per_xcd = (double)a.tiles_m * a.tiles_n / 8.0;
+        auto foot = [&](double t_fast, double t_slow, double b_fast, double b_slow) {
+            const double slow_panels = std::min(t_slow, per_xcd / t_fast + 1.0);
+            const double fast_panels = std::min(t_fast, per_xcd);
+            return slow_panels * b_slow + fast_panels * b_fast;
+        };
+        const double n_fast = foot(a.tiles_n, a.tiles_m, BN, BM);   // bytes ~ panels * width (same K)
+        const double m_fast = foot(a.tiles_m, a.tiles_n, BM, BN);
+        a.m_fastest = (g_force_order >= 0) ? g_force_order : (m_fast < n_fast ? 1 : 0);
+    }
+    int blocks = a.tiles_m * a.tiles_n * split;
+    if (max_blocks > 0 && WGK == 1 && EPI == EPI_PLAIN && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP>
+int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int mb) {
+    const EpiArgs ep{};
+    if (tA == 0 && tB == 0)
+        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, false, EPI_PLAIN>(a, ep, split, st, mb);
+    if (tA == 0 && tB == 1)
+        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, true, EPI_PLAIN>(a, ep, split, st, mb);
+    return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, false, false, EPI_PLAIN>(a, ep, split, st, mb);
+}
+
+struct TileCfg { int BM, BN; };
+constexpr int NUM_CFG = 14;
+const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 128}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 128},
+                               {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}};
+
+int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int mb = 0) {
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 64, 64, 1, 16, false>(tA, tB, a, split, st, mb);
+        case 1: return launch_cfg<128, 128, 64, 64, 1, 32, false>(tA, tB, a, split, st, mb);
+        case 2: return launch_cfg<64, 64, 32, 32, 1, 16, false>(tA, tB, a, split, st, mb);
+        case 3: return launch_cfg<64, 64, 32, 32, 1, 32, false>(tA, tB, a, split, st, mb);
+        case 4: return launch_cfg<64, 64, 32, 32, 1, 64, false>(tA, tB, a, split, st, mb);
+        case 5: return launch_cfg<128, 64, 64, 32, 1, 32, false>(tA, tB, a, split, st, mb);
+        case 6: return launch_cfg<64, 128, 32, 64, 1, 32, false>(tA, tB, a, split, st, mb);
+        case 7: return launch_cfg<64, 32, 32, 32, 2, 64, false>(tA, tB, a, split, st, mb);
+        case 8: return launch_cfg<32, 32, 32, 32, 4, 64, false>(tA, tB, a, split, st, mb);
+        case 9: return launch_cfg<32, 64, 32, 32, 2, 64, false>(tA, tB, a, split, st, mb);
+        case 10: return launch_cfg<64, 64, 32, 32, 1, 64, true>(tA, tB, a, split, st, mb);
+        case 11: return launch_cfg<64, 32, 32, 32, 2, 64, true>(tA, tB, a, split, st, mb);
+        case 12: return launch_cfg<64, 64, 32, 32, 1, 32, true>(tA, tB, a, split, st, mb);
+        case 13: return launch_cfg<64, 32, 32, 32, 2, 32, true>(tA, tB, a, split, st, mb);
+        default: return VQA_ERR_ARG;
+    }
+}
+
+// fused GRU-step GEMMs: layout fixed by the epilogue (forward NN, backward NT)
+template <int EPI>
+int launch_gru(int cfg, const GemmArgs& a, const EpiArgs& ep, hipStream_t st) {
+    constexpr bool BKC = (EPI == EPI_BWD_RH || EPI == EPI_BWD_DH);
+    switch (cfg) {
+        case 4: return launch_one<64, 64, 32, 32, 1, 64, false, true, BKC, EPI>(a, ep, 1, st);
+        case 7: return launch_one<64, 32, 32, 32, 2, 64, false, true, BKC, EPI>(a, ep, 1, st);
+        case 8: return launch_one<32, 32, 32, 32, 4, 64, false, true, BKC, EPI>(a, ep, 1, st);
+        case 9: return launch_one<32, 64, 32, 32, 2, 64, false, true, BKC, EPI>(a, ep, 1, st);
+        case 10: return launch_one<64, 64, 32, 32, 1, 64, true, true, BKC, EPI>(a, ep, 1, st);
+        case 11: return launch_one<64, 32, 32, 32, 2, 64, true, true, BKC, EPI>(a, ep, 1, st);
+        case 13: return launch_one<64, 32, 32, 32, 2, 32, true, true, BKC, EPI>(a, ep, 1, st);
+        default: return VQA_ERR_ARG;
+    }
+}
+
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// tile / split-k choice: fill 256 CUs (>= ~2 blocks per CU when the problem allows it)
-void choose(int M, int N, int K, int& big, int& split) {
-    const int64_t blocks_big = cdiv(M, 128) * cdiv(N, 128);
-    const int64_t blocks_small = cdiv(M, 64) * cdiv(N, 64);
-    big = (blocks_big >= 384) ? 1 : 0;
+int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
+int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
+int g_gru_cfg = 7;      // tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config)
+
+// Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
+//  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 32, and
+//    enough split-k slabs for >= 512 workgroups (dWv 696 us = 111 TFLOP/s);
+//  * tall activations (M >= 2048): 64x128 tiles (v_linear_v forward 746 us = 104 TFLOP/s),
+//    64x64 when N is narrow;
+//  * batch-sized M (512): 64x32 tiles with in-block split-k (NN) / 64x64 BK 64 (NT).
+void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
+    int64_t target;
+    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 1 : 3; target = 512; }
+    else if (M >= 2048) { cfg = (N >= 512) ? 6 : 3; target = 256; }
+    else { cfg = tB ? 4 : 7; target = 256; }
+    if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
+    const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
     if (split <= 0) {
-        const int64_t blocks = big ? blocks_big : blocks_small;
         split = 1;
         if ((N % 4) == 0) {
-            while (blocks * split < 256 && K / (split * 2) >= 256 && split < 16) split *= 2;
+            while (blocks * split < target && K / (split * 2) >= 256 && split < 16) split *= 2;
         }
     }
 }
 
+GemmArgs make_args(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, const float* D, int ldd) {
+    GemmArgs a;
+    a.M = M; a.N = N; a.K = K;
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.bias = bias; a.D = D; a.ldd = ldd;
+    a.vecA = (lda % 4 == 0) && vqa_aligned16(A);
+    a.vecB = (ldb % 4 == 0) && vqa_aligned16(B);
+    a.slab_stride = 0;
+    a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
+    return a;
+}
+
 }  // namespace
 
-extern "C" int64_t vqa_gemm_workspace_floats(int M, int N, int K, int split_k) {
-    int big, split = split_k;
-    choose(M, N, K, big, split);
+extern "C" int64_t vqa_gemm_workspace_floats(int transA, int transB, int M, int N, int K, int split_k) {
+    int cfg, split = split_k;
+    choose(transA, transB, M, N, K, cfg, split);
     return split > 1 ? (int64_t)split * M * N : 0;
+}
+
+extern "C" int vqa_gemm_set_config(int cfg) {
+    VQA_REQUIRE(cfg >= -1 && cfg < NUM_CFG, VQA_ERR_ARG);
+    g_force_cfg = cfg;
+    return VQA_OK;
+}
+
+extern "C" int vqa_gemm_set_gru_config(int cfg) {
+    VQA_REQUIRE(cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13, VQA_ERR_ARG);
+    g_gru_cfg = cfg;
+    return VQA_OK;
 }
 
 extern "C" int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
                             float* workspace, int64_t workspace_floats, void* stream) {
+    return vqa_gemm_f32_ex(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, D, ldd, split_k, workspace,
+                           workspace_floats, g_max_blocks, stream);
+}
+
+extern "C" int vqa_gemm_set_order(int order) {
+    g_force_order = (order == 0 || order == 1) ? order : -1;
+    return VQA_OK;
+}
+
+extern "C" int vqa_gemm_set_max_blocks(int n) {
+    g_max_blocks = n > 0 ? n : 0;
+    return VQA_OK;
+}
+
+extern "C" int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                               int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
+                               float* workspace, int64_t workspace_floats, int max_blocks, void* stream) {
     VQA_REQUIRE(M >= 0 && N >= 0 && K >= 0, VQA_ERR_ARG);
     if (M == 0 || N == 0) return VQA_OK;
     VQA_REQUIRE(A && B && C, VQA_ERR_ARG);
@@ -270,28 +630,21 @@ extern "C" int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const f
     VQA_REQUIRE(D == nullptr || ldd >= N, VQA_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    int big, split = split_k;
-    choose(M, N, K, big, split);
+    int cfg, split = split_k;
+    choose(transA, transB, M, N, K, cfg, split);
     if (split > 1 && ((N % 4) != 0 || workspace == nullptr)) split = 1;
 
-    GemmArgs a;
-    a.M = M; a.N = N; a.K = K;
-    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
-    a.bias = bias; a.D = D; a.ldd = ldd;
-    a.vecA = (lda % 4 == 0) && vqa_aligned16(A);
-    a.vecB = (ldb % 4 == 0) && vqa_aligned16(B);
+    GemmArgs a = make_args(M, N, K, A, lda, B, ldb, C, ldc, bias, D, ldd);
     if (split > 1) {
         VQA_REQUIRE(workspace_floats >= (int64_t)split * M * N, VQA_ERR_WORKSPACE);
-        int kps = (int)cdiv(cdiv(K, split), BK) * BK;
+        int kps = (int)cdiv(cdiv(K, split), 64) * 64;
         a.k_per_split = kps;
         split = (int)cdiv(K, kps);
     }
-    int rc;
     if (split > 1) {
         // slab 0 also carries bias / addend, so the reduce is a plain sum
         a.C = workspace; a.ldc = N; a.slab_stride = (int64_t)M * N;
-        rc = big ? launch_cfg<128, 128, 64, 64>(transA, transB, a, split, st)
-                 : launch_cfg<64, 64, 32, 32>(transA, transB, a, split, st);
+        int rc = launch_by_id(cfg, transA, transB, a, split, st, max_blocks);
         if (rc != VQA_OK) return rc;
         const int64_t n4 = (int64_t)M * N / 4;
         const int grid = (int)std::min<int64_t>(cdiv(n4, 256), 2048);
@@ -299,8 +652,99 @@ extern "C" int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const f
         VQA_CHECK_LAUNCH();
         return VQA_OK;
     }
-    a.C = C; a.ldc = ldc; a.slab_stride = 0;
-    a.k_per_split = (int)cdiv(std::max(K, 1), BK) * BK;
-    return big ? launch_cfg<128, 128, 64, 64>(transA, transB, a, 1, st)
-               : launch_cfg<64, 64, 32, 32>(transA, transB, a, 1, st);
+    a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
+    return launch_by_id(cfg, transA, transB, a, 1, st, max_blocks);
+}
+
+// ---------------------------------------------------------------------------- fused GRU recurrence
+// tf.contrib.rnn.GRUCell + tf.nn.dynamic_rnn(sequence_length) (vlmap/modules.py:124-140): two
+// GEMM launches per time step with the gate math in their epilogues.
+extern "C" int vqa_gru_seq_fwd(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
+                               float* r, float* u, float* c, float* rh, int T, int B, int H, void* stream) {
+    return vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, len, hs, r, u, c, rh, T, B, H, 0, B, stream);
+}
+
+// rows [row0, row0 + rows) of the batch only (independent chains: one per stream)
+extern "C" int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
+                                    float* r, float* u, float* c, float* rh, int T, int B, int H, int row0, int rows,
+                                    void* stream) {
+    VQA_REQUIRE(xp && Wg_h && Wc_h && len && hs && r && u && c && rh && T >= 0 && B > 0 && H > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= B, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0, VQA_ERR_ALIGN);
+    if (rows == 0) return VQA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t BH = (int64_t)B * H, o = (int64_t)row0 * H;
+    for (int t = 0; t < T; ++t) {
+        float* xpt = xp + ((int64_t)t * B + row0) * 3 * H;
+        const float* hp = hs + t * BH + o;
+        EpiArgs eg{};
+        eg.H = H; eg.h_prev = hp; eg.o0 = r + t * BH + o; eg.o1 = u + t * BH + o; eg.o2 = rh + t * BH + o;
+        GemmArgs ag = make_args(rows, 2 * H, H, hp, H, Wg_h, 2 * H, nullptr, 0, nullptr, xpt, 3 * H);
+        int rc = launch_gru<EPI_GATES>(g_gru_cfg, ag, eg, st);
+        if (rc != VQA_OK) return rc;
+        EpiArgs ec{};
+        ec.H = H; ec.t = t; ec.len = len + row0; ec.h_prev = hp; ec.i0 = u + t * BH + o; ec.o0 = c + t * BH + o;
+        ec.o1 = hs + (t + 1) * BH + o;
+        GemmArgs ac = make_args(rows, H, H, rh + t * BH + o, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
+        rc = launch_gru<EPI_CAND>(g_gru_cfg, ac, ec, st);
+        if (rc != VQA_OK) return rc;
+    }
+    return VQA_OK;
+}
+
+// Back-propagation through time.  dh_T [B,H] is the gradient wrt the final state (consumed:
+// used as scratch); dxp [T,B,3H] receives (dr_pre | du_pre | dc_pre) per step; dh0 [B,H]
+// scratch/returns the gradient wrt the initial state.
+extern "C" int vqa_gru_seq_bwd(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                               const float* hs, const float* r, const float* u, const float* c, float* dxp,
+                               float* dh_scratch, int T, int B, int H, void* stream) {
+    return vqa_gru_seq_bwd_rows(dh_T, Wg_h, Wc_h, len, hs, r, u, c, dxp, dh_scratch, T, B, H, 0, B, stream);
+}
+
+extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                                    const float* hs, const float* r, const float* u, const float* c, float* dxp,
+                                    float* dh_scratch, int T, int B, int H, int row0, int rows, void* stream) {
+    VQA_REQUIRE(dh_T && Wg_h && Wc_h && len && hs && r && u && c && dxp && dh_scratch && T >= 0 && B > 0 && H > 0,
+                VQA_ERR_ARG);
+    VQA_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= B, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0, VQA_ERR_ALIGN);
+    if (T == 0 || rows == 0) return VQA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t BH = (int64_t)B * H, o = (int64_t)row0 * H;
+    const int ld = 3 * H;
+    len += row0;
+    float* dhT = dh_T + o;
+    float* dhS = dh_scratch + o;
+    float* dh_acc = dhS;   // running dL/dh_{t-1} (partial)
+    // first half of step T-1 from dh_T
+    {
+        const int t = T - 1;
+        float* dxpt = dxp + ((int64_t)t * B + row0) * ld;
+        int rc = vqa_gru_bwd_a(dhT, hs + t * BH + o, u + t * BH + o, c + t * BH + o, len, t, dxpt + 2 * H, ld,
+                               dxpt + H, ld, dh_acc, rows, H, stream);
+        if (rc != VQA_OK) return rc;
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        float* dxpt = dxp + ((int64_t)t * B + row0) * ld;
+        // drh = dc_pre * Wc_h^T ; epilogue: dr_pre, dh_acc += drh*r
+        EpiArgs e1{};
+        e1.H = H; e1.ldo = ld; e1.h_prev = hs + t * BH + o; e1.i0 = r + t * BH + o; e1.o0 = dxpt; e1.o1 = dh_acc;
+        GemmArgs a1 = make_args(rows, H, H, dxpt + 2 * H, ld, Wc_h, H, nullptr, 0, nullptr, nullptr, 0);
+        int rc = launch_gru<EPI_BWD_RH>(g_gru_cfg, a1, e1, st);
+        if (rc != VQA_OK) return rc;
+        // dh_{t-1} = (dr_pre|du_pre) * Wg_h^T + dh_acc ; epilogue: first half of step t-1
+        if (t > 0) {
+            float* dxpp = dxp + ((int64_t)(t - 1) * B + row0) * ld;
+            float* dh_next = (dh_acc == dhS) ? dhT : dhS;
+            EpiArgs e2{};
+            e2.H = H; e2.t = t - 1; e2.ldo = ld; e2.len = len; e2.h_prev = hs + (t - 1) * BH + o;
+            e2.i0 = u + (t - 1) * BH + o; e2.i1 = c + (t - 1) * BH + o; e2.o0 = dxpp + 2 * H; e2.o1 = dxpp + H;
+            e2.o2 = dh_next;
+            GemmArgs a2 = make_args(rows, H, 2 * H, dxpt, ld, Wg_h, 2 * H, nullptr, 0, nullptr, dh_acc, H);
+            rc = launch_gru<EPI_BWD_DH>(g_gru_cfg, a2, e2, st);
+            if (rc != VQA_OK) return rc;
+            dh_acc = dh_next;
+        }
+    }
+    return VQA_OK;
 }

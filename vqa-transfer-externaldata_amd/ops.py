@@ -33,7 +33,7 @@ def gemm(A, B, transA=False, transB=False, bias=None, addend=None, split_k=0, ou
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == K
     Cm = out if out is not None else _f32(M, N, like=A)
-    nws = int(lib.vqa_gemm_workspace_floats(M, N, K, split_k))
+    nws = int(lib.vqa_gemm_workspace_floats(int(transA), int(transB), M, N, K, split_k))
     ws = _f32(max(nws, 4), like=A)
     _lib.check(lib.vqa_gemm_f32(int(transA), int(transB), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(Cm),
                                 Cm.stride(0), _p(bias), _p(addend), addend.stride(0) if addend is not None else 0,
