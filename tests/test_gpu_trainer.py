@@ -1,0 +1,118 @@
+"""GPU end-to-end tests of the Model / Trainer / Evaler mirrors on synthetic data."""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(tmp_path, model_type="vlmap_answer", **kw):
+    from vqa_transfer_externaldata_amd import trainer
+    c = trainer.parse_config(["--batch_size", "32", "--max_train_iter", "12", "--train_average_iter", "4",
+                              "--val_average_iter", "2", "--validation_step", "6", "--checkpoint_step", "6",
+                              "--heavy_summary_step", "6", "--model_type", model_type, "--learning_rate", "0.002"])
+    Vq, A = 60, 40
+    c.vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
+    c.answer_dict = {"vocab": ["a%d" % i for i in range(A)], "dict": {"a%d" % i: i for i in range(A)},
+                     "num_train_answer": 30, "is_object": [i % 2 for i in range(A)],
+                     "is_attribute": [1 - i % 2 for i in range(A)]}
+    c.synthetic = 1
+    c.train_dir = str(tmp_path / "run")
+    c.tf_record_dir = str(tmp_path / "data")
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c, Vq, A
+
+
+def _features(n_img=24, R=36, D=64):
+    rng = np.random.default_rng(0)
+    return {"features": np.maximum(rng.standard_normal((n_img, R, D)), 0).astype(np.float32),
+            "spatials": np.zeros((n_img, R, 6), np.float32), "normal_boxes": np.zeros((n_img, R, 4), np.float32),
+            "num_boxes": np.full(n_img, R, np.int32), "max_box_num": R, "vfeat_dim": D}
+
+
+def _datasets(Vq, A):
+    from vqa_transfer_externaldata_amd import input_ops_vqa as io
+    return {"train": io.synthetic_split(96, 24, Vq, A, seed=1), "val": io.synthetic_split(40, 24, Vq, A, seed=2),
+            "testval": io.synthetic_split(40, 24, Vq, A, seed=3)}
+
+
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard"])
+def test_trainer_runs_logs_checkpoints_and_learns(tmp_path, model_type):
+    from vqa_transfer_externaldata_amd import trainer
+    c, Vq, A = _config(tmp_path, model_type)
+    t = trainer.Trainer(c, datasets=_datasets(Vq, A), image_features=_features())
+    assert set(t.model.report) == {
+        "answer_train_loss", "answer_report_loss", "answer_acc", "exist_acc", "test_acc", "normal_test_acc",
+        "normal_test_object_acc", "normal_test_attribute_acc", "normal_exist_acc", "normal_train_exist_acc",
+        "max_exist_acc", "test_max_acc", "test_max_exist_acc"}
+    assert set(t.model.output) == {"att_score", "logit", "pred", "test_obj_score", "test_obj_max_score",
+                                   "test_attr_score", "test_attr_max_score", "all_score", "max_train_score"}
+    if model_type == "vlmap_answer":
+        assert not any(v.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer")
+                       for v in t.train_vars)
+        assert sorted({v.split("/")[0] for v in t.transfer_vars}) == ["joint_fc", "pooled_linear_l", "q_linear_l"]
+        # untrained WordWeightAnswer head: logits -100 (vlmap/modules.py:601-602)
+        assert float(t.model.output["logit"].max()) == -100.0
+    step, summary, loss0, report, dt = t.run_train_step(True)
+    assert step == 1 and summary is not None and dt > 0 and np.isfinite(loss0)
+    t.train()
+    assert t.global_step == 13
+    assert os.path.exists(os.path.join(c.train_dir, "model-2")) and os.path.exists(os.path.join(c.train_dir, "model-8"))
+    assert os.path.exists(os.path.join(c.train_dir, "summaries.jsonl"))
+    _, _, loss1, _, _ = t.run_val_step(False, "val")
+    if model_type == "standard":
+        assert loss1 < loss0                                         # all variables train -> loss drops
+
+
+def test_checkpoint_restore_and_transfer_load(tmp_path):
+    from vqa_transfer_externaldata_amd import trainer
+    c, Vq, A = _config(tmp_path, "vlmap_answer")
+    t = trainer.Trainer(c, datasets=_datasets(Vq, A), image_features=_features())
+    for _ in range(3):
+        t.run_train_step(False)
+    path = t.save_checkpoint()
+    sd = torch.load(path)
+    assert "v_linear_v/fc/weights" in sd and "v_linear_v/fc/weights/Adam" in sd and int(sd["global_step"]) == 3
+    # full restore
+    c2, _, _ = _config(tmp_path, "vlmap_answer", checkpoint=path, train_dir=str(tmp_path / "run2"))
+    t2 = trainer.Trainer(c2, datasets=_datasets(Vq, A), image_features=_features())
+    assert t2.global_step == 3
+    for n, p in t.model.variables().items():
+        assert torch.equal(p, t2.model.variables()[n]), n
+    assert torch.equal(t.model.engine.m_flat, t2.model.engine.m_flat)
+    # transfer-only restore (pretrained_param_path): only q_linear_l / pooled_linear_l / joint_fc change
+    c3, _, _ = _config(tmp_path, "vlmap_answer", pretrained_param_path=path, train_dir=str(tmp_path / "run3"),
+                       seed=999)
+    t3 = trainer.Trainer(c3, datasets=_datasets(Vq, A), image_features=_features())
+    for n, p in t3.model.variables().items():
+        same = torch.equal(p.cpu(), sd[n])
+        assert same == (n.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc")) or n.endswith("biases") \
+            or "LayerNorm" in n or n.startswith("WordWeightAnswer") or "gru_cell" in n and n.endswith("bias"), n
+
+
+def test_evaler_results_schema(tmp_path):
+    from vqa_transfer_externaldata_amd import evaler, trainer
+    c, Vq, A = _config(tmp_path, "standard")
+    ds = _datasets(Vq, A)
+    t = trainer.Trainer(c, datasets=ds, image_features=_features())
+    t.run_train_step(False)
+    ckpt = t.save_checkpoint()
+    ec = argparse.Namespace(**vars(c))
+    ec.checkpoint, ec.split, ec.max_iter, ec.dump_heavy_output = ckpt, "testval", -1, True
+    ev = evaler.Evaler(ec, image_features=_features(), data=ds["testval"])
+    res = ev.eval()
+    saved = pickle.load(open(ev.save_pkl, "rb"))
+    assert set(saved) == {"qid2result", "avg_eval_report"}
+    assert len(saved["qid2result"]) == 40
+    r = saved["qid2result"][0]
+    assert set(r) == {"image_id", "pred", "question", "score", "max_train_score", "test_obj_score",
+                      "test_obj_max_score", "test_attr_score", "test_attr_max_score", "heavy_output_idx"}
+    assert r["pred"].startswith("a") and r["question"].startswith("w")
+    rep = saved["avg_eval_report"]
+    assert rep["answer_acc_num_point"] == 40 and "testonly_score" in rep and "test_obj_only_score_num_point" in rep
+    assert np.load(ev.save_hdf5)["condition"].shape == (40, 1024)

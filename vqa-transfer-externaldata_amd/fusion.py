@@ -211,6 +211,26 @@ class FusionEngine:
             pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
             joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False))
 
+    def resize(self, B, T, global_batch=None):
+        """Re-target the engine to another batch size / padded question length (the reference pads
+        each batch to its own max length, input_ops_vqa_tf_record_memft.py:62-71, and the last batch
+        of an epoch is short).  Parameters and optimiser state are untouched; the workspace only
+        grows."""
+        d = self.dims
+        if B == d.B and T == d.T and global_batch is None:
+            return
+        d.B, d.T = B, T
+        d.inv_global_batch = 1.0 / float(global_batch or B)
+        need = int(self.lib.vqa_fusion_workspace_bytes(C.byref(d)))
+        if need <= 0:
+            raise _lib.VqaHotError("vqa_fusion_workspace_bytes rejected the dims")
+        if need > self.workspace.numel():
+            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        self._tensor_cache = {}
+        for a in ("_keep_att", "_keep_joint"):
+            if hasattr(self, a):
+                delattr(self, a)
+
     # ------------------------------------------------------------------ workspace views
     def tensor(self, name):
         """Named intermediate (reference mid_result / output key) as a torch view."""

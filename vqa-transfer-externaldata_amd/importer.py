@@ -1,0 +1,28 @@
+"""String -> Model class registry, the counterpart of vqa/importer.py:1-52.
+
+Only the two models on the hot path are built natively;
+the reference's 14 ablation variants are listed so that a request for one fails
+with a precise message instead of an import error."""
+
+_NATIVE = ("standard", "vlmap_answer")
+_REFERENCE_ONLY = (
+    "vqa", "standard_testmask", "standard_word2vec", "vlmap_only", "vlmap_finetune", "vlmap_answer_vqa_all",
+    "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_noc", "vlmap_answer_nocarch", "vlmap_answer_adapt",
+    "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise")
+
+
+def get_model_types():
+    return list(_NATIVE)
+
+
+def get_model_class(model_type="vlmap_answer"):
+    if model_type == "standard":
+        from .model_standard import Model
+    elif model_type == "vlmap_answer":
+        from .model_vlmap_answer import Model
+    elif model_type in _REFERENCE_ONLY:
+        raise ValueError("model_type %r is an ablation variant of the reference that is out of scope of the "
+                         "MI355X hot path (supported: %s)" % (model_type, ", ".join(_NATIVE)))
+    else:
+        raise ValueError("Unknown model_type: {}".format(model_type))
+    return Model

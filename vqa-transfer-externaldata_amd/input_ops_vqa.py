@@ -1,0 +1,104 @@
+"""Batch provider with the contract of vqa/datasets/input_ops_vqa_tf_record_memft.py:6-82.
+
+create(batch_size, data_dir, split, is_train, shuffle) returns an iterator of batch dicts
+  id i64[B], image_id str[B], image_idx i64[B], q_intseq i32[B, Tmax_of_batch] (zero padded),
+  q_intseq_len i32[B], answer_target f32[B, num_answers] (dense from sparse ids/scores)
+The last batch of a pass may be short.  Behaviour kept from the reference pipeline:
+  * train (is_train and shuffle): one shuffle, batches cached after batching (so the same
+    batches repeat every epoch, input_ops...:61-78), repeated 1000 times;
+  * otherwise a single ordered pass, then StopIteration (the reference's OutOfRangeError,
+    vqa/evaler.py:119-123).
+Storage: `<data_dir>/<split>.npz` (ragged arrays + offsets) and `<data_dir>/data_info.json`
+{"num_answers": A}; the tfrecord/tf.Example reader of the reference needs TensorFlow and is a
+later-round item.  `SyntheticSplit` makes the same dicts from a seed.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+
+class SplitData:
+    """In-memory examples of one split (the fields of the reference's tf.Example schema,
+    data/tools/vqa_v2/generator_tf_record_memft_genome.py:184-194)."""
+
+    def __init__(self, qid, image_id, image_idx, q_flat, q_off, ans_ids, ans_scores, ans_off, num_answers):
+        self.qid, self.image_id, self.image_idx = qid, image_id, image_idx
+        self.q_flat, self.q_off = q_flat, q_off
+        self.ans_ids, self.ans_scores, self.ans_off = ans_ids, ans_scores, ans_off
+        self.num_answers = int(num_answers)
+
+    def __len__(self):
+        return len(self.qid)
+
+    @staticmethod
+    def load(data_dir, split):
+        with open(os.path.join(data_dir, "data_info.json")) as f:
+            num_answers = json.load(f)["num_answers"]
+        z = np.load(os.path.join(data_dir, split + ".npz"), allow_pickle=False)
+        return SplitData(z["qid"], z["image_id"], z["image_idx"], z["q_flat"], z["q_off"], z["ans_ids"],
+                         z["ans_scores"], z["ans_off"], num_answers)
+
+    def save(self, data_dir, split):
+        os.makedirs(data_dir, exist_ok=True)
+        with open(os.path.join(data_dir, "data_info.json"), "w") as f:
+            json.dump({"num_answers": self.num_answers}, f)
+        np.savez(os.path.join(data_dir, split + ".npz"), qid=self.qid, image_id=self.image_id,
+                 image_idx=self.image_idx, q_flat=self.q_flat, q_off=self.q_off, ans_ids=self.ans_ids,
+                 ans_scores=self.ans_scores, ans_off=self.ans_off)
+
+    def batch(self, rows):
+        B = len(rows)
+        lens = (self.q_off[rows + 1] - self.q_off[rows]).astype(np.int32)
+        T = max(int(lens.max()) if B else 0, 1)
+        q = np.zeros((B, T), np.int32)
+        tgt = np.zeros((B, self.num_answers), np.float32)
+        for i, r in enumerate(rows):
+            q[i, :lens[i]] = self.q_flat[self.q_off[r]:self.q_off[r + 1]]
+            a0, a1 = self.ans_off[r], self.ans_off[r + 1]
+            tgt[i, self.ans_ids[a0:a1]] = self.ans_scores[a0:a1]      # tf.sparse_to_dense
+        return {"id": self.qid[rows].astype(np.int64), "image_id": self.image_id[rows],
+                "image_idx": self.image_idx[rows].astype(np.int64), "q_intseq": q, "q_intseq_len": lens,
+                "answer_target": tgt}
+
+
+def synthetic_split(num_examples, num_images, vocab_size, num_answers, max_len=14, min_len=3, seed=0):
+    """Synthetic examples shaped like the VQA-v2 records: 1-3 answers per question
+    with scores from {0.3, 0.6, 0.9, 1.0}, 3..14 tokens."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(min_len, max_len + 1, size=num_examples)
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    q_flat = rng.integers(1, max(vocab_size - 3, 2), size=int(q_off[-1])).astype(np.int32)
+    nans = rng.integers(1, 4, size=num_examples)
+    ans_off = np.concatenate([[0], np.cumsum(nans)]).astype(np.int64)
+    ans_ids = np.concatenate([rng.choice(num_answers, size=k, replace=False) for k in nans]).astype(np.int32)
+    ans_scores = rng.choice(np.array([0.3, 0.6, 0.9, 1.0], np.float32), size=int(ans_off[-1]))
+    image_idx = rng.integers(0, num_images, size=num_examples).astype(np.int64)
+    image_id = np.array(["synthetic-%08d.jpg" % i for i in image_idx])
+    return SplitData(np.arange(num_examples, dtype=np.int64), image_id, image_idx, q_flat, q_off, ans_ids,
+                     ans_scores, ans_off, num_answers)
+
+
+def create(batch_size, data_dir, split, is_train=True, scope="vqa", shuffle=True, seed=0, data=None,
+           repeat=1000):
+    """Iterator of batch dicts; `data` (a SplitData) overrides the files under data_dir."""
+    d = data if data is not None else SplitData.load(data_dir, split)
+    n = len(d)
+    order = np.arange(n)
+    if is_train and shuffle:
+        np.random.default_rng(seed).shuffle(order)
+    chunks = [order[i:i + batch_size] for i in range(0, n, batch_size)]
+
+    def gen():
+        cache = {}
+        for _ in range(repeat if is_train else 1):
+            for ci, rows in enumerate(chunks):
+                if is_train:
+                    if ci not in cache:
+                        cache[ci] = d.batch(rows)          # dataset.cache() after padded_batch
+                    yield cache[ci]
+                else:
+                    yield d.batch(rows)
+    return gen()

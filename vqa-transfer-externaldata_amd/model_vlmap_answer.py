@@ -1,0 +1,271 @@
+"""MI355X counterpart of vqa/model_vlmap_answer.py (and, via model_standard.py, of
+vqa/model_standard.py): same constructor, attributes and variable names; the graph
+is replaced by libvqahot.so driven through FusionEngine.
+
+Reference contract reproduced (vqa/model_vlmap_answer.py:17-100, 304-326):
+  Model(batch, config, is_train=True, image_features=None) -> build() sets
+  .loss, .losses, .report (13 keys), .output, .mid_result, .heavy_output, .vocab,
+  .answer_dict; filter_train_vars / filter_transfer_vars select by top-level scope.
+Differences forced by the platform: there is no deferred TF graph, so build() runs
+the forward pass for the CURRENT self.batch (set_batch() swaps it); tensors are torch
+CUDA tensors; the dropout that the reference draws inside tf.nn.dropout comes from
+explicit reproducible keep-masks keyed by (config.seed, step).
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import fusion as F
+from .log import log
+
+W_DIM = 300   # Word dimension           (vqa/model_vlmap_answer.py:10-12)
+L_DIM = 1024  # Language dimension
+V_DIM = 1024
+
+
+def get_dummy_data():
+    """util/__init__.py:5-17 (--debug 1): zero features for 500 images, one box each."""
+    bn, bs, dim = 500, 36, 2048
+    return (np.zeros([bn, bs, dim], np.float32), np.zeros([bn, bs, 6], np.float32),
+            np.zeros([bn, bs, 4], np.float32), np.ones([bn], np.int32), bs, dim)
+
+
+def _load_pickle(path):
+    with open(path, "rb") as f:
+        try:
+            return pickle.load(f)
+        except UnicodeDecodeError:      # python-2 cPickle files of the reference
+            f.seek(0)
+            return pickle.load(f, encoding="latin1")
+
+
+def learn_glove_init(vocab, glove=None, rng=None):
+    """modules.LearnGloVe (vlmap/modules.py:415-448): rows of words found in GloVe get
+    their vector, others zeros.  `glove` = {'dict': word->row, 'param': [n,300]} or None
+    (GloVe files are download-only; then every row starts at zero like an OOV word, or
+    small uniform noise when an rng is given for synthetic runs)."""
+    n = len(vocab["vocab"])
+    w = np.zeros([n, W_DIM], np.float32)
+    if glove is not None:
+        for i, word in enumerate(vocab["vocab"]):
+            j = glove["dict"].get(word)
+            if j is not None and j < glove["param"].shape[0]:
+                w[i] = glove["param"][j]
+    elif rng is not None:
+        w = rng.uniform(-0.01, 0.01, size=w.shape).astype(np.float32)
+    return w
+
+
+def answer_exist_mask(answer_dict, word_answer_dict=None):
+    """modules.AnswerExistMask (vlmap/modules.py:575-586)."""
+    mask = np.zeros([len(answer_dict["vocab"])], np.float32)
+    if word_answer_dict is not None:
+        for i, a in enumerate(answer_dict["vocab"]):
+            if a in word_answer_dict["dict"]:
+                mask[i] = 1.0
+    else:
+        mask += 1.0
+    return mask
+
+
+def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_bias=-100.0):
+    """modules.WordWeightAnswer (vlmap/modules.py:589-627): head initialised by answer-string
+    lookup into the exported class weights; missing answers get weight 0 and bias -100."""
+    dim = len(answer_dict["vocab"])
+    weights = np.zeros([input_dim, dim], np.float32)
+    biases = np.zeros([dim], np.float32) + default_bias
+    if word_weights is not None:
+        wd = word_weights["answer_dict"]["dict"]
+        for i, a in enumerate(answer_dict["vocab"]):
+            if a in wd:
+                weights[:, i] = word_weights["class_weights"][:, wd[a]]
+                biases[i] = word_weights["class_biases"][wd[a]]
+    return weights, biases
+
+
+def load_word_weight_dir(path):
+    """word_weights_model-N/ written by export_word_weights (weights.npz replaces weights.hdf5)."""
+    ad = _load_pickle(os.path.join(path, "answer_dict.pkl"))
+    z = np.load(os.path.join(path, "weights.npz"))
+    return {"answer_dict": ad, "class_weights": z["class_weights"], "class_biases": z["class_biases"]}
+
+
+class Model(object):
+    MODEL_TYPE = "vlmap_answer"
+
+    def __init__(self, batch, config, is_train=True, image_features=None):
+        self.batch = batch
+        self.config = config
+        self.image_dir = getattr(config, "image_dir", None)
+        self.is_train = is_train
+        self.device = torch.device(getattr(config, "device", "cuda:0"))
+
+        self.word_weight_dir = getattr(config, "vlmap_word_weight_dir", None)
+        if self.word_weight_dir is None and self.MODEL_TYPE == "vlmap_answer":
+            log.warning("word_weight_dir is None")
+
+        self.losses, self.report, self.mid_result = {}, {}, {}
+        self.output, self.heavy_output, self.vis_image = {}, {}, {}
+
+        # vocab / answer_dict: pickles at the reference's paths, or in-memory dicts on the config
+        self.vocab = getattr(config, "vocab", None) or _load_pickle(config.vocab_path)
+        self.answer_dict = getattr(config, "answer_dict", None) or _load_pickle(
+            os.path.join(config.tf_record_dir, "answer_dict.pkl"))
+        self.num_answer = len(self.answer_dict["vocab"])
+        self.num_train_answer = self.answer_dict["num_train_answer"]
+        A = self.num_answer
+        self.train_answer_mask = (np.arange(A) < self.num_train_answer).astype(np.float32)
+        self.test_answer_mask = 1.0 - self.train_answer_mask
+        self.obj_answer_mask = np.asarray(self.answer_dict["is_object"], np.float32)
+        self.attr_answer_mask = np.asarray(self.answer_dict["is_attribute"], np.float32)
+
+        word_weights = None
+        if self.word_weight_dir is not None:
+            word_weights = getattr(config, "word_weights", None) or load_word_weight_dir(self.word_weight_dir)
+        self.answer_exist_mask = answer_exist_mask(
+            self.answer_dict, word_weights["answer_dict"] if word_weights else None)
+
+        if getattr(config, "debug", 0):
+            feats = get_dummy_data()
+        elif image_features is None:
+            log.infov("loading image features...")
+            z = np.load(config.vfeat_path, mmap_mode="r")    # .npz/.npy re-pack of the reference hdf5
+            feats = (z["image_features"], z["spatial_features"], z["normal_boxes"], z["num_boxes"],
+                     int(z["max_box_num"]), int(z["vfeat_dim"]))
+            log.infov("done")
+        else:
+            feats = (image_features["features"], image_features["spatials"], image_features["normal_boxes"],
+                     image_features["num_boxes"], image_features["max_box_num"], image_features["vfeat_dim"])
+        (self.features, self.spatials, self.normal_boxes, self.num_boxes, self.max_box_num, self.vfeat_dim) = feats
+
+        self._word_weights = word_weights
+        self._step = 0
+        self._engine = None
+        self.build()
+
+    # ---------------------------------------------------------------- variable filters
+    def filter_train_vars(self, trainable_vars):
+        return F.filter_train_vars(list(trainable_vars), self.MODEL_TYPE)
+
+    def filter_transfer_vars(self, all_vars):
+        return F.filter_transfer_vars(list(all_vars), self.MODEL_TYPE)
+
+    # ---------------------------------------------------------------- engine plumbing
+    def _initial_params(self, shapes):
+        cfg = self.config
+        seed = int(getattr(cfg, "seed", 123))
+        g = torch.Generator().manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        sc = F.scope_names(self.MODEL_TYPE)
+        p = {}
+        for n, s in shapes.items():
+            if n == sc["embed"]:
+                p[n] = learn_glove_init(self.vocab, getattr(cfg, "glove", None),
+                                        rng if getattr(cfg, "debug", 0) or getattr(cfg, "synthetic", 0) else None)
+            elif n.endswith("/weights") or n.endswith("/kernel"):
+                lim = (6.0 / (s[0] + s[1])) ** 0.5            # layers.fully_connected: Xavier uniform
+                p[n] = ((torch.rand(s, generator=g) * 2 - 1) * lim).numpy()
+            elif n.endswith("gates/bias") or n.endswith("LayerNorm/gamma"):
+                p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
+            else:
+                p[n] = np.zeros(s, np.float32)
+        if self.MODEL_TYPE == "vlmap_answer":
+            w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
+            p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
+        return p
+
+    def _to_dev(self, a, dtype):
+        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _make_engine(self, B, T):
+        Vq = len(self.vocab["vocab"])
+        shapes = F.variable_shapes(self.MODEL_TYPE, Vq, W_DIM, self.vfeat_dim, V_DIM, self.num_answer)
+        eng = F.FusionEngine(model_type=self.MODEL_TYPE, B=B, R=self.max_box_num, D=self.vfeat_dim, H=V_DIM, T=T,
+                             W=W_DIM, A=self.num_answer, Vq=Vq, N_img=len(self.features),
+                             params=self._initial_params(shapes), device=self.device,
+                             global_batch=getattr(self.config, "global_batch", None))
+        eng.bind_inputs(
+            table=self._to_dev(self.features, torch.float32),        # the whole table lives in HBM (a1)
+            nbox_table=self._to_dev(self.num_boxes, torch.int32),
+            answer_masks={"train": self._to_dev(self.train_answer_mask, torch.float32),
+                          "obj": self._to_dev(self.obj_answer_mask, torch.float32),
+                          "attr": self._to_dev(self.attr_answer_mask, torch.float32),
+                          "exist": self._to_dev(self.answer_exist_mask, torch.float32)})
+        return eng
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def variables(self):
+        """name -> tensor for every variable (TF variable names)."""
+        return dict(self._engine.params)
+
+    def set_batch(self, batch):
+        self.batch = batch
+
+    def _device_batch(self):
+        b = self.batch
+        db = {"image_idx": self._to_dev(b["image_idx"], torch.int64),
+              "q_intseq": self._to_dev(b["q_intseq"], torch.int32),
+              "q_intseq_len": self._to_dev(b["q_intseq_len"], torch.int32),
+              "answer_target": self._to_dev(b["answer_target"], torch.float32)}
+        return db
+
+    # ---------------------------------------------------------------- build = forward
+    def build(self):
+        """build network architecture and loss (here: run it on self.batch)"""
+        db = self._device_batch()
+        B, T = db["q_intseq"].shape
+        gb = getattr(self.config, "global_batch", None)
+        if self._engine is None:
+            self._engine = self._make_engine(B, T)
+        else:
+            self._engine.resize(B, T, gb)
+        eng = self._engine
+        if getattr(self.config, "dropout_off", False):
+            ka = kj = None
+        else:   # tf.nn.dropout is applied unconditionally in the reference (also at eval time)
+            ka, kj = eng.make_keep_masks(int(getattr(self.config, "seed", 123)), self._step)
+        self._step += 1
+        self._db, self._keep = db, (ka, kj)
+        eng.forward(db, ka, kj, want_dz=self.is_train)
+
+        d = eng.dims
+        A, R = d.A, d.R
+        stats = eng.tensor("stats").view(B, 16)
+        rep = eng.tensor("report")
+        keys = [eng.lib.vqa_report_key(i).decode() for i in range(13)]
+        self.report = {k: rep[i] for i, k in enumerate(keys)}
+        self.losses = {"answer": rep[0]}
+        self.loss = rep[0]
+        self.mid_result = {
+            "num_V_ft": eng.tensor("num_V_ft"), "q_linear_v": eng.tensor("q_linear_v").view(B, -1),
+            "att_score": eng.tensor("att_score").view(B, R), "pooled_V_ft": eng.tensor("pooled_V_ft").view(B, -1),
+            "pooled_linear_l": eng.tensor("pooled_linear_l").view(B, -1),
+            "l_linear_l": eng.tensor("l_linear_l").view(B, -1), "joint": eng.tensor("joint").view(B, -1),
+            "logit": eng.tensor("logit").view(B, A), "pred": eng.tensor("pred"),
+        }
+        self.output = {
+            "att_score": self.mid_result["att_score"], "logit": self.mid_result["logit"],
+            "pred": self.mid_result["pred"],
+            "test_obj_score": stats[:, 5], "test_obj_max_score": stats[:, 10],
+            "test_attr_score": stats[:, 6], "test_attr_max_score": stats[:, 11],
+            "all_score": stats[:, 2], "max_train_score": stats[:, 14],
+        }
+        self.heavy_output = {"condition": eng.tensor("condition").view(B, -1)}
+        return self.loss
+
+    # the two halves of optimize_loss that the Trainer drives (vqa/trainer.py:106-114)
+    def backward(self):
+        self._engine.backward()
+
+    def apply_gradients(self, learning_rate, allreduce=None):
+        if allreduce is not None:
+            allreduce(self._engine.grad_flat)
+        self._engine.optimizer_step(learning_rate)
