@@ -250,6 +250,32 @@ int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* params, cons
                         float* embed_slice_sq, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Region-feature extractor, NHWC fp32.
+ * ------------------------------------------------------------------------ */
+/* conv + folded inference BatchNorm (+ residual) (+ ReLU):
+ *   y = [relu]( conv(x, w) * scale[co] + shift[co] + residual )
+ * x [B,Hi,Wi,Ci], w HWIO [kh,kw,Ci,Co] (TF layout), explicit top/left zero padding, output
+ * [B,Ho,Wo,Co]; scale/shift/residual may be NULL.  1x1/stride-1 -> plain MFMA GEMM, otherwise an
+ * implicit GEMM (needs Ci % 32 == 0).  Replaces slim conv2d/conv2d_same + batch_norm(is_training=
+ * False) + relu of resnet_v1 (vlmap/modules.py:143-191) and modules.conv2d (:552-572). */
+int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co,
+                    int stride, int pad_t, int pad_l, int Ho, int Wo, const float* scale, const float* shift,
+                    const float* residual, int relu, float* y, void* stream);
+/* explicit im2col for the 3-channel conv1 (7x7/2): col [B*Ho*Wo, Kpad], zero in the K padding;
+ * mean_host (3 floats on the HOST, may be NULL) is subtracted from in-bounds pixels only
+ * (the RGB mean subtraction of vlmap/modules.py:170-174 precedes the zero padding). */
+int vqa_im2col_nhwc(const float* x, int B, int Hi, int Wi, int Ci, int kh, int kw, int stride, int pad_t, int pad_l,
+                    int Ho, int Wo, const float* mean_host, float* col, int Kpad, void* stream);
+/* slim pool1: max_pool2d(3x3, stride 2, 'SAME'); y [B,ceil(Hi/2),ceil(Wi/2),C] */
+int vqa_maxpool3x3s2_same_nhwc(const float* x, int B, int Hi, int Wi, int C, float* y, void* stream);
+/* resnet_utils.subsample (1x1 max-pool with stride = strided slicing) */
+int vqa_subsample_nhwc(const float* x, int B, int Hi, int Wi, int C, int factor, float* y, void* stream);
+/* tf.image.crop_and_resize (bilinear, extrapolation 0): boxes [n,4] = normalised [y1,x1,y2,x2],
+ * box_ind i32[n] -> out [n,crop_h,crop_w,C]   (modules.roi_pool, vlmap/modules.py:204-216) */
+int vqa_crop_and_resize_nhwc(const float* fmap, int B, int H, int W, int C, const float* boxes,
+                             const int32_t* box_ind, int n_boxes, int crop_h, int crop_w, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement probe (bench.py): HIP events recorded by the library on the
  * op's own stream around every launch group whose label matches.  Labels:
  * "v_linear_v.fwd_gemm", "v_linear_v.dw_gemm", "gru.fwd", "gru.bwd",

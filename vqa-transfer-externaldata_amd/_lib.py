@@ -82,6 +82,11 @@ SIGNATURES = {
     "vqa_sumsq_workspace_floats": (_L, [_L]),
     "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
+    "vqa_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "vqa_im2col_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _P]),
+    "vqa_maxpool3x3s2_same_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "vqa_subsample_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "vqa_crop_and_resize_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "vqa_probe_enable": (_I, [C.c_char_p, _I]),
     "vqa_probe_read": (_I, [C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]),
     "vqa_probe_disable": (_I, []),

@@ -38,6 +38,10 @@ struct GemmArgs {
     int vecA, vecB;       // 16-byte global loads allowed for A / B
     int tiles_m, tiles_n, nsplit;   // 1-D grid: workgroups walk the (split, m, n) tiles
     int m_fastest;                  // tile order inside a split: m fastest (1) or n fastest (0)
+    const float* scale;             // per-column scale (folded BatchNorm), applied to the accumulator
+    int relu;                       // ReLU after scale / bias / addend
+    // implicit-GEMM convolution (A = NHWC activations, row m = output pixel, k = (ky, kx, ci))
+    int Hi, Wi, Ci, Ho, Wo, cstride, pad_t, pad_l, kw;
 };
 
 // XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
@@ -111,6 +115,22 @@ struct Stager {
             }
         }
     }
+    // implicit im2col: one k tile lies inside ONE filter tap (Ci % BK == 0), so the tap offset is
+    // wave-uniform and each lane only adds it to its pre-decoded pixel coordinates.
+    __device__ __forceinline__ void load_conv(const float* g, const int (&iy0)[NV], const int (&ix0)[NV],
+                                              const int (&pix)[NV], int k0, int Hi, int Wi, int Ci, int kw) {
+        const int tap = k0 / Ci, c0 = k0 - tap * Ci;
+        const int ky = tap / kw, kx = tap - ky * kw;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int kq = (idx % KQ) * 4;
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            reg[i] = in ? *reinterpret_cast<const float4*>(g + ((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __device__ __forceinline__ void store(float* s) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -146,7 +166,7 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
@@ -211,8 +231,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         // one tile of register prefetch: enough when >= 2-3 workgroups share a CU
         Stager<BM, BK, A_KC> sa;
         Stager<BN, BK, B_KC> sb;
+        constexpr int NVA = Stager<BM, BK, A_KC>::NV;
+        int iy0[NVA], ix0[NVA], pix[NVA];
+        if (CONV) {
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int idx = threadIdx.x + i * 256;
+                const int m = m0 + idx / (BK / 4);
+                pix[i] = -1; iy0[i] = ix0[i] = 0;
+                if (idx < BM * (BK / 4) && m < p.M) {
+                    const int hw = p.Ho * p.Wo;
+                    const int b = m / hw, r = m - b * hw;
+                    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+                    iy0[i] = oy * p.cstride - p.pad_t;
+                    ix0[i] = ox * p.cstride - p.pad_l;
+                    pix[i] = b * p.Hi * p.Wi;
+                }
+            }
+        }
+        auto load_a = [&](int k0) {
+            if (CONV) sa.load_conv(p.A, iy0, ix0, pix, k0, p.Hi, p.Wi, p.Ci, p.kw);
+            else sa.load(p.A, p.lda, m0, k0, p.M, kend, va);
+        };
         if (nt > 0) {
-            sa.load(p.A, p.lda, m0, kbeg, p.M, kend, va);
+            load_a(kbeg);
             sb.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
             sa.store(L0);
             sb.store(L0 + A_FL);
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             float* cur = (t & 1) ? L1 : L0;
             float* nxt = (t & 1) ? L0 : L1;
             if (t + 1 < nt) {
-                sa.load(p.A, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, va);
+                load_a(kbeg + (t + 1) * BK);
                 sb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, vb);
             }
             compute_tile(cur, cur + A_FL);
@@ -320,6 +362,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 const int rbase = m0 + wm * WM + a * 32 + 4 * (lane >> 5);
                 if (col >= p.N) continue;
                 const float bv = (p.bias != nullptr && first) ? p.bias[col] : 0.f;
+                const float sv = (p.scale != nullptr) ? p.scale[col] : 1.f;
                 float dv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -329,7 +372,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) Cz[(int64_t)row * p.ldc + col] = acc[a][b][r] + bv + dv[r];
+                    if (row < p.M) {
+                        float v = acc[a][b][r] * sv + bv + dv[r];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        Cz[(int64_t)row * p.ldc + col] = v;
+                    }
                 }
             }
         continue;   // next tile (the loop's last barrier already fenced the LDS tiles)
@@ -452,13 +499,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
     constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
     constexpr size_t stage = (EPI == EPI_PLAIN) ? 0 : (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {   // MI355X has 160 KiB of LDS per CU; > 64 KiB needs the opt-in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -579,6 +626,8 @@ GemmArgs make_args(int M, int N, int K, const float* A, int lda, const float* B,
     a.vecB = (ldb % 4 == 0) && vqa_aligned16(B);
     a.slab_stride = 0;
     a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
+    a.scale = nullptr; a.relu = 0;
+    a.Hi = a.Wi = a.Ci = a.Ho = a.Wo = a.cstride = a.pad_t = a.pad_l = a.kw = 0;
     return a;
 }
 
@@ -747,4 +796,33 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
         }
     }
     return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------- convolution (NHWC)
+// slim resnet_v1 inference conv + folded BatchNorm (+ residual) (+ ReLU): vlmap/modules.py:143-191,
+// 219-239, 552-572.  1x1/stride-1 convs are plain GEMMs over [B*H*W, Ci]; every other filter is an
+// implicit GEMM whose A tiles are gathered from the NHWC activations (no im2col buffer).
+extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co,
+                               int stride, int pad_t, int pad_l, int Ho, int Wo, const float* scale,
+                               const float* shift, const float* residual, int relu, float* y, void* stream) {
+    VQA_REQUIRE(x && w && y && B > 0 && Hi > 0 && Wi > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 &&
+                    Ho > 0 && Wo > 0,
+                VQA_ERR_ARG);
+    VQA_REQUIRE((int64_t)B * Ho * Wo < (1ll << 31) && (int64_t)B * Hi * Wi < (1ll << 31), VQA_ERR_ARG);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int M = B * Ho * Wo, K = kh * kw * Ci;
+    const bool plain = (kh == 1 && kw == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == Hi && Wo == Wi);
+    GemmArgs a = make_args(M, Co, K, x, Ci, w, Co, y, Co, shift, residual, Co);
+    a.scale = scale;
+    a.relu = relu;
+    if (plain) {
+        const int cfg = (Co >= 128) ? 6 : 3;
+        return launch_by_id(cfg, 0, 0, a, 1, st, 0);
+    }
+    VQA_REQUIRE(Ci % 32 == 0 && vqa_aligned16(x), VQA_ERR_ALIGN);   // one 32-deep k tile per filter tap
+    a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+    a.kw = kw;
+    const EpiArgs ep{};
+    if (Co >= 128) return launch_one<64, 128, 32, 64, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
+    return launch_one<64, 64, 32, 32, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
 }

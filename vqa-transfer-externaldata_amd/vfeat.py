@@ -1,0 +1,240 @@
+"""Region-feature extractor on MI355X: slim-style ResNet-v1 bottleneck stack + ROI crop
+(SURVEY rows a13-a16).
+
+Counterpart of modules.encode_I_block3 / encode_I_full / roi_pool / I_reduce_dim / I2V
+(vlmap/modules.py:143-239) and of vqa/model_vfeat.py, vqa/model_vfeat_resnet.py.  Inference
+only, as in the reference extraction path (is_training=False -> BatchNorm uses moving
+statistics, folded here to per-channel scale/shift).  Variable names are slim's
+(`resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/weights`, `.../BatchNorm/gamma` ...), the
+contract of data/nets/resnet_v1_50.ckpt.  Layout NHWC, fp32, convolutions on the f32 MFMA.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ENC_I_MEAN = (123.68, 116.78, 103.94)      # vlmap/modules.py:18-20
+SLIM_BN_EPS = 1e-5                          # resnet_arg_scope
+LAYERS_BN_EPS = 1e-3                        # tf.contrib.layers.batch_norm default (modules.conv2d)
+
+BLOCKS_R50_B3 = [("block1", 64, 3, 2), ("block2", 128, 4, 2), ("block3", 256, 6, 2)]
+BLOCKS_R50_FULL = BLOCKS_R50_B3 + [("block4", 512, 3, 1)]
+BLOCKS_R101_FULL = [("block1", 64, 3, 2), ("block2", 128, 4, 2), ("block3", 256, 23, 2), ("block4", 512, 3, 1)]
+
+
+def block_units(base_depth, num_units, stride):
+    """slim resnet_v1_block: stride on the LAST unit."""
+    return [(base_depth * 4, base_depth, 1)] * (num_units - 1) + [(base_depth * 4, base_depth, stride)]
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class ConvBN:
+    """conv weights (HWIO) + BatchNorm folded to scale/shift, resident on the device."""
+
+    def __init__(self, params, prefix, eps, device, wname="/weights", bn="/BatchNorm/", pad_k_to=None):
+        w = np.asarray(params[prefix + wname], np.float32)
+        self.kh, self.kw, self.ci, self.co = w.shape
+        g, b, m, v = (np.asarray(params[prefix + bn + k], np.float64)
+                      for k in ("gamma", "beta", "moving_mean", "moving_variance"))
+        scale = g / np.sqrt(v + eps)
+        shift = b - m * scale
+        w2 = w.reshape(self.kh * self.kw * self.ci, self.co)
+        if pad_k_to is not None and pad_k_to > w2.shape[0]:
+            w2 = np.concatenate([w2, np.zeros((pad_k_to - w2.shape[0], self.co), np.float32)], 0)
+        self.w = torch.from_numpy(np.ascontiguousarray(w2)).to(device)
+        self.scale = torch.from_numpy(scale.astype(np.float32)).to(device)
+        self.shift = torch.from_numpy(shift.astype(np.float32)).to(device)
+
+
+def conv2d(x, cb, stride=1, pad=(0, 0), out_hw=None, residual=None, relu=True):
+    """y = [relu](conv(x)*scale + shift [+ residual]) through vqa_conv2d_nhwc."""
+    lib = _lib.load()
+    B, Hi, Wi, Ci = x.shape
+    assert Ci * cb.kh * cb.kw <= cb.w.shape[0] and x.is_contiguous()
+    Ho, Wo = out_hw if out_hw is not None else (Hi, Wi)
+    y = torch.empty(B, Ho, Wo, cb.co, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vqa_conv2d_nhwc(_p(x), B, Hi, Wi, Ci, _p(cb.w), cb.kh, cb.kw, cb.co, stride, pad[0], pad[1], Ho, Wo,
+                                   _p(cb.scale), _p(cb.shift), _p(residual), int(relu), _p(y), _st(x)),
+               "vqa_conv2d_nhwc")
+    return y
+
+
+def max_pool_3x3_s2_same(x):
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vqa_maxpool3x3s2_same_nhwc(_p(x), B, H, W, Cc, _p(y), _st(x)), "vqa_maxpool3x3s2_same_nhwc")
+    return y
+
+
+def subsample(x, factor):
+    if factor == 1:
+        return x
+    lib = _lib.load()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, (H - 1) // factor + 1, (W - 1) // factor + 1, Cc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vqa_subsample_nhwc(_p(x), B, H, W, Cc, factor, _p(y), _st(x)), "vqa_subsample_nhwc")
+    return y
+
+
+def roi_pool(ftmap, box, height, width):
+    """modules.roi_pool (vlmap/modules.py:204-216): box [B,n,4] normalised [y1,x1,y2,x2]."""
+    lib = _lib.load()
+    B, H, W, Cc = ftmap.shape
+    n = box.shape[1]
+    boxes = box.reshape(-1, 4).contiguous().float()
+    ids = torch.arange(B, device=ftmap.device, dtype=torch.int32).repeat_interleave(n).contiguous()
+    out = torch.empty(B * n, height, width, Cc, dtype=torch.float32, device=ftmap.device)
+    _lib.check(lib.vqa_crop_and_resize_nhwc(_p(ftmap), B, H, W, Cc, _p(boxes), _p(ids), B * n, height, width, _p(out),
+                                            _st(ftmap)), "vqa_crop_and_resize_nhwc")
+    return out.view(B, n, height, width, Cc)
+
+
+class ResNetV1:
+    """modules.encode_I_block3 / encode_I_full: mean subtraction + conv1 + pool1 + bottleneck blocks."""
+
+    def __init__(self, params, blocks=BLOCKS_R50_B3, scope="resnet_v1_50", device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.VqaHotError("ResNetV1 needs a GPU (no CPU fallback)")
+        self.device = torch.device(device)
+        self.blocks = blocks
+        self.conv1 = ConvBN(params, scope + "/conv1", SLIM_BN_EPS, self.device, pad_k_to=148)   # K = 147 -> 148
+        self.units = []
+        cin = self.conv1.co
+        for name, base, n, stride in blocks:
+            for i, (depth, db, s) in enumerate(block_units(base, n, stride)):
+                pre = "%s/%s/unit_%d/bottleneck_v1" % (scope, name, i + 1)
+                u = {"depth": depth, "stride": s,
+                     "shortcut": ConvBN(params, pre + "/shortcut", SLIM_BN_EPS, self.device) if depth != cin else None,
+                     "conv1": ConvBN(params, pre + "/conv1", SLIM_BN_EPS, self.device),
+                     "conv2": ConvBN(params, pre + "/conv2", SLIM_BN_EPS, self.device),
+                     "conv3": ConvBN(params, pre + "/conv3", SLIM_BN_EPS, self.device)}
+                self.units.append(u)
+                cin = depth
+        self.out_channels = cin
+        self._mean = (C.c_float * 3)(*ENC_I_MEAN)
+
+    def stem(self, images):
+        lib = _lib.load()
+        B, H, W, Cc = images.shape
+        assert Cc == 3 and images.dtype == torch.float32 and images.is_contiguous()
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1          # conv2d_same(7, stride 2): pad 3/3, VALID
+        col = torch.empty(B * Ho * Wo, 148, dtype=torch.float32, device=images.device)
+        _lib.check(lib.vqa_im2col_nhwc(_p(images), B, H, W, 3, 7, 7, 2, 3, 3, Ho, Wo, self._mean, _p(col), 148,
+                                       _st(images)), "vqa_im2col_nhwc")
+        cb = self.conv1
+        one = ConvBN.__new__(ConvBN)
+        one.kh = one.kw = 1
+        one.ci, one.co, one.w, one.scale, one.shift = 148, cb.co, cb.w, cb.scale, cb.shift
+        y = conv2d(col.view(1, B * Ho * Wo, 1, 148), one, relu=True).view(B, Ho, Wo, cb.co)
+        return max_pool_3x3_s2_same(y)
+
+    def bottleneck(self, x, u):
+        s = u["stride"]
+        B, H, W, _ = x.shape
+        Ho, Wo = ((H - 1) // s + 1, (W - 1) // s + 1) if s > 1 else (H, W)
+        if u["shortcut"] is None:
+            shortcut = subsample(x, s)
+        else:
+            shortcut = conv2d(x, u["shortcut"], stride=s, out_hw=(Ho, Wo), relu=False)
+        r = conv2d(x, u["conv1"], relu=True)
+        r = conv2d(r, u["conv2"], stride=s, pad=(1, 1), out_hw=(Ho, Wo), relu=True)    # conv2d_same(3, s)
+        return conv2d(r, u["conv3"], residual=shortcut, relu=True)
+
+    def __call__(self, images):
+        x = self.stem(images)
+        for u in self.units:
+            x = self.bottleneck(x, u)
+        return x
+
+
+class VfeatResnetModel:
+    """vqa/model_vfeat_resnet.py:28-40: conv map -> 1x1 crop_and_resize -> outputs['V_ft'] [B,n_box,C]."""
+
+    def __init__(self, params, blocks=BLOCKS_R50_B3, device="cuda:0"):
+        self.net = ResNetV1(params, blocks, device=device)
+        self.outputs = {}
+
+    def build(self, batch):
+        enc = self.net(batch["image"])
+        nb = batch["normal_box"].shape[1]
+        self.outputs["enc_I"] = enc
+        self.outputs["V_ft"] = roi_pool(enc, batch["normal_box"], 1, 1).view(-1, nb, enc.shape[3])
+        return self.outputs["V_ft"]
+
+
+class VfeatModel:
+    """vqa/model_vfeat.py:28-51: block3 -> I_reduce_dim -> 5x5 ROI crop -> I2V (two 3x3 VALID convs sharing
+    one weight tensor and one BatchNorm, vlmap/modules.py:232-237) -> [B,n_box,512]."""
+
+    ROI_SZ = 5
+
+    def __init__(self, params, blocks=BLOCKS_R50_B3, device="cuda:0"):
+        self.net = ResNetV1(params, blocks, device=device)
+        dev = self.net.device
+        self.reduce = ConvBN(params, "I_reduce_dim/conv2d", LAYERS_BN_EPS, dev, wname="/conv2d/weights")
+        self.i2v = ConvBN(params, "I2V/conv2d_1", LAYERS_BN_EPS, dev, wname="/conv2d/weights")
+        self.outputs = {}
+
+    def build(self, batch):
+        enc = self.net(batch["image"])
+        low = conv2d(enc, self.reduce, relu=True)
+        B, nb = batch["normal_box"].shape[:2]
+        roi = roi_pool(low, batch["normal_box"], self.ROI_SZ, self.ROI_SZ)
+        flat = roi.view(B * nb, self.ROI_SZ, self.ROI_SZ, self.reduce.co)
+        v = conv2d(flat, self.i2v, out_hw=(3, 3), relu=True)            # VALID 5x5 -> 3x3
+        v = conv2d(v, self.i2v, out_hw=(1, 1), relu=True)               # VALID 3x3 -> 1x1, same weights
+        self.outputs["V_ft"] = v.view(B, nb, self.i2v.co)
+        return self.outputs["V_ft"]
+
+
+def spatial_features(normal_box):
+    """The 6-d box feature the extractor stores (vqa/vfeat_extractor_tf_record_memft.py:132-139).  The
+    reference labels column 0 'x1' although normal_box is [y1,x1,y2,x2]; the stored tuple is therefore
+    (b0, b1, b2, b3, b2-b0, b3-b1) -- reproduced as is."""
+    b = normal_box
+    return np.stack([b[:, 0], b[:, 1], b[:, 2], b[:, 3], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1)
+
+
+class Extractor:
+    """vqa/vfeat_extractor_tf_record_memft.py:26-147: run the model over batches and fill dense
+    [N, max_roi, D] arrays (image_features, normal_boxes, spatial_features, num_boxes, data_info);
+    written as .npz (h5py is not available)."""
+
+    def __init__(self, model, image_id2idx, max_roi_num):
+        self.model, self.image_id2idx, self.max_roi_num = model, image_id2idx, max_roi_num
+
+    def extract(self, batches, save_path=None):
+        N = len(self.image_id2idx)
+        feats = boxes = spat = None
+        num_boxes = np.zeros([N], np.int32)
+        for batch in batches:
+            v = self.model.build({"image": batch["image"], "normal_box": batch["normal_box"]}).cpu().numpy()
+            nbx = batch["normal_box"].cpu().numpy()
+            for b in range(v.shape[0]):
+                n = min(int(batch["num_box"][b]), self.max_roi_num)
+                if feats is None:
+                    feats = np.zeros((N, self.max_roi_num, v.shape[2]), np.float32)
+                    boxes = np.zeros((N, self.max_roi_num, 4), np.float32)
+                    spat = np.zeros((N, self.max_roi_num, 6), np.float32)
+                    num_boxes += n                               # reference initialises every entry to the first n
+                idx = self.image_id2idx[batch["image_id"][b]]
+                feats[idx, :n] = v[b, :n]
+                boxes[idx, :n] = nbx[b, :n]
+                spat[idx, :n] = spatial_features(nbx[b, :n])
+        out = {"image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
+               "max_box_num": np.int32(self.max_roi_num), "vfeat_dim": np.int32(feats.shape[2])}
+        if save_path is not None:
+            np.savez(save_path, **out)
+        return out
