@@ -103,12 +103,41 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=2):
                       "oracle/torch_ref.py; the reference TF1 path cannot run here)" % (steps, cfg["B"])}
 
 
+def vfeat_bench(device, batch=16, iters=3):
+    """vfeat imgs/sec (second half of BASELINE.json's metric): slim-style ResNet-101 blocks 1-4 on
+    synthetic 448x448 images + 1x1 crop_and_resize of 36 boxes -> [36, 2048] per image (BASELINE
+    configs[2] extractor; random-init He weights, identity-ish BN statistics)."""
+    from oracle import conv_oracle as CO   # only for the parameter-name/shape generator + FLOP count
+    from vqa_transfer_externaldata_amd import vfeat as VF
+    rng = np.random.default_rng(1234)
+    params = CO.init_resnet_params(rng, CO.BLOCKS_R101_FULL)
+    model = VF.VfeatResnetModel(params, VF.BLOCKS_R101_FULL, device=device)
+    g = torch.Generator(device=device).manual_seed(1)
+    img = torch.rand(batch, 448, 448, 3, generator=g, device=device) * 255.0
+    ys = torch.sort(torch.rand(batch, 36, 2, generator=g, device=device), dim=-1).values
+    xs = torch.sort(torch.rand(batch, 36, 2, generator=g, device=device), dim=-1).values
+    box = torch.stack([ys[..., 0], xs[..., 0], ys[..., 1], xs[..., 1]], dim=-1).contiguous()
+    b = {"image": img, "normal_box": box}
+    model.build(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        v = model.build(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    fl = CO.conv_flops_per_image(CO.BLOCKS_R101_FULL, 448, 448)
+    return {"imgs_per_sec": batch / dt, "batch": batch, "image": "448x448x3", "net": "resnet_v1_101 blocks1-4 + "
+            "1x1 crop_and_resize of 36 boxes", "gflop_per_image": fl / 1e9, "tflops": batch * fl / dt / 1e12,
+            "frac_f32_mfma_peak": batch * fl / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "out_shape": list(v.shape)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vfeat", action="store_true")
     ap.add_argument("--probe", type=str, default="v_linear_v.fwd_gemm")
     args = ap.parse_args()
 
@@ -197,6 +226,8 @@ def main():
                          "kernel_ms": kern_ms, "samples": n.value},
             "final_train_loss": loss,
         }
+        if world == 1 and not args.no_vfeat:
+            out["vfeat"] = vfeat_bench(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, table, nbox, am, batches[0], cfg)
         print(json.dumps(out), flush=True)
