@@ -103,6 +103,23 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=2):
                       "oracle/torch_ref.py; the reference TF1 path cannot run here)" % (steps, cfg["B"])}
 
 
+ROOFLINE_KERNEL_KEY = "gemm_f32_kernel<64, 128, 32, 64, 1, 32, false, true, false, 0, false> grid=2304"
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the roofline kernel, from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; Infinity-Cache hits are included in
+    the fabric-side counter).  None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d[ROOFLINE_KERNEL_KEY]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def vfeat_bench(device, batch=16, iters=3):
     """vfeat imgs/sec (second half of BASELINE.json's metric): slim-style ResNet-101 blocks 1-4 on
     synthetic 448x448 images + 1x1 crop_and_resize of 36 boxes -> [36, 2048] per image (BASELINE
@@ -222,7 +239,8 @@ def main():
             "roofline": {"kernel": "gemm_f32_kernel<64,128,32,64,1,32,false,true,false,0> (v_linear_v forward GEMM, "
                                    "M=18432 N=1024 K=2048, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_unit": "bytes/launch (L2<->fabric, PMC; algorithmic minimum 235e6)",
                          "kernel_ms": kern_ms, "samples": n.value},
             "final_train_loss": loss,
         }
