@@ -163,7 +163,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("VQA_BENCH_BACKEND", "nccl")      # "gloo" = rehearsal on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -207,7 +213,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -40,6 +40,12 @@ def allreduce_flat_(flat, group=None, bucket_floats=None):
     bucket_floats to split it (used to start reducing early-finished gradients)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return flat
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (several ranks sharing one GPU, no RCCL): stage through host memory
+        host = flat.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return flat
     if bucket_floats is None or bucket_floats >= flat.numel():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return flat
