@@ -167,7 +167,7 @@ def test_fused_gru_tile_configs_match_oracle(gru_cfg):
         eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
         run_engine(eng, batch, masks)
     finally:
-        lib.vqa_gemm_set_gru_config(7)
+        lib.vqa_gemm_set_gru_config(11)
     loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
                                              to64(masks))
     grads, dx = O.backward(to64(p), to64(batch), to64(am), to64(masks), tape)

@@ -20,6 +20,7 @@
 #include "vqa_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -38,6 +39,7 @@ struct GemmArgs {
     int vecA, vecB;       // 16-byte global loads allowed for A / B
     int tiles_m, tiles_n, nsplit;   // 1-D grid: workgroups walk the (split, m, n) tiles
     int m_fastest;                  // tile order inside a split: m fastest (1) or n fastest (0)
+    unsigned a_bytes, b_bytes;      // operand extents for the buffer descriptors (0 => use the generic loader)
     const float* scale;             // per-column scale (folded BatchNorm), applied to the accumulator
     int relu;                       // ReLU after scale / bias / addend
     // implicit-GEMM convolution (A = NHWC activations, row m = output pixel, k = (ky, kx, ci))
@@ -115,9 +117,38 @@ struct Stager {
             }
         }
     }
+    // Fast form for the common case (16-byte aligned operands < 4 GiB, K % 4 == 0, and for a
+    // row-contiguous operand M or N % 4 == 0): every float4 is wholly inside or wholly outside, so
+    // the tile is fetched with BUFFER loads whose hardware range check returns zeros for the
+    // out-of-range offset we substitute -- no branch and no select on the loaded value.  (Any
+    // `in ? load : 0` form makes hipcc predicate the load under exec and wait vmcnt(0) right after
+    // issuing it, i.e. the prefetch would not overlap the MFMA loop at all.)
+    static constexpr unsigned OOB = 0xFFFFFFF0u;
+    __device__ __forceinline__ static float4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    __device__ __forceinline__ void load_fast(__amdgpu_buffer_rsrc_t rs, int ld, int r0, int k0, int RLIM, int KLIM) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            if (KC) {
+                const int row = idx / KQ, kq = (idx % KQ) * 4;
+                const int gr = r0 + row, gk = k0 + kq;
+                const bool in = (idx < BR * KQ) && (gr < RLIM) && (gk < KLIM);
+                reg[i] = bload(rs, in ? (unsigned)(((int64_t)gr * ld + gk) * 4) : OOB);
+            } else {
+                constexpr int QPR = BR / 4;
+                const int k = idx / QPR, rq = (idx % QPR) * 4;
+                const int gk = k0 + k, gr = r0 + rq;
+                const bool in = (idx < BK * QPR) && (gk < KLIM) && (gr < RLIM);
+                reg[i] = bload(rs, in ? (unsigned)(((int64_t)gk * ld + gr) * 4) : OOB);
+            }
+        }
+    }
     // implicit im2col: one k tile lies inside ONE filter tap (Ci % BK == 0), so the tap offset is
     // wave-uniform and each lane only adds it to its pre-decoded pixel coordinates.
-    __device__ __forceinline__ void load_conv(const float* g, const int (&iy0)[NV], const int (&ix0)[NV],
+    __device__ __forceinline__ void load_conv(__amdgpu_buffer_rsrc_t rs, const int (&iy0)[NV], const int (&ix0)[NV],
                                               const int (&pix)[NV], int k0, int Hi, int Wi, int Ci, int kw) {
         const int tap = k0 / Ci, c0 = k0 - tap * Ci;
         const int ky = tap / kw, kx = tap - ky * kw;
@@ -127,8 +158,7 @@ struct Stager {
             const int kq = (idx % KQ) * 4;
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
-            reg[i] = in ? *reinterpret_cast<const float4*>(g + ((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            reg[i] = bload(rs, in ? (unsigned)((((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq) * 4) : OOB);
         }
     }
     __device__ __forceinline__ void store(float* s) const {
@@ -166,7 +196,8 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
+          bool EDGE = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
@@ -204,6 +235,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const bool va = p.vecA, vb = p.vecB;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
     auto compute_tile = [&](const float* As, const float* Bs) {
 #pragma unroll
         for (int cc = 0; cc < BK / 8 / WGK; ++cc) {
@@ -250,28 +283,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             }
         }
         auto load_a = [&](int k0) {
-            if (CONV) sa.load_conv(p.A, iy0, ix0, pix, k0, p.Hi, p.Wi, p.Ci, p.kw);
-            else sa.load(p.A, p.lda, m0, k0, p.M, kend, va);
+            if (CONV) sa.load_conv(rsA, iy0, ix0, pix, k0, p.Hi, p.Wi, p.Ci, p.kw);
+            else if (EDGE) sa.load(p.A, p.lda, m0, k0, p.M, kend, va);
+            else sa.load_fast(rsA, p.lda, m0, k0, p.M, kend);
+        };
+        auto load_b = [&](int k0) {
+            if (EDGE) sb.load(p.B, p.ldb, n0, k0, p.N, kend, vb);
+            else sb.load_fast(rsB, p.ldb, n0, k0, p.N, kend);
         };
         if (nt > 0) {
             load_a(kbeg);
-            sb.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
+            load_b(kbeg);
             sa.store(L0);
             sb.store(L0 + A_FL);
         }
         __syncthreads();
-        for (int t = 0; t < nt; ++t) {
+        // steady state without conditionals (the last tile is peeled): loads of tile t+1 are issued
+        // before tile t's MFMA loop and consumed (LDS store) after it
+        for (int t = 0; t + 1 < nt; ++t) {
             float* cur = (t & 1) ? L1 : L0;
             float* nxt = (t & 1) ? L0 : L1;
-            if (t + 1 < nt) {
-                load_a(kbeg + (t + 1) * BK);
-                sb.load(p.B, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, vb);
-            }
+            load_a(kbeg + (t + 1) * BK);
+            load_b(kbeg + (t + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMA loop (hipcc sinks it otherwise)
             compute_tile(cur, cur + A_FL);
-            if (t + 1 < nt) {
-                sa.store(nxt);
-                sb.store(nxt + A_FL);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            sa.store(nxt);
+            sb.store(nxt + A_FL);
+            __syncthreads();
+        }
+        if (nt > 0) {
+            float* cur = ((nt - 1) & 1) ? L1 : L0;
+            compute_tile(cur, cur + A_FL);
             __syncthreads();
         }
     } else {
@@ -280,44 +323,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         // the global-load latency, so the loads need two phases of cover.
         Stager<BM, BK, A_KC> sa0, sa1;
         Stager<BN, BK, B_KC> sb0, sb1;
-        if (nt > 0) {
-            sa0.load(p.A, p.lda, m0, kbeg, p.M, kend, va);
-            sb0.load(p.B, p.ldb, n0, kbeg, p.N, kend, vb);
+        auto ld0 = [&](int tile) {
+            sa0.load_fast(rsA, p.lda, m0, kbeg + tile * BK, p.M, kend);
+            sb0.load_fast(rsB, p.ldb, n0, kbeg + tile * BK, p.N, kend);
+        };
+        auto ld1 = [&](int tile) {
+            sa1.load_fast(rsA, p.lda, m0, kbeg + tile * BK, p.M, kend);
+            sb1.load_fast(rsB, p.ldb, n0, kbeg + tile * BK, p.N, kend);
+        };
+        auto st0 = [&]() { sa0.store(L0); sb0.store(L0 + A_FL); };
+        auto st1 = [&]() { sa1.store(L1); sb1.store(L1 + A_FL); };
+        if (nt > 0) ld0(0);
+        if (nt > 1) ld1(1);
+        if (nt > 0) st0();
+        __syncthreads();
+        int t = 0;
+        // steady state, unrolled by 2 so every register index is static and free of conditionals:
+        // entering a pair, L0 holds tile t and set 1 holds tile t+1 (in flight)
+        for (; t + 3 < nt; t += 2) {
+            ld0(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(L0, L0 + A_FL);
+            __builtin_amdgcn_sched_barrier(0);
+            st1();
+            __syncthreads();
+            ld1(t + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(L1, L1 + A_FL);
+            __builtin_amdgcn_sched_barrier(0);
+            st0();
+            __syncthreads();
         }
-        if (nt > 1) {
-            sa1.load(p.A, p.lda, m0, kbeg + BK, p.M, kend, va);
-            sb1.load(p.B, p.ldb, n0, kbeg + BK, p.N, kend, vb);
+        const int rem = nt - t;   // 0..3 tiles left: L0 = tile t, set 1 = tile t+1
+        if (rem >= 3) {
+            ld0(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (nt > 0) {
-            sa0.store(L0);
-            sb0.store(L0 + A_FL);
+        if (rem >= 1) compute_tile(L0, L0 + A_FL);
+        if (rem >= 2) {
+            st1();
+            __syncthreads();
+            compute_tile(L1, L1 + A_FL);
+        }
+        if (rem >= 3) {
+            st0();
+            __syncthreads();
+            compute_tile(L0, L0 + A_FL);
         }
         __syncthreads();
-        for (int t = 0; t < nt; t += 2) {
-            // even phase: L0 holds tile t, set 1 holds tile t+1
-            if (t + 2 < nt) {
-                sa0.load(p.A, p.lda, m0, kbeg + (t + 2) * BK, p.M, kend, va);
-                sb0.load(p.B, p.ldb, n0, kbeg + (t + 2) * BK, p.N, kend, vb);
-            }
-            compute_tile(L0, L0 + A_FL);
-            if (t + 1 < nt) {
-                sa1.store(L1);
-                sb1.store(L1 + A_FL);
-            }
-            __syncthreads();
-            if (t + 1 >= nt) break;
-            // odd phase: L1 holds tile t+1, set 0 holds tile t+2
-            if (t + 3 < nt) {
-                sa1.load(p.A, p.lda, m0, kbeg + (t + 3) * BK, p.M, kend, va);
-                sb1.load(p.B, p.ldb, n0, kbeg + (t + 3) * BK, p.N, kend, vb);
-            }
-            compute_tile(L1, L1 + A_FL);
-            if (t + 2 < nt) {
-                sa0.store(L0);
-                sb0.store(L0 + A_FL);
-            }
-            __syncthreads();
-        }
     }
 
     if (WGK > 1) {
@@ -499,13 +552,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
+          bool EDGE = false>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
     constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
     constexpr size_t stage = (EPI == EPI_PLAIN) ? 0 : (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {   // MI355X has 160 KiB of LDS per CU; > 64 KiB needs the opt-in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -553,7 +607,31 @@ constexpr int NUM_CFG = 14;
 const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 128}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 128},
                                {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}};
 
-int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int mb = 0) {
+// operands that allow the buffer-load fast path (see Stager::load_fast); fills the descriptor extents
+bool fast_ok(int tA, int tB, GemmArgs& a) {
+    if (!a.vecA || !a.vecB || a.K < 4 || (a.K % 4) != 0) return false;
+    if (tA && ((a.M % 4) != 0 || a.M < 4)) return false;          // A stored [K][M]
+    if (!tB && ((a.N % 4) != 0 || a.N < 4)) return false;         // B stored [K][N]
+    const int64_t ab = (tA ? ((int64_t)(a.K - 1) * a.lda + a.M) : ((int64_t)(a.M - 1) * a.lda + a.K)) * 4;
+    const int64_t bb = (tB ? ((int64_t)(a.N - 1) * a.ldb + a.K) : ((int64_t)(a.K - 1) * a.ldb + a.N)) * 4;
+    if (ab >= 0xFFFFFF00ll || bb >= 0xFFFFFF00ll) return false;   // 32-bit buffer offsets
+    a.a_bytes = (unsigned)ab;
+    a.b_bytes = (unsigned)bb;
+    return true;
+}
+
+int launch_edge(int tA, int tB, const GemmArgs& a, int split, hipStream_t st) {
+    const EpiArgs ep{};
+    if (tA == 0 && tB == 0)
+        return launch_one<64, 64, 32, 32, 1, 16, false, true, false, EPI_PLAIN, false, true>(a, ep, split, st, 0);
+    if (tA == 0 && tB == 1)
+        return launch_one<64, 64, 32, 32, 1, 16, false, true, true, EPI_PLAIN, false, true>(a, ep, split, st, 0);
+    return launch_one<64, 64, 32, 32, 1, 16, false, false, false, EPI_PLAIN, false, true>(a, ep, split, st, 0);
+}
+
+int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a_in, int split, hipStream_t st, int mb = 0) {
+    GemmArgs a = a_in;
+    if (!fast_ok(tA, tB, a)) return launch_edge(tA, tB, a, split, st);   // ragged / unaligned shapes
     switch (cfg) {
         case 0: return launch_cfg<128, 128, 64, 64, 1, 16, false>(tA, tB, a, split, st, mb);
         case 1: return launch_cfg<128, 128, 64, 64, 1, 32, false>(tA, tB, a, split, st, mb);
@@ -575,8 +653,10 @@ int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a, int split, hipStrea
 
 // fused GRU-step GEMMs: layout fixed by the epilogue (forward NN, backward NT)
 template <int EPI>
-int launch_gru(int cfg, const GemmArgs& a, const EpiArgs& ep, hipStream_t st) {
+int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st) {
     constexpr bool BKC = (EPI == EPI_BWD_RH || EPI == EPI_BWD_DH);
+    GemmArgs a = a_in;
+    if (!fast_ok(0, BKC ? 1 : 0, a)) return VQA_ERR_ALIGN;
     switch (cfg) {
         case 4: return launch_one<64, 64, 32, 32, 1, 64, false, true, BKC, EPI>(a, ep, 1, st);
         case 7: return launch_one<64, 32, 32, 32, 2, 64, false, true, BKC, EPI>(a, ep, 1, st);
@@ -593,19 +673,19 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
-int g_gru_cfg = 7;      // tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config)
+int g_gru_cfg = 11;     // tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config)
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
 //  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 32, and
-//    enough split-k slabs for >= 512 workgroups (dWv 696 us = 111 TFLOP/s);
-//  * tall activations (M >= 2048): 64x128 tiles (v_linear_v forward 746 us = 104 TFLOP/s),
-//    64x64 when N is narrow;
-//  * batch-sized M (512): 64x32 tiles with in-block split-k (NN) / 64x64 BK 64 (NT).
+//    enough split-k slabs for >= 512 workgroups (dWv 603 us = 128 TFLOP/s);
+//  * tall activations (M >= 2048): 64x128 tiles (v_linear_v forward 618 us = 125 TFLOP/s);
+//  * batch-sized M (512) or narrow N: 64x32 tiles with in-block split-k and two tiles of register
+//    prefetch (one workgroup per CU cannot hide a global load behind a single tile's MFMAs).
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
     if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 1 : 3; target = 512; }
-    else if (M >= 2048) { cfg = (N >= 512) ? 6 : 3; target = 256; }
-    else { cfg = tB ? 4 : 7; target = 256; }
+    else if (M >= 2048) { cfg = (N >= 512) ? 6 : 13; target = 256; }
+    else { cfg = tB ? 11 : 13; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
     if (split <= 0) {
@@ -627,6 +707,7 @@ GemmArgs make_args(int M, int N, int K, const float* A, int lda, const float* B,
     a.slab_stride = 0;
     a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
     a.scale = nullptr; a.relu = 0;
+    a.a_bytes = a.b_bytes = 0;   // filled by set_extents() once the layout is known
     a.Hi = a.Wi = a.Ci = a.Ho = a.Wo = a.cstride = a.pad_t = a.pad_l = a.kw = 0;
     return a;
 }
@@ -822,6 +903,10 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     VQA_REQUIRE(Ci % 32 == 0 && vqa_aligned16(x), VQA_ERR_ALIGN);   // one 32-deep k tile per filter tap
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.kw = kw;
+    const int64_t xb = (int64_t)B * Hi * Wi * Ci * 4, wb = (int64_t)K * Co * 4;
+    VQA_REQUIRE(xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll && Co % 4 == 0 && vqa_aligned16(w), VQA_ERR_UNSUPPORTED);
+    a.a_bytes = (unsigned)xb;
+    a.b_bytes = (unsigned)wb;
     const EpiArgs ep{};
     if (Co >= 128) return launch_one<64, 128, 32, 64, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
     return launch_one<64, 64, 32, 32, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
