@@ -188,7 +188,7 @@ def main():
                          W=cfg["W"], A=cfg["A"], Vq=cfg["Vq"], N_img=cfg["N_img"], params=params, device=device,
                          global_batch=cfg["B"] * world)
     eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
-    reducer = PAR.GradAllReduce(eng) if world > 1 else None
+    reducer = PAR.BucketedAllReduce() if world > 1 else None
     lib = _lib.load()
     if os.environ.get("VQA_GRU_CFG"):
         _lib.check(lib.vqa_gemm_set_gru_config(int(os.environ["VQA_GRU_CFG"])), "vqa_gemm_set_gru_config")

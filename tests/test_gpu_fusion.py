@@ -191,3 +191,40 @@ def test_repeated_runs_are_bitwise_identical():
         assert torch.equal(z1, eng.tensor("logit"))
         emb = eng.embed_floats                     # the embedding scatter-add uses float atomics (order varies)
         assert torch.equal(g1[emb:], eng.grad_flat[emb:])
+
+
+def test_phased_backward_equals_monolithic_and_bucket_layout():
+    """vqa_fusion_backward_phases(1|2|4 in order) == vqa_fusion_backward, and the flat layout puts the
+    buckets where FusionEngine.backward(reducer=...) slices them."""
+    dims, B, R, T, N = MED, 48, 36, 14, 64
+    for mt in ("vlmap_answer", "standard"):
+        p, table, nbox, batch, am, masks = make_case(41, mt, B, R, T, N, dims)
+        eng = make_engine(mt, p, table, nbox, am, B, R, T, dims)
+        run_engine(eng, batch, masks)
+        ref = eng.grad_flat.clone()
+        seen = []
+
+        class Rec:
+            def start(self, bucket):
+                seen.append((bucket.data_ptr() - eng.grad_flat.data_ptr()) // 4)
+                seen.append(bucket.numel())
+
+            def finish(self):
+                pass
+        eng.grad_flat.fill_(float("nan"))
+        eng.backward(reducer=Rec())
+        torch.cuda.synchronize()
+        emb = eng.embed_floats
+        for n in eng.train_names[1:]:                                            # dense grads bit-identical
+            off, cnt = eng._train_tab[n]
+            assert torch.equal(ref[off:off + cnt], eng.grad_flat[off:off + cnt]), n
+        assert torch.equal(ref[eng.n_train], eng.grad_flat[eng.n_train])         # slice sum of squares
+        cnt = eng._train_tab[eng.train_names[0]][1]
+        assert torch.allclose(ref[:cnt], eng.grad_flat[:cnt], rtol=1e-4, atol=1e-7)   # atomics: order varies
+        # buckets: rest, embed, tail, gru -- disjoint and covering the whole buffer
+        offs, lens = seen[0::2], seen[1::2]
+        assert offs == [eng.gru_end, 0, eng.n_train, emb] and sum(lens) == eng.grad_flat.numel()
+        gru_names = [n for n in eng.train_names if n.startswith("encode_L/")]
+        for n in gru_names:
+            off = eng._train_tab[n][0]
+            assert emb <= off < eng.gru_end

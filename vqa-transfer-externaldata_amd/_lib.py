@@ -93,6 +93,8 @@ SIGNATURES = {
     "vqa_fusion_workspace_bytes": (_L, [C.POINTER(Dims)]),
     "vqa_fusion_tensor": (_I, [C.POINTER(Dims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "vqa_fusion_forward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _P, _L, _I, _P]),
+    "vqa_fusion_backward_phases": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
+                                        _P, _I, _P]),
     "vqa_fusion_backward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
                                  _P, _P]),
 }

@@ -370,6 +370,17 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
 extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_params_t* G,
                                    const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
                                    float* embed_slice_sq, void* stream) {
+    return vqa_fusion_backward_phases(dims, P, G, bt, workspace, workspace_bytes, embed_slice_sq, 7, stream);
+}
+
+// phases (bit mask), in dependency order:
+//   1  head .. attention .. v_linear_v / q_linear_v / score gradients      (complete after this phase)
+//   2  GRU back-propagation through time, dx, embedding scatter-add, slice sum of squares
+//   4  GRU weight / bias gradients
+// so a data-parallel caller can start all-reducing each gradient bucket while the next phase runs.
+extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_params_t* G,
+                                          const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
+                                          float* embed_slice_sq, int phases, void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && G && bt && workspace, VQA_ERR_ARG);
     const Layout L = make_layout(*dims);
     Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream), 0};
@@ -378,7 +389,10 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
     const float* hs = c.f("hs");
     const float* h = hs + T * B * H;
+    float* dh = c.f("d_h0");
+    float* dxp = c.f("dxp");
 
+    if (phases & 1) {
     // head: logit = joint*W + b
     if (G->head.w != nullptr) {
         TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit"), (int)A, G->head.w, (int)A));
@@ -392,7 +406,6 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
                     c.st));
     TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
                        "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));
-    float* dh = c.f("d_h0");
     TRY(fc_ln_relu_bwd(c, c.f("d_ll"), h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll",
                        nullptr, 1.f, "d_pre_ll", dh, false));
     // attention + pooling
@@ -419,9 +432,11 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
     // q_linear_v: dh += ...
     TRY(fc_ln_relu_bwd(c, c.f("d_qv"), h, B, H, H, P->q_linear_v, &G->q_linear_v, 1, "pre_qv", "mean_qv", "rstd_qv",
                        nullptr, 1.f, "d_pre_qv", dh, true));
+    if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
+    }   // phase 1
 
+    if (phases & 2) {
     // GRU back-propagation through time (gate math fused into the GEMM epilogues)
-    float* dxp = c.f("dxp");
     const float* Wg_h = P->gru_wg + W * 2 * H;
     const float* Wc_h = P->gru_wc + W * H;
     {
@@ -439,6 +454,16 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
                                 c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
         }
     }
+    // embedding: un-aggregated slices dx [T,B,W], then scatter-add
+    float* dx = c.f("dx_embed");
+    TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
+    TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+    if (G->embed != nullptr) TRY(vqa_embed_bwd(dx, bt->q_intseq, G->embed, (int)B, (int)T, (int)W, dims->Vq, c.st));
+    if (embed_slice_sq != nullptr)
+        TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
+    }   // phase 2
+
+    if (phases & 4) {
     if (G->gru_wg != nullptr) {
         TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
@@ -447,14 +472,7 @@ extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P
         TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
         TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
     }
-    // embedding: un-aggregated slices dx [T,B,W], then scatter-add
-    float* dx = c.f("dx_embed");
-    TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
-    TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
-    if (G->embed != nullptr) TRY(vqa_embed_bwd(dx, bt->q_intseq, G->embed, (int)B, (int)T, (int)W, dims->Vq, c.st));
-    if (embed_slice_sq != nullptr)
-        TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
-    if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
+    }   // phase 3
     return VQA_OK;
 }
 

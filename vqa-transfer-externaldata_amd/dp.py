@@ -66,3 +66,29 @@ class GradAllReduce:
 
     def __call__(self, grad_flat):
         return allreduce_flat_(grad_flat, self.group, self.bucket_floats)
+
+
+class BucketedAllReduce:
+    """Overlapped gradient reduction: FusionEngine.backward(reducer=...) calls start(bucket) as soon as a
+    backward phase has been enqueued and finish() at the end.  On RCCL each bucket is an async all-reduce:
+    the collective stream waits (event) for the compute stream at the point of the call, i.e. for the phase
+    that produced the bucket, and runs beside the next phase; finish() makes the compute stream wait for
+    all of them before the optimizer.  Buckets: everything-but-GRU/embedding (9-60 MB), embedding table
+    (19.7 MB at Vq = 16384) + slice sum of squares, GRU weights (16.3 MB)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._works = []
+
+    def start(self, bucket):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        if bucket.is_cuda and dist.get_backend(self.group) == "gloo":
+            allreduce_flat_(bucket, self.group)            # rehearsal path: synchronous host staging
+            return
+        self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()
+        self._works = []

@@ -126,6 +126,11 @@ class FusionEngine:
         self._train_tab, self.n_train = carve(self.train_names)
         self._frozen_tab, self.n_frozen = carve(self.frozen_names)
         self.embed_floats = _pad4(int(np.prod(self.shapes[embed])))
+        # gradient buckets in the order backward completes them (see vqa_fusion_backward_phases):
+        # [embed | GRU (encode_L/*) | everything else]; the GRU tensors must sit right after the table
+        gru = [n for n in self.train_names if n.startswith("encode_L/")]
+        assert self.train_names[1:1 + len(gru)] == gru, "flat layout: encode_L/* must follow the embedding"
+        self.gru_end = self.embed_floats + sum(_pad4(int(np.prod(self.shapes[n]))) for n in gru)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.train_flat = torch.zeros(self.n_train, **f32)
         self.frozen_flat = torch.zeros(max(self.n_frozen, 4), **f32)
@@ -280,14 +285,33 @@ class FusionEngine:
                                                C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
                                                1 if want_dz else 0, self._stream()), "vqa_fusion_forward")
 
-    def backward(self):
+    def _backward_phases(self, phases):
+        tail = self.grad_flat[self.n_train:]
+        _lib.check(self.lib.vqa_fusion_backward_phases(
+            C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct), C.byref(self._bs),
+            C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(), C.c_void_p(tail.data_ptr()), phases,
+            self._stream()), "vqa_fusion_backward_phases")
+
+    def backward(self, reducer=None):
+        """All gradients into grad_flat.  With a bucketed `reducer` (dp.BucketedAllReduce) the three
+        dependency-ordered phases are launched one by one and each finished bucket's all-reduce is started
+        right away, so it overlaps the next phase: [everything but GRU/embedding] during BPTT, the
+        embedding bucket (+ slice sum of squares) during the GRU weight-gradient GEMMs; only the GRU
+        bucket's reduction is exposed."""
         # only the embedding gradient is scatter-added; everything else is overwritten
         self.grad_flat[:self.embed_floats].zero_()
-        tail = self.grad_flat[self.n_train:]
-        _lib.check(self.lib.vqa_fusion_backward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct),
-                                                C.byref(self._bs), C.c_void_p(self.workspace.data_ptr()),
-                                                self.workspace.numel(), C.c_void_p(tail.data_ptr()),
-                                                self._stream()), "vqa_fusion_backward")
+        if reducer is None:
+            self._backward_phases(7)
+            return
+        e, g, n = self.embed_floats, self.gru_end, self.n_train
+        self._backward_phases(1)
+        reducer.start(self.grad_flat[g:n])
+        self._backward_phases(2)
+        reducer.start(self.grad_flat[:e])
+        reducer.start(self.grad_flat[n:])
+        self._backward_phases(4)
+        reducer.start(self.grad_flat[e:g])
+        reducer.finish()
 
     def optimizer_step(self, lr):
         """clip_by_global_norm(20) + Adam on the flat buffers.  The norm uses the
@@ -309,9 +333,12 @@ class FusionEngine:
 
     def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None):
         self.forward(batch, keep_att, keep_joint, want_dz=True)
-        self.backward()
-        if allreduce is not None:
-            allreduce(self.grad_flat)
+        if allreduce is not None and hasattr(allreduce, "start"):
+            self.backward(reducer=allreduce)          # bucketed, overlapped with the backward phases
+        else:
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.grad_flat)
         self.optimizer_step(lr)
 
     # ------------------------------------------------------------------ results

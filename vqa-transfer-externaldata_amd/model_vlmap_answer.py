@@ -262,8 +262,9 @@ class Model(object):
         return self.loss
 
     # the two halves of optimize_loss that the Trainer drives (vqa/trainer.py:106-114)
-    def backward(self):
-        self._engine.backward()
+    def backward(self, reducer=None):
+        """reducer: optional dp.BucketedAllReduce -> gradient buckets are all-reduced while backward runs."""
+        self._engine.backward(reducer=reducer)
 
     def apply_gradients(self, learning_rate, allreduce=None):
         if allreduce is not None:

@@ -88,7 +88,7 @@ class Trainer(object):
         self.train_vars = self.model.filter_train_vars(all_vars)
         self.transfer_vars = self.model.filter_transfer_vars(all_vars)
         log.warning("Filtered train variables: %s", ", ".join(self.train_vars))
-        self._allreduce = dp.GradAllReduce() if self.world > 1 else None
+        self._allreduce = dp.BucketedAllReduce() if self.world > 1 else None
 
         self.train_average_iter = config.train_average_iter
         self.val_average_iter = config.val_average_iter
@@ -141,8 +141,8 @@ class Trainer(object):
         _start_time = time.time()
         self.model.set_batch(self._next("train"))
         self.model.build()
-        self.model.backward()
-        self.model.apply_gradients(self._lr(), self._allreduce)
+        self.model.backward(reducer=self._allreduce)       # buckets reduced while backward still runs
+        self.model.apply_gradients(self._lr())
         loss, report = self._report_values()
         self.global_step += 1
         _end_time = time.time()
