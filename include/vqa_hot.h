@@ -94,6 +94,16 @@ int vqa_ln_relu_bwd(const float* dy, const float* pre, const float* mean, const 
                     const float* gamma, const float* beta, const uint8_t* keepmask, float keep_prob,
                     float* dpre, float* part_dgamma, float* part_dbeta, float* part_dbias, int G, int rows,
                     int N, void* stream);
+/* The same with an activation selector: act 0 = ReLU, 1 = tanh (fc_layer(activation_fn=tf.tanh) of the
+ * pre-training model's 'wordset_ft', vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:376-378). */
+int vqa_ln_act_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask, float keep_prob,
+                   float* y, float* mean, float* rstd, int G, int rows, int N, int act, void* stream);
+int vqa_ln_act_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, const uint8_t* keepmask, float keep_prob, float* dpre, float* part_dgamma,
+                   float* part_dbeta, float* part_dbias, int G, int rows, int N, int act, void* stream);
+/* y = tanh(x) ; dx = dy * (1 - y^2)   (tanh of the word-set embedding, same file :373-375) */
+int vqa_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int vqa_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 /* out[N] = sum_m X[m,:]  (deterministic two-stage; workspace >= vqa_colsum_workspace_floats). */
 int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace, int64_t workspace_floats,
                void* stream);
@@ -157,6 +167,17 @@ int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, con
                       const float* w, const uint8_t* keepmask, float keep_prob, float* dv, float* dqv,
                       float* part_dw, float* part_db, int B, int R, int H, int D, void* stream);
 
+/* `rep` queries per memory (the cfg-5 pre-training model attends n = 5 key boxes per image over the
+ * same regions, vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:323-364, without materialising the
+ * x5 tile): v [B,R,H], V [B,R,D], nb [B] per memory; qv [B*rep,H], keepmask [B*rep,R,H], att
+ * [B*rep,R], pooled [B*rep,D] per query; dv [B,R,H] is summed over the queries of a memory. */
+int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
+                          const float* bias, const uint8_t* keepmask, float keep_prob, float* att, float* pooled,
+                          int B, int rep, int R, int H, int D, void* stream);
+int vqa_attn_pool_bwd_rep(const float* dpooled, const float* v, const float* qv, const float* V, const float* att,
+                          const float* w, const uint8_t* keepmask, float keep_prob, float* dv, float* dqv,
+                          float* part_dw, float* part_db, int B, int rep, int R, int H, int D, void* stream);
+
 /* --------------------------------------------------------------- a11 / K11
  * sigmoid-CE loss, argmax, VQA scores (vqa/model_vlmap_answer.py:192-288).
  * Per sample stats[b, VQA_STAT_*]; dz = (sigmoid(z)-t)*(loss_mask?)/B_norm when
@@ -171,6 +192,12 @@ enum {
 int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, const float* obj_mask,
                  const float* attr_mask, const float* exist_mask, int use_train_mask_in_loss, float inv_batch,
                  float* stats, int32_t* pred, float* dz, int B, int A, void* stream);
+/* n-way softmax cross-entropy with a validity mask + top-1 / top-k hits (n_way_classification_loss,
+ * vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:675-706).  z [rows,A], label i32[rows], valid f32[rows];
+ * stats [rows,4] = {ce*valid, top1*valid, topk*valid, valid}; dz = (softmax-onehot)*valid*inv_valid_sum[0]
+ * (inv_valid_sum is a DEVICE scalar = 1/sum(valid); dz may be NULL). */
+int vqa_softmax_ce_fwd(const float* z, const int32_t* label, const float* valid, int topk,
+                       const float* inv_valid_sum, float* stats, float* dz, int rows, int A, void* stream);
 /* report[13] in the order of vqa_report_key(i): means over B + guarded ratios. */
 int vqa_report_reduce(const float* stats, int B, float* report, void* stream);
 #define VQA_REPORT_COUNT 13

@@ -1,0 +1,84 @@
+"""GPU parity of the cfg-5 pre-training model against its oracle: forward report,
+logits, every gradient (torch-autograd reference), clip+Adam step, export bridge."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pretrain_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _setup(seed, B, n, R, D, H, L, W, Vq, n_ws, A):
+    from vqa_transfer_externaldata_amd import pretrain as PT
+    rng = np.random.default_rng(seed)
+    p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H)
+    batch = PO.make_batch(rng, B, n, R, D, L, Vq, n_ws, A)
+    masks = PO.make_masks(rng, B, n, R, H)
+    eng = PT.PretrainEngine(n=n, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=n_ws, params=p)
+    db = {k: dev(v) for k, v in batch.items()}
+    dm = {k: dev(v.astype(np.uint8)) for k, v in masks.items()}
+    return PT, eng, p, batch, masks, db, dm
+
+
+@pytest.mark.parametrize("cfg", [dict(B=3, n=5, R=6, D=16, H=8, L=4, W=12, Vq=20, n_ws=7, A=12),
+                                 dict(B=16, n=5, R=36, D=256, H=128, L=10, W=300, Vq=200, n_ws=50, A=400)])
+def test_forward_backward_match_oracle(cfg):
+    PT, eng, p, batch, masks, db, dm = _setup(5, **cfg)
+    eng.forward(db, dm)
+    eng.backward()
+    torch.cuda.synchronize()
+    rep = eng.fetch_report()
+    to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
+    total, report, mid = PO.forward(to64(p), to64(batch), to64(masks), cfg["n"])
+    assert sorted(rep) == sorted(report)                              # the 13 report keys of the reference
+    for k in report:
+        assert abs(rep[k] - report[k]) <= 2e-4 * max(1.0, abs(report[k])), (k, rep[k], report[k])
+    for k in PO.KINDS:
+        z = eng._tape["kinds"][k]["blank_fill"]["z"].cpu().numpy().reshape(mid[k + "/bf_logit"].shape)
+        assert np.abs(z - mid[k + "/bf_logit"]).max() < 1e-3
+        z = eng._tape["kinds"][k]["wordset"]["z"].cpu().numpy().reshape(mid[k + "/ws_logit"].shape)
+        assert np.abs(z - mid[k + "/ws_logit"]).max() < 1e-3
+        att = eng._tape["kinds"][k]["att"].cpu().numpy()
+        assert np.abs(att - mid[k + "/att"]).max() < 1e-5
+    _, _, grads, slices = PO.torch_loss_and_grads(to64(p), to64(batch), to64(masks), cfg["n"])
+    for name in eng.train_names:
+        g = eng.grads[name].cpu().numpy().astype(np.float64)
+        sc = max(np.abs(grads[name]).max(), 1e-12)
+        if name.endswith("score/fc/biases"):
+            assert np.abs(g).max() < 1e-5                              # analytically zero
+            continue
+        assert np.abs(g - grads[name]).max() <= 1e-3 * sc + 1e-8, (name, np.abs(g - grads[name]).max(), sc)
+    sq = sum(float((v ** 2).sum()) for v in slices.values())
+    assert abs(float(eng.grad_flat[eng.n_train]) - sq) <= 1e-3 * sq + 1e-12
+
+
+def test_train_steps_reduce_loss_and_export_bridge(tmp_path):
+    cfg = dict(B=16, n=5, R=36, D=128, H=64, L=8, W=300, Vq=100, n_ws=30, A=60)
+    PT, eng, p, batch, masks, db, dm = _setup(6, **cfg)
+    losses = []
+    for it in range(12):
+        eng.train_step(db, dm, 2e-3)
+        losses.append(eng.fetch_report()["total_loss"])
+    assert losses[-1] < losses[0] - 0.5, losses
+    assert np.isfinite(losses).all()
+    # V_GloVe / LearnAnswerGloVe never move (no gradient path in this model)
+    for k in PT.NO_GRAD_VARS:
+        np.testing.assert_array_equal(eng.params[k].cpu().numpy(), p[k])
+    vocab = {"vocab": ["w%d" % i for i in range(cfg["Vq"])]}
+    adict = {"vocab": ["a%d" % i for i in range(cfg["A"])], "dict": {"a%d" % i: i for i in range(cfg["A"])}}
+    d = PT.export_word_weights(eng.state_dict(), vocab, adict, str(tmp_path / "word_weights_model-12"))
+    # ... and the VQA model's WordWeightAnswer init consumes it (vlmap/modules.py:589-627)
+    from vqa_transfer_externaldata_amd import model_vlmap_answer as MV
+    ww = MV.load_word_weight_dir(d)
+    vqa_answers = {"vocab": ["a3", "zzz", "a7"]}
+    w, b = MV.word_weight_answer_init(vqa_answers, 2 * cfg["H"], ww)
+    cw = eng.params["classifier/fc/weights"].cpu().numpy()
+    np.testing.assert_array_equal(w[:, 0], cw[:, 3]); np.testing.assert_array_equal(w[:, 2], cw[:, 7])
+    assert np.all(w[:, 1] == 0) and b[1] == -100.0
+    with pytest.raises(ValueError, match="Do not overwrite"):
+        PT.export_word_weights(eng.state_dict(), vocab, adict, d)

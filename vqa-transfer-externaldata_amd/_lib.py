@@ -64,6 +64,11 @@ SIGNATURES = {
     "vqa_gru_seq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_ln_act_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_ln_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_tanh_fwd": (_I, [_P, _P, _L, _P]),
+    "vqa_tanh_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "vqa_softmax_ce_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "vqa_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
     "vqa_colsum_workspace_floats": (_L, [_I, _I]),
     "vqa_mul": (_I, [_P, _P, _P, _L, _P]),
@@ -75,6 +80,8 @@ SIGNATURES = {
     "vqa_gru_bwd_b": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
     "vqa_attn_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_attn_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_attn_pool_fwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vqa_attn_pool_bwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _P]),
     "vqa_report_reduce": (_I, [_P, _I, _P, _P]),
     "vqa_report_key": (C.c_char_p, [_I]),

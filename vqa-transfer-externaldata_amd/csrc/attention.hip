@@ -5,6 +5,11 @@
 //   s[b,r]   = sum_h (v[b,r,h] * qv[b,h]) * keep[b,r,h]/keep_prob * w[h] + bias
 //   s[r>=nb] = -inf ; att = softmax_R(s) ; pooled[b,:] = sum_r att[b,r] * V[b,r,:]
 //
+// `rep` queries may share one memory (the pre-training model attends 5 key boxes per image over the
+// same 36 regions: vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:323-364 tiles V_ft x5 -- here
+// the tile is never materialised): v, V, nb are indexed by the memory m, qv / keepmask / att / pooled
+// by the query q = m*rep + j.
+//
 // HBM-bound.  One workgroup (4 waves) per sample keeps s/att for the <= 36
 // regions in LDS, so v (147 KB), the keep mask (37 KB) and the raw features V
 // (295 KB) are each read exactly once with 16-byte-per-lane coalesced loads and
@@ -20,14 +25,15 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     const float* __restrict__ v, const float* __restrict__ qv, const float* __restrict__ V,
     const int32_t* __restrict__ nb, const float* __restrict__ w, const float* __restrict__ bias,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ att_out, float* __restrict__ pooled, int R,
-    int H, int D) {
+    int H, int D, int rep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // qw[H] | s[R]
     float* qw = lds;
     float* s = lds + H;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* vb = v + (int64_t)b * R * H;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // b = query index
+    const int mem = b / rep;
+    const float* vb = v + (int64_t)mem * R * H;
     const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
-    const float* Vb = V + (int64_t)b * R * D;
+    const float* Vb = V + (int64_t)mem * R * D;
 
     for (int h = threadIdx.x; h < H; h += 256) qw[h] = qv[(int64_t)b * H + h] * w[h];
     __syncthreads();
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     __syncthreads();
 
     if (wave == 0) {
-        const int n_valid = nb[b];
+        const int n_valid = nb[mem];
         float mx = -INFINITY;
         for (int r = lane; r < R; r += 64) {
             const float x = (r < n_valid) ? s[r] : -INFINITY;
@@ -88,71 +94,97 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     }
 }
 
+// Backward.  One workgroup per MEMORY walks its `rep` queries, so dv (the gradient of the shared
+// v block) is accumulated over the queries in registers and written once.
+template <int REP>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     const float* __restrict__ dpooled, const float* __restrict__ v, const float* __restrict__ qv,
     const float* __restrict__ V, const float* __restrict__ att, const float* __restrict__ w,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dv, float* __restrict__ dqv,
-    float* __restrict__ part_dw, float* __restrict__ part_db, int R, int H, int D) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[D] | ds[R]
+    float* __restrict__ part_dw, float* __restrict__ part_db, int R, int H, int D, int rep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[D] | ds[REP][R]
     float* dp = lds;
     float* ds = lds + D;
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* vb = v + (int64_t)b * R * H;
-    const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
-    const float* Vb = V + (int64_t)b * R * D;
-
-    for (int d = threadIdx.x; d < D; d += 256) dp[d] = dpooled[(int64_t)b * D + d];
-    __syncthreads();
-
-    // datt[r] = <dpooled[b], V[b,r]>
+    const int mem = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* vb = v + (int64_t)mem * R * H;
+    const float* Vb = V + (int64_t)mem * R * D;
     const int D4 = D / 4;
-    for (int r = wave; r < R; r += 4) {
-        float acc = 0.f;
-        for (int du = lane; du < D4; du += 64) {
-            const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
-            const float4 g = reinterpret_cast<const float4*>(dp)[du];
-            acc += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+
+    for (int j = 0; j < rep; ++j) {
+        const int q = mem * rep + j;
+        __syncthreads();
+        for (int d = threadIdx.x; d < D; d += 256) dp[d] = dpooled[(int64_t)q * D + d];
+        __syncthreads();
+        // datt[r] = <dpooled[q], V[mem,r]>
+        float* dsj = ds + j * R;
+        for (int r = wave; r < R; r += 4) {
+            float acc = 0.f;
+            for (int du = lane; du < D4; du += 64) {
+                const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
+                const float4 g = reinterpret_cast<const float4*>(dp)[du];
+                acc += x.x * g.x + x.y * g.y + x.z * g.z + x.w * g.w;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) dsj[r] = acc;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) ds[r] = acc;
-    }
-    __syncthreads();
-    // softmax backward: ds = att * (datt - sum(att*datt))
-    if (wave == 0) {
-        float dot = 0.f;
-        for (int r = lane; r < R; r += 64) dot += att[(int64_t)b * R + r] * ds[r];
-        dot = wave_sum(dot);
-        float tot = 0.f;
-        for (int r = lane; r < R; r += 64) {
-            const float g = att[(int64_t)b * R + r] * (ds[r] - dot);
-            ds[r] = g;
-            tot += g;
+        __syncthreads();
+        // softmax backward: ds = att * (datt - sum(att*datt))
+        if (wave == 0) {
+            float dot = 0.f;
+            for (int r = lane; r < R; r += 64) dot += att[(int64_t)q * R + r] * dsj[r];
+            dot = wave_sum(dot);
+            float tot = 0.f;
+            for (int r = lane; r < R; r += 64) {
+                const float g = att[(int64_t)q * R + r] * (dsj[r] - dot);
+                dsj[r] = g;
+                tot += g;
+            }
+            tot = wave_sum(tot);
+            if (lane == 0) part_db[q] = tot;
         }
-        tot = wave_sum(tot);
-        if (lane == 0) part_db[b] = tot;
     }
     __syncthreads();
 
     const int H4 = H / 4;
     for (int hu = threadIdx.x; hu < H4; hu += 256) {
-        const float4 q = reinterpret_cast<const float4*>(qv + (int64_t)b * H)[hu];
         const float4 ww = reinterpret_cast<const float4*>(w)[hu];
-        const float4 qw = make_float4(q.x * ww.x, q.y * ww.y, q.z * ww.z, q.w * ww.w);
-        float4 S = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-        for (int r = 0; r < R; ++r) {
-            float4 g = make_float4(ds[r], ds[r], ds[r], ds[r]);
-            if (mb != nullptr) {
-                const uchar4 m = reinterpret_cast<const uchar4*>(mb + (int64_t)r * H)[hu];
-                g.x *= m.x * inv_keep; g.y *= m.y * inv_keep; g.z *= m.z * inv_keep; g.w *= m.w * inv_keep;
-            }
-            const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
-            S.x += g.x * x.x; S.y += g.y * x.y; S.z += g.z * x.z; S.w += g.w * x.w;
-            reinterpret_cast<float4*>(dv + ((int64_t)b * R + r) * H)[hu] =
-                make_float4(g.x * qw.x, g.y * qw.y, g.z * qw.z, g.w * qw.w);
+        float4 qj[REP], S[REP];
+#pragma unroll
+        for (int j = 0; j < REP; ++j) {
+            S[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            qj[j] = (j < rep) ? reinterpret_cast<const float4*>(qv + (int64_t)(mem * rep + j) * H)[hu]
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        reinterpret_cast<float4*>(dqv + (int64_t)b * H)[hu] = make_float4(S.x * ww.x, S.y * ww.y, S.z * ww.z, S.w * ww.w);
-        reinterpret_cast<float4*>(part_dw + (int64_t)b * H)[hu] = make_float4(S.x * q.x, S.y * q.y, S.z * q.z, S.w * q.w);
+        for (int r = 0; r < R; ++r) {
+            const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < REP; ++j) {
+                if (j < rep) {
+                    const float d = ds[j * R + r];
+                    float4 g = make_float4(d, d, d, d);
+                    if (keepmask != nullptr) {
+                        const uchar4 m =
+                            reinterpret_cast<const uchar4*>(keepmask + ((int64_t)(mem * rep + j) * R + r) * H)[hu];
+                        g.x *= m.x * inv_keep; g.y *= m.y * inv_keep; g.z *= m.z * inv_keep; g.w *= m.w * inv_keep;
+                    }
+                    S[j].x += g.x * x.x; S[j].y += g.y * x.y; S[j].z += g.z * x.z; S[j].w += g.w * x.w;
+                    acc.x += g.x * qj[j].x * ww.x; acc.y += g.y * qj[j].y * ww.y;
+                    acc.z += g.z * qj[j].z * ww.z; acc.w += g.w * qj[j].w * ww.w;
+                }
+            }
+            reinterpret_cast<float4*>(dv + ((int64_t)mem * R + r) * H)[hu] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < REP; ++j) {
+            if (j < rep) {
+                const int64_t q = (int64_t)mem * rep + j;
+                reinterpret_cast<float4*>(dqv + q * H)[hu] =
+                    make_float4(S[j].x * ww.x, S[j].y * ww.y, S[j].z * ww.z, S[j].w * ww.w);
+                reinterpret_cast<float4*>(part_dw + q * H)[hu] =
+                    make_float4(S[j].x * qj[j].x, S[j].y * qj[j].y, S[j].z * qj[j].z, S[j].w * qj[j].w);
+            }
+        }
     }
 }
 
@@ -161,6 +193,13 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
 extern "C" int vqa_attn_pool_fwd(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
                                  const float* bias, const uint8_t* keepmask, float keep_prob, float* att,
                                  float* pooled, int B, int R, int H, int D, void* stream) {
+    return vqa_attn_pool_fwd_rep(v, qv, V, nb, w, bias, keepmask, keep_prob, att, pooled, B, 1, R, H, D, stream);
+}
+
+extern "C" int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const float* V, const int32_t* nb,
+                                     const float* w, const float* bias, const uint8_t* keepmask, float keep_prob,
+                                     float* att, float* pooled, int B, int rep, int R, int H, int D, void* stream) {
+    VQA_REQUIRE(rep >= 1 && rep <= 8, VQA_ERR_ARG);
     VQA_REQUIRE(v && qv && V && nb && w && bias && att && pooled, VQA_ERR_ARG);
     VQA_REQUIRE(B >= 0 && R > 0 && R <= MAX_R && H > 0 && D > 0, VQA_ERR_ARG);
     VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
@@ -169,8 +208,8 @@ extern "C" int vqa_attn_pool_fwd(const float* v, const float* qv, const float* V
     VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
     if (B == 0) return VQA_OK;
     const size_t lds = (size_t)(H + R) * sizeof(float);
-    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, v, qv, V, nb, w, bias,
-                       keepmask, keepmask ? 1.f / keep_prob : 1.f, att, pooled, R, H, D);
+    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B * rep), dim3(256), lds, (hipStream_t)stream, v, qv, V, nb, w, bias,
+                       keepmask, keepmask ? 1.f / keep_prob : 1.f, att, pooled, R, H, D, rep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -178,6 +217,15 @@ extern "C" int vqa_attn_pool_fwd(const float* v, const float* qv, const float* V
 extern "C" int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, const float* V,
                                  const float* att, const float* w, const uint8_t* keepmask, float keep_prob, float* dv,
                                  float* dqv, float* part_dw, float* part_db, int B, int R, int H, int D, void* stream) {
+    return vqa_attn_pool_bwd_rep(dpooled, v, qv, V, att, w, keepmask, keep_prob, dv, dqv, part_dw, part_db, B, 1, R, H,
+                                 D, stream);
+}
+
+extern "C" int vqa_attn_pool_bwd_rep(const float* dpooled, const float* v, const float* qv, const float* V,
+                                     const float* att, const float* w, const uint8_t* keepmask, float keep_prob,
+                                     float* dv, float* dqv, float* part_dw, float* part_db, int B, int rep, int R,
+                                     int H, int D, void* stream) {
+    VQA_REQUIRE(rep >= 1 && rep <= 8, VQA_ERR_ARG);
     VQA_REQUIRE(dpooled && v && qv && V && att && w && dv && dqv && part_dw && part_db, VQA_ERR_ARG);
     VQA_REQUIRE(B >= 0 && R > 0 && R <= MAX_R && H > 0 && D > 0, VQA_ERR_ARG);
     VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
@@ -187,9 +235,18 @@ extern "C" int vqa_attn_pool_bwd(const float* dpooled, const float* v, const flo
                 VQA_ERR_ALIGN);
     VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
     if (B == 0) return VQA_OK;
-    const size_t lds = (size_t)(D + R) * sizeof(float);
-    hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dpooled, v, qv, V, att, w,
-                       keepmask, keepmask ? 1.f / keep_prob : 1.f, dv, dqv, part_dw, part_db, R, H, D);
+    const size_t lds = (size_t)(D + rep * R) * sizeof(float);
+    const float ik = keepmask ? 1.f / keep_prob : 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    if (rep == 1)
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
+                           dv, dqv, part_dw, part_db, R, H, D, rep);
+    else if (rep <= 5)
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<5>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
+                           dv, dqv, part_dw, part_db, R, H, D, rep);
+    else
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<8>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
+                           dv, dqv, part_dw, part_db, R, H, D, rep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -46,7 +46,7 @@ template <int U>
 __global__ void ln_relu_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, const uint8_t* __restrict__ keepmask,
                                    float inv_keep, float* __restrict__ y, float* __restrict__ mean_out,
-                                   float* __restrict__ rstd_out, int rows, int N, int CUt, int RY) {
+                                   float* __restrict__ rstd_out, int rows, int N, int CUt, int RY, int act) {
     __shared__ float red[16];
     const int g = blockIdx.x;
     const int cx = threadIdx.x % CUt, ry = threadIdx.x / CUt;
@@ -82,7 +82,8 @@ __global__ void ln_relu_fwd_kernel(const float* __restrict__ pre, const float* _
             if (keepmask != nullptr) km.load_mask(keepmask + off);
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                float v = fmaxf((x.v[j] - mean) * rstd * ga.v[j] + be.v[j], 0.f);
+                const float ln = (x.v[j] - mean) * rstd * ga.v[j] + be.v[j];
+                float v = act == 0 ? fmaxf(ln, 0.f) : tanhf(ln);
                 if (keepmask != nullptr) v = v * km.v[j] * inv_keep;
                 o.v[j] = v;
             }
@@ -122,7 +123,7 @@ __global__ void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dpre,
                                    float* __restrict__ part_dgamma, float* __restrict__ part_dbeta,
-                                   float* __restrict__ part_dbias, int rows, int N, int CUt, int RY) {
+                                   float* __restrict__ part_dbias, int rows, int N, int CUt, int RY, int act) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];  // [2][RY*CUt*U] when RY > 1
     __shared__ float red[16];
     const int g = blockIdx.x;
@@ -155,7 +156,9 @@ __global__ void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __
                     const float ln = xh * ga.v[j] + be.v[j];
                     float gg = d.v[j];
                     if (keepmask != nullptr) gg = gg * km.v[j] * inv_keep;
-                    const float dln = ln > 0.f ? gg : 0.f;
+                    float dln;
+                    if (act == 0) dln = ln > 0.f ? gg : 0.f;
+                    else { const float th = tanhf(ln); dln = gg * (1.f - th * th); }
                     const float dxh = dln * ga.v[j];
                     s1 += dxh;
                     s2 += dxh * xh;
@@ -190,7 +193,10 @@ __global__ void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __
                     const float ln = xh * ga.v[j] + be.v[j];
                     float gg = d.v[j];
                     if (keepmask != nullptr) gg = gg * km.v[j] * inv_keep;
-                    const float dxh = (ln > 0.f ? gg : 0.f) * ga.v[j];
+                    float dln;
+                    if (act == 0) dln = ln > 0.f ? gg : 0.f;
+                    else { const float th = tanhf(ln); dln = gg * (1.f - th * th); }
+                    const float dxh = dln * ga.v[j];
                     const float dp = rstd * (dxh - m1 - xh * m2);
                     o.v[j] = dp;
                     cbias[j] += dp;
@@ -223,6 +229,13 @@ Shape pick(const void* a, const void* b, const void* c, int rows, int N, bool ma
 extern "C" int vqa_ln_relu_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask,
                                float keep_prob, float* y, float* mean, float* rstd, int G, int rows, int N,
                                void* stream) {
+    return vqa_ln_act_fwd(pre, gamma, beta, keepmask, keep_prob, y, mean, rstd, G, rows, N, 0, stream);
+}
+
+extern "C" int vqa_ln_act_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask,
+                              float keep_prob, float* y, float* mean, float* rstd, int G, int rows, int N, int act,
+                              void* stream) {
+    VQA_REQUIRE(act == 0 || act == 1, VQA_ERR_ARG);
     VQA_REQUIRE(pre && gamma && beta && y && mean && rstd && G >= 0 && rows > 0 && N > 0, VQA_ERR_ARG);
     VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
     if (G == 0) return VQA_OK;
@@ -235,10 +248,10 @@ extern "C" int vqa_ln_relu_fwd(const float* pre, const float* gamma, const float
     hipStream_t st = (hipStream_t)stream;
     if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_fwd_kernel<4>, dim3(G), dim3(s.threads), 0, st, pre, gamma, beta, keepmask, inv_keep,
-                           y, mean, rstd, rows, N, s.CUt, s.RY);
+                           y, mean, rstd, rows, N, s.CUt, s.RY, act);
     else
         hipLaunchKernelGGL(ln_relu_fwd_kernel<1>, dim3(G), dim3(s.threads), 0, st, pre, gamma, beta, keepmask, inv_keep,
-                           y, mean, rstd, rows, N, s.CUt, s.RY);
+                           y, mean, rstd, rows, N, s.CUt, s.RY, act);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -247,6 +260,15 @@ extern "C" int vqa_ln_relu_bwd(const float* dy, const float* pre, const float* m
                                const float* gamma, const float* beta, const uint8_t* keepmask, float keep_prob,
                                float* dpre, float* part_dgamma, float* part_dbeta, float* part_dbias, int G, int rows,
                                int N, void* stream) {
+    return vqa_ln_act_bwd(dy, pre, mean, rstd, gamma, beta, keepmask, keep_prob, dpre, part_dgamma, part_dbeta,
+                          part_dbias, G, rows, N, 0, stream);
+}
+
+extern "C" int vqa_ln_act_bwd(const float* dy, const float* pre, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, const uint8_t* keepmask, float keep_prob,
+                              float* dpre, float* part_dgamma, float* part_dbeta, float* part_dbias, int G, int rows,
+                              int N, int act, void* stream) {
+    VQA_REQUIRE(act == 0 || act == 1, VQA_ERR_ARG);
     VQA_REQUIRE(dy && pre && mean && rstd && gamma && beta && dpre && G >= 0 && rows > 0 && N > 0, VQA_ERR_ARG);
     VQA_REQUIRE((part_dgamma == nullptr) == (part_dbeta == nullptr), VQA_ERR_ARG);
     VQA_REQUIRE(keepmask == nullptr || keep_prob > 0.f, VQA_ERR_ARG);
@@ -263,10 +285,10 @@ extern "C" int vqa_ln_relu_bwd(const float* dy, const float* pre, const float* m
     hipStream_t st = (hipStream_t)stream;
     if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_bwd_kernel<4>, dim3(G), dim3(s.threads), dyn, st, dy, pre, mean, rstd, gamma, beta,
-                           keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY);
+                           keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY, act);
     else
         hipLaunchKernelGGL(ln_relu_bwd_kernel<1>, dim3(G), dim3(s.threads), dyn, st, dy, pre, mean, rstd, gamma, beta,
-                           keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY);
+                           keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY, act);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

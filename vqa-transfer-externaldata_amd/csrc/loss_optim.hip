@@ -141,6 +141,60 @@ __global__ __launch_bounds__(256) void report_reduce_kernel(const float* __restr
     }
 }
 
+// n-way softmax cross-entropy with a validity mask, top-1 and top-k hit (cfg-5 pre-training model:
+// n_way_classification_loss, vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:675-706).
+// One workgroup per row.  stats[row] = {ce*valid, (argmax == label)*valid, (label in top-k)*valid, valid};
+// dz[row,:] = (softmax - onehot) * valid * inv_valid_sum[0]   (inv_valid_sum = 1 / sum(valid), on device)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, const int32_t* __restrict__ label,
+                                                         const float* __restrict__ valid, int topk,
+                                                         const float* __restrict__ inv_valid_sum,
+                                                         float* __restrict__ stats, float* __restrict__ dz, int A) {
+    __shared__ float red[16];
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* zb = z + (int64_t)b * A;
+    const int lab = label[b];
+    const float zl = zb[min(max(lab, 0), A - 1)];
+    float mx = -INFINITY;
+    ArgMax am{-INFINITY, 0x7fffffff};
+    int rank = 0;   // entries that tf.nn.top_k orders before the label: larger, or equal with a lower index
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float x = zb[a];
+        mx = fmaxf(mx, x);
+        if (x > am.v) { am.v = x; am.i = a; }
+        rank += (x > zl || (x == zl && a < lab)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax other{__shfl_xor(am.v, o, 64), __shfl_xor(am.i, o, 64)};
+        am = argmax_combine(am, other);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) { redv[wave] = am.v; redi[wave] = am.i; red[8 + wave] = mx; }
+    const float frank = block_sum((float)rank, red);      // (its barriers also publish redv/redi/red[8..])
+    mx = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+    ArgMax best{redv[0], redi[0]};
+    for (int k = 1; k < 4; ++k) best = argmax_combine(best, ArgMax{redv[k], redi[k]});
+    float se = 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) se += expf(zb[a] - mx);
+    se = block_sum(se, red);
+    const float lse = mx + logf(se);
+    const float vm = valid[b];
+    if (dz != nullptr) {
+        const float sc = vm * inv_valid_sum[0];
+        for (int a = threadIdx.x; a < A; a += 256)
+            dz[(int64_t)b * A + a] = (expf(zb[a] - lse) - (a == lab ? 1.f : 0.f)) * sc;
+    }
+    if (threadIdx.x == 0) {
+        float* s = stats + (int64_t)b * 4;
+        s[0] = (lse - zl) * vm;
+        s[1] = (best.i == lab ? 1.f : 0.f) * vm;
+        s[2] = (frank < (float)topk ? 1.f : 0.f) * vm;
+        s[3] = vm;
+    }
+}
+
 // ------------------------------------------------------------------ optimiser
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
                                                             float* __restrict__ partial) {
@@ -225,6 +279,17 @@ extern "C" int vqa_loss_fwd(const float* z, const float* target, const float* tr
     if (B == 0) return VQA_OK;
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z, target, train_mask, obj_mask,
                        attr_mask, exist_mask, use_train_mask_in_loss, inv_batch, stats, pred, dz, A);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_softmax_ce_fwd(const float* z, const int32_t* label, const float* valid, int topk,
+                                  const float* inv_valid_sum, float* stats, float* dz, int rows, int A, void* stream) {
+    VQA_REQUIRE(z && label && valid && stats && rows >= 0 && A > 0 && topk > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(dz == nullptr || inv_valid_sum != nullptr, VQA_ERR_ARG);
+    if (rows == 0) return VQA_OK;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, z, label, valid, topk,
+                       inv_valid_sum, stats, dz, A);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ ac
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc[i] += x[i];
 }
 
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dx, int64_t n) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float t = y[i];
+        dx[i] = dy[i] * (1.f - t * t);
+    }
+}
+
 // ------------------------------------------------------------------ a4 (GRU gate math)
 __global__ __launch_bounds__(256) void gru_gates_fwd_kernel(const float* __restrict__ gpre, int ldg,
                                                             const float* __restrict__ h_prev, float* __restrict__ r,
@@ -218,6 +229,20 @@ extern "C" int vqa_mul_bwd(const float* dz, const float* a, const float* b, floa
     VQA_REQUIRE(dz && a && b && da && db && n >= 0, VQA_ERR_ARG);
     if (n == 0) return VQA_OK;
     hipLaunchKernelGGL(mul_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dz, a, b, da, db, n);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+    VQA_REQUIRE(x && y && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    VQA_REQUIRE(dy && y && dx && n >= 0, VQA_ERR_ARG);
+    if (n == 0) return VQA_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

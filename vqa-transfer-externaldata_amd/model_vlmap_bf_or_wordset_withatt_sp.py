@@ -1,0 +1,124 @@
+"""Model class of the cfg-5 pre-training stage with the constructor / attributes of
+vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:13-94: Model(batch, config, is_train) ->
+.loss, .losses, .report (13 scalars), .mid_result, .vocab, .answer_dict, .ws_dict; config carries
+data_cfg (n_obj_bf, n_attr_bf, max_box_num, vfeat_dim), data_dir, expand_depth.  build() runs the
+forward pass of the current batch on libvqahot.so through pretrain.PretrainEngine."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import pretrain as PT
+from .dataset_vlmap import _load_pickle
+
+TOP_K = 5
+W_DIM = 300   # Word dimension
+L_DIM = 1024  # Language dimension
+V_DIM = 1024
+
+
+class Model(object):
+
+    def __init__(self, batch, config, is_train=True):
+        self.batch = batch
+        self.config = config
+        self.data_cfg = config.data_cfg
+        self.data_dir = getattr(config, "data_dir", None)
+        self.is_train = is_train
+        self.device = torch.device(getattr(config, "device", "cuda:0"))
+        self.losses, self.report, self.mid_result, self.vis_image = {}, {}, {}, {}
+
+        self.vocab = getattr(config, "vocab", None) or _load_pickle(os.path.join(self.data_dir, "vocab.pkl"))
+        self.answer_dict = getattr(config, "answer_dict", None) or _load_pickle(
+            os.path.join(self.data_dir, "answer_dict.pkl"))
+        self.num_answer = len(self.answer_dict["vocab"])
+        self.ws_dict = getattr(config, "ws_dict", None) or _load_pickle(os.path.join(
+            self.data_dir, "wordset_dict5_depth{}.pkl".format(int(getattr(config, "expand_depth", 0)))))
+        self.num_ws = len(self.ws_dict["vocab"])
+        self._step = 0
+        self._engine = None
+        self.build()
+
+    def filter_train_vars(self, trainable_vars):
+        return list(trainable_vars)                       # every variable trains (:45-51)
+
+    def _initial_params(self, shapes):
+        seed = int(getattr(self.config, "seed", 123))
+        g = torch.Generator().manual_seed(seed)
+        p = {}
+        for n, s in shapes.items():
+            if n.endswith("/weights") or n.endswith("/kernel"):
+                lim = (6.0 / (s[0] + s[1])) ** 0.5
+                p[n] = ((torch.rand(s, generator=g) * 2 - 1) * lim).numpy()
+            elif n.endswith("gates/bias") or n.endswith("/gamma"):
+                p[n] = np.ones(s, np.float32)
+            elif n == "wordset_map/learn":                 # random_uniform(-0.01, 0.01), modules.py:351-358
+                p[n] = (torch.rand(s, generator=g) * 0.02 - 0.01).numpy()
+            elif n.endswith("embed_map"):                  # GloVe rows when available, else zeros (OOV)
+                glove = getattr(self.config, "glove", None)
+                p[n] = np.zeros(s, np.float32) if glove is None else glove[n]
+                if glove is None and getattr(self.config, "synthetic", 0):
+                    p[n] = (torch.rand(s, generator=g) * 0.02 - 0.01).numpy()
+            else:
+                p[n] = np.zeros(s, np.float32)
+        return p
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def variables(self):
+        return dict(self._engine.params)
+
+    def set_batch(self, batch):
+        self.batch = batch
+
+    def _device_batch(self):
+        keep = ("image_ft", "spatial_ft", "num_boxes")
+        out = {}
+        for k, v in self.batch.items():
+            if k in keep or k.split("/")[-1] in ("normal_boxes", "fills", "blanks", "blanks_len", "wordsets", "num"):
+                if k == "normal_boxes":
+                    continue
+                t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
+                out[k] = t.to(self.device)
+        for k in ("image_ft", "spatial_ft"):
+            out[k] = out[k].float()
+        for k in list(out):
+            if k.endswith("_blank_fill/normal_boxes"):
+                out[k] = out[k].float()
+        return out
+
+    def build(self):
+        """build network architecture and loss (here: run it on self.batch)"""
+        db = self._device_batch()
+        if self._engine is None:
+            cfg = self.data_cfg
+            shapes = PT.variable_shapes(len(self.vocab["vocab"]), self.num_ws, self.num_answer, W_DIM, cfg.vfeat_dim,
+                                        V_DIM)
+            self._engine = PT.PretrainEngine(n=cfg.n_obj_bf, R=cfg.max_box_num, D=cfg.vfeat_dim, H=V_DIM, W=W_DIM,
+                                             A=self.num_answer, Vq=len(self.vocab["vocab"]), n_ws=self.num_ws,
+                                             params=self._initial_params(shapes), device=self.device)
+        eng = self._engine
+        B = db["image_ft"].shape[0]
+        masks = None if getattr(self.config, "dropout_off", False) else eng.make_keep_masks(
+            B, int(getattr(self.config, "seed", 123)), self._step)
+        self._step += 1
+        eng.forward(db, masks)
+        self.report = eng.fetch_report()
+        self.losses = {k[:-5]: v for k, v in self.report.items() if k.endswith("_loss") and k != "total_loss"}
+        self.loss = self.report["total_loss"]
+        for k in PT.KINDS:
+            kt = eng._tape["kinds"][k]
+            name = "object" if k == "obj" else "attribute"
+            self.mid_result[name + "_pooled_V_ft"] = kt["pooled"].view(B, eng.n, -1)
+            self.mid_result[k + "_blank_fill/logit"] = kt["wordset"]["z"].view(B, eng.n, -1)
+        return self.loss
+
+    def backward(self):
+        self._engine.backward()
+
+    def apply_gradients(self, learning_rate):
+        self._engine.optimizer_step(learning_rate)

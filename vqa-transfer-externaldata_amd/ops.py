@@ -154,3 +154,124 @@ def sumsq(g, extra=None):
     ws = _f32(int(lib.vqa_sumsq_workspace_floats(g.numel())) + 4, like=g)
     _lib.check(lib.vqa_sumsq(_p(g), g.numel(), _p(extra), _p(out), _p(ws), ws.numel(), _st(g)), "vqa_sumsq")
     return out[0]
+
+
+# ---------------------------------------------------------------- ops used by the pre-training model
+def ln_act_fwd(pre, gamma, beta, rows=1, act="relu", keepmask=None, keep_prob=1.0):
+    """modules.fc_layer's layer_norm + activation ('relu' | 'tanh') (+ dropout)."""
+    lib = _lib.load()
+    M, N = pre.shape
+    G = M // rows
+    y = torch.empty_like(pre)
+    mean, rstd = _f32(G, like=pre), _f32(G, like=pre)
+    _lib.check(lib.vqa_ln_act_fwd(_p(pre), _p(gamma), _p(beta), _p(keepmask), keep_prob, _p(y), _p(mean), _p(rstd), G,
+                                  rows, N, 0 if act == "relu" else 1, _st(pre)), "vqa_ln_act_fwd")
+    return y, mean, rstd
+
+
+def ln_act_bwd(dy, pre, mean, rstd, gamma, beta, rows=1, act="relu", keepmask=None, keep_prob=1.0):
+    lib = _lib.load()
+    M, N = pre.shape
+    G = M // rows
+    dpre = torch.empty_like(pre)
+    pg, pb, pbias = _f32(G, N, like=pre), _f32(G, N, like=pre), _f32(G, N, like=pre)
+    _lib.check(lib.vqa_ln_act_bwd(_p(dy), _p(pre), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(keepmask), keep_prob,
+                                  _p(dpre), _p(pg), _p(pb), _p(pbias), G, rows, N, 0 if act == "relu" else 1,
+                                  _st(pre)), "vqa_ln_act_bwd")
+    return dpre, colsum(pg), colsum(pb), colsum(pbias)
+
+
+def attn_pool_fwd_rep(v, qv, V, nb, w, bias, rep, keepmask=None, keep_prob=1.0):
+    """`rep` queries per memory: v [B,R,H], V [B,R,D], nb [B]; qv [B*rep,H] -> att [B*rep,R], pooled [B*rep,D]."""
+    lib = _lib.load()
+    B, R, H = v.shape
+    D = V.shape[2]
+    att, pooled = _f32(B * rep, R, like=v), _f32(B * rep, D, like=v)
+    _lib.check(lib.vqa_attn_pool_fwd_rep(_p(v), _p(qv), _p(V), _p(nb), _p(w), _p(bias), _p(keepmask), keep_prob,
+                                         _p(att), _p(pooled), B, rep, R, H, D, _st(v)), "vqa_attn_pool_fwd_rep")
+    return att, pooled
+
+
+def attn_pool_bwd_rep(dpooled, v, qv, V, att, w, rep, keepmask=None, keep_prob=1.0):
+    lib = _lib.load()
+    B, R, H = v.shape
+    D = V.shape[2]
+    dv, dqv = torch.empty_like(v), torch.empty_like(qv)
+    pdw, pdb = _f32(B * rep, H, like=v), _f32(B * rep, 1, like=v)
+    _lib.check(lib.vqa_attn_pool_bwd_rep(_p(dpooled), _p(v), _p(qv), _p(V), _p(att), _p(w), _p(keepmask), keep_prob,
+                                         _p(dv), _p(dqv), _p(pdw), _p(pdb), B, rep, R, H, D, _st(v)),
+               "vqa_attn_pool_bwd_rep")
+    return dv, dqv, colsum(pdw), colsum(pdb)
+
+
+def tanh_fwd(x):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    _lib.check(lib.vqa_tanh_fwd(_p(x), _p(y), x.numel(), _st(x)), "vqa_tanh_fwd")
+    return y
+
+
+def tanh_bwd(dy, y):
+    lib = _lib.load()
+    dx = torch.empty_like(y)
+    _lib.check(lib.vqa_tanh_bwd(_p(dy), _p(y), _p(dx), y.numel(), _st(y)), "vqa_tanh_bwd")
+    return dx
+
+
+def mul(a, b):
+    lib = _lib.load()
+    z = torch.empty_like(a)
+    _lib.check(lib.vqa_mul(_p(a), _p(b), _p(z), a.numel(), _st(a)), "vqa_mul")
+    return z
+
+
+def mul_bwd(dz, a, b):
+    lib = _lib.load()
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    _lib.check(lib.vqa_mul_bwd(_p(dz), _p(a), _p(b), _p(da), _p(db), a.numel(), _st(a)), "vqa_mul_bwd")
+    return da, db
+
+
+def add_inplace(acc, x):
+    lib = _lib.load()
+    _lib.check(lib.vqa_add_inplace(_p(acc), _p(x), acc.numel(), _st(acc)), "vqa_add_inplace")
+    return acc
+
+
+def embed_bwd_into(dx_tm, q, dE):
+    """dE[q[b,t],:] += dx_tm[t,b,:] (scatter-add into an existing gradient buffer)."""
+    lib = _lib.load()
+    T, B, W = dx_tm.shape
+    _lib.check(lib.vqa_embed_bwd(_p(dx_tm), _p(q), _p(dE), B, T, W, dE.shape[0], _st(dx_tm)), "vqa_embed_bwd")
+
+
+def gru_seq_fwd(xp, Wg_h, Wc_h, lens, T, B, H):
+    """Fused recurrence.  xp [T,B,3H] (x-projections + biases); returns hs [T+1,B,H] and the tape."""
+    lib = _lib.load()
+    hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=xp.device)
+    r, u, c, rh = (_f32(T, B, H, like=xp) for _ in range(4))
+    _lib.check(lib.vqa_gru_seq_fwd(_p(xp), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(rh), T, B, H,
+                                   _st(xp)), "vqa_gru_seq_fwd")
+    return hs, (r, u, c, rh)
+
+
+def gru_seq_bwd(dh_T, Wg_h, Wc_h, lens, hs, tape, T, B, H):
+    """Returns dxp [T,B,3H] = (dr_pre | du_pre | dc_pre); dh_T is consumed."""
+    lib = _lib.load()
+    r, u, c, rh = tape
+    dxp = _f32(T, B, 3 * H, like=hs)
+    scratch = _f32(B, H, like=hs)
+    _lib.check(lib.vqa_gru_seq_bwd(_p(dh_T), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(dxp),
+                                   _p(scratch), T, B, H, _st(hs)), "vqa_gru_seq_bwd")
+    return dxp
+
+
+def softmax_ce(z, label, valid, inv_valid_sum, topk=5, want_dz=True):
+    """n_way_classification_loss rows: stats [rows,4] = {ce, top1, topk, valid} (x valid); dz for backward."""
+    lib = _lib.load()
+    rows, A = z.shape
+    stats = _f32(rows, 4, like=z)
+    dz = torch.empty_like(z) if want_dz else None
+    _lib.check(lib.vqa_softmax_ce_fwd(_p(z), _p(label), _p(valid), topk, _p(inv_valid_sum), _p(stats), _p(dz), rows, A,
+                                      _st(z)), "vqa_softmax_ce_fwd")
+    return stats, dz
