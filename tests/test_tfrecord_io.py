@@ -1,0 +1,77 @@
+"""TF-free TFRecord / tf.Example IO: known-answer vectors of the public formats and a
+round trip through the reference's VQA example schema."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vqa_transfer_externaldata_amd import input_ops_vqa, tfrecord_io as T
+
+
+def test_crc32c_known_answers():
+    assert T.crc32c(b"") == 0
+    assert T.crc32c(b"123456789") == 0xE3069283           # the standard CRC-32C check value
+    assert T.crc32c(b"\x00" * 32) == 0x8A9136AA            # RFC 3720 B.4 test vector
+    assert T.masked_crc32c(b"123456789") == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_example_wire_format_known_bytes():
+    # hand-assembled tf.Example {"a": int64_list[3]}:  features(1){ feature(1){ key(1)="a", value(2){ int64_list(3){ value(1) packed [3] }}}}
+    raw = bytes([0x0A, 0x0C, 0x0A, 0x0A, 0x0A, 0x01, 0x61, 0x12, 0x05, 0x1A, 0x03, 0x0A, 0x01, 0x03])
+    assert T.make_example({"a": [3]}) == raw
+    ex = T.parse_example(raw)
+    np.testing.assert_array_equal(ex["a"], [3])
+    # un-packed int64 (wire type 0) and negative values are accepted too
+    raw2 = bytes([0x0A, 0x0B, 0x0A, 0x09, 0x0A, 0x01, 0x62, 0x12, 0x04, 0x1A, 0x02, 0x08, 0x05])
+    np.testing.assert_array_equal(T.parse_example(raw2)["b"], [5])
+    np.testing.assert_array_equal(T.parse_example(T.make_example({"n": [-1, 2 ** 40]}))["n"], [-1, 2 ** 40])
+
+
+def test_vqa_schema_round_trip_and_batching(tmp_path):
+    d = input_ops_vqa.synthetic_split(23, 10, 50, 21, seed=5)
+    recs = []
+    for r in range(len(d)):
+        q = d.q_flat[d.q_off[r]:d.q_off[r + 1]]
+        a0, a1 = d.ans_off[r], d.ans_off[r + 1]
+        recs.append(T.make_example({                        # generator_tf_record_memft_genome.py:184-194
+            "qid": [int(d.qid[r])], "image_id": str(d.image_id[r]), "image_idx": [int(d.image_idx[r])],
+            "q_intseq/list": q, "q_intseq/len": [len(q)], "answers/ids": d.ans_ids[a0:a1],
+            "answers/scores": d.ans_scores[a0:a1], "answers/max_freq_answer": [int(d.ans_ids[a0])]}))
+    os.makedirs(tmp_path / "val")
+    T.write_records(str(tmp_path / "val" / "val-00000-of-00002"), recs[:12])
+    T.write_records(str(tmp_path / "val" / "val-00001-of-00002"), recs[12:])
+    (tmp_path / "data_info.json").write_text('{"num_answers": 21}')
+    assert len(list(T.read_records(str(tmp_path / "val" / "val-00000-of-00002"), verify=True))) == 12
+    got = list(input_ops_vqa.create(8, str(tmp_path), "val", is_train=False, shuffle=False))
+    want = list(input_ops_vqa.create(8, None, "val", is_train=False, shuffle=False, data=d))
+    assert len(got) == len(want) == 3
+    for g, w in zip(got, want):
+        for k in ("id", "image_idx", "q_intseq", "q_intseq_len", "answer_target"):
+            np.testing.assert_array_equal(g[k], w[k])
+        assert list(g["image_id"]) == list(w["image_id"])
+    # corruption is detected when verification is on
+    p = tmp_path / "val" / "val-00001-of-00002"
+    b = bytearray(p.read_bytes()); b[20] ^= 0xFF; p.write_bytes(bytes(b))
+    with pytest.raises(IOError, match="CRC"):
+        list(T.read_records(str(p), verify=True))
+
+
+def test_eval_collection_formats(tmp_path):
+    import pickle
+    from vqa_transfer_externaldata_amd import eval_collection as EC
+    run = tmp_path / "run"
+    for it, sc in ((1, 0.1), (801, 0.45)):
+        (run / ("model-%d" % it)).parent.mkdir(exist_ok=True)
+        (run / ("model-%d" % it)).write_bytes(b"x")
+        ed = run / ("model-%d_eval_testval_20180101-000000" % it)
+        ed.mkdir()
+        avg = {}
+        for k in ("testonly_score", "test_obj_only_score", "test_attr_only_score"):
+            avg[k], avg[k + "_num_point"] = sc, 7
+        pickle.dump({"qid2result": {}, "avg_eval_report": avg}, open(ed / "results.pkl", "wb"))
+    assert [os.path.basename(p) for p in EC.checkpoints_of(str(run))] == ["model-1", "model-801"]
+    res = EC.collect(str(run), "testval")
+    assert res["iter"] == [1, 801] and res["testonly_score"] == [0.1, 0.45]
+    lines = (run / "collect_eval_testval_result.txt").read_text().splitlines()
+    assert lines[0].split()[0] == "iter" and lines[2] == "00801 0.45000 00000007 0.45000 00000007 0.45000 00000007"

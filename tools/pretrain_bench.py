@@ -1,0 +1,30 @@
+"""Throughput of the cfg-5 pre-training step (BASELINE configs[4], stage 1) at bs 512 on one MI355X."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pretrain_oracle as PO  # noqa: E402  (parameter / batch generators only)
+from vqa_transfer_externaldata_amd import pretrain as PT  # noqa: E402
+
+B, n, R, D, H, L, W, Vq, n_ws, A = 512, 5, 36, 2048, 1024, 10, 300, 5000, 2000, 4000
+rng = np.random.default_rng(0)
+p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H, perturb=False)
+batch = PO.make_batch(rng, B, n, R, D, L, Vq, n_ws, A)
+eng = PT.PretrainEngine(n=n, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=n_ws, params=p)
+db = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for i in range(3):
+    eng.train_step(db, eng.make_keep_masks(B, 1, i), 1e-3)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    eng.train_step(db, eng.make_keep_masks(B, 1, 3 + i), 1e-3)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+rep = eng.fetch_report()
+print("pretrain step %.2f ms  -> %.0f images/s (%.0f blank-fill entries/s); total_loss %.3f"
+      % (dt * 1e3, B / dt, 2 * B * n / dt, rep["total_loss"]))

@@ -603,9 +603,10 @@ int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int
 }
 
 struct TileCfg { int BM, BN; };
-constexpr int NUM_CFG = 14;
+constexpr int NUM_CFG = 16;
 const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 128}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 128},
-                               {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}};
+                               {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}, {128, 32},
+                               {128, 64}};
 
 // operands that allow the buffer-load fast path (see Stager::load_fast); fills the descriptor extents
 bool fast_ok(int tA, int tB, GemmArgs& a) {
@@ -647,6 +648,8 @@ int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a_in, int split, hipSt
         case 11: return launch_cfg<64, 32, 32, 32, 2, 64, true>(tA, tB, a, split, st, mb);
         case 12: return launch_cfg<64, 64, 32, 32, 1, 32, true>(tA, tB, a, split, st, mb);
         case 13: return launch_cfg<64, 32, 32, 32, 2, 32, true>(tA, tB, a, split, st, mb);
+        case 14: return launch_cfg<128, 32, 32, 32, 1, 64, true>(tA, tB, a, split, st, mb);
+        case 15: return launch_cfg<128, 64, 32, 64, 1, 32, true>(tA, tB, a, split, st, mb);
         default: return VQA_ERR_ARG;
     }
 }

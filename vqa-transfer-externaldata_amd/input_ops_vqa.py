@@ -84,7 +84,15 @@ def synthetic_split(num_examples, num_images, vocab_size, num_answers, max_len=1
 def create(batch_size, data_dir, split, is_train=True, scope="vqa", shuffle=True, seed=0, data=None,
            repeat=1000):
     """Iterator of batch dicts; `data` (a SplitData) overrides the files under data_dir."""
-    d = data if data is not None else SplitData.load(data_dir, split)
+    if data is not None:
+        d = data
+    elif os.path.exists(os.path.join(data_dir, split + ".npz")):
+        d = SplitData.load(data_dir, split)
+    else:                                    # the reference's own tfrecord shards (no TensorFlow needed)
+        from . import tfrecord_io
+        with open(os.path.join(data_dir, "data_info.json")) as f:
+            num_answers = json.load(f)["num_answers"]
+        d = tfrecord_io.load_vqa_split(data_dir, split, num_answers)
     n = len(d)
     order = np.arange(n)
     if is_train and shuffle:

@@ -65,7 +65,8 @@ class Trainer(object):
         ds = datasets or {}
         self._iters = {}
         for split, shuffle in (("train", True), ("val", False), ("testval", False), ("test", False)):
-            if split in ds or os.path.exists(os.path.join(self.tf_record_dir, split + ".npz")):
+            if split in ds or os.path.exists(os.path.join(self.tf_record_dir, split + ".npz")) or \
+                    os.path.isdir(os.path.join(self.tf_record_dir, split)):
                 self._iters[split] = input_ops_vqa.create(
                     self.batch_size, self.tf_record_dir, split, is_train=True, scope="%s_ops" % split,
                     shuffle=shuffle, seed=config.seed, data=ds.get(split))
