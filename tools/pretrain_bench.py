@@ -7,13 +7,15 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pretrain_oracle as PO  # noqa: E402  (parameter / batch generators only)
 from vqa_transfer_externaldata_amd import pretrain as PT  # noqa: E402
 
 B, n, R, D, H, L, W, Vq, n_ws, A = 512, 5, 36, 2048, 1024, 10, 300, 5000, 2000, 4000
 rng = np.random.default_rng(0)
-p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H, perturb=False)
-batch = PO.make_batch(rng, B, n, R, D, L, Vq, n_ws, A)
+p = PT.init_random_params(rng, Vq, n_ws, A, W=W, D=D, H=H)
+from vqa_transfer_externaldata_amd import dataset_vlmap as DV  # noqa: E402
+ds = DV.Dataset(split="train", data=DV.synthetic_dataset(B, Vq, n_ws, A, R=R, D=D, max_len=L, seed=0), seed=0)
+batch = next(DV.create_ops(B, ds, is_train=True, shuffle=False))
+batch = {k: v for k, v in batch.items() if v.dtype.kind in "fi" and k != "image_id"}
 eng = PT.PretrainEngine(n=n, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=n_ws, params=p)
 db = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10

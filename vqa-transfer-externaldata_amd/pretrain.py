@@ -58,6 +58,23 @@ def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024):
     return s
 
 
+def init_random_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024):
+    """Random-init weights of the architecture (Xavier-uniform FCs, GRU gate bias 1, LN gamma 1,
+    embeddings U(-0.01, 0.01); GloVe vectors are download-only)."""
+    p = {}
+    for n, shp in variable_shapes(Vq, n_ws, A, W, D, H).items():
+        if n.endswith("/weights") or n.endswith("/kernel"):
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            p[n] = rng.uniform(-lim, lim, size=shp).astype(np.float32)
+        elif n.endswith("gates/bias") or n.endswith("/gamma"):
+            p[n] = np.ones(shp, np.float32)
+        elif n.endswith("embed_map") or n.endswith("/learn"):
+            p[n] = rng.uniform(-0.01, 0.01, size=shp).astype(np.float32)
+        else:
+            p[n] = np.zeros(shp, np.float32)
+    return p
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 

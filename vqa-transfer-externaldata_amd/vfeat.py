@@ -31,6 +31,50 @@ def block_units(base_depth, num_units, stride):
     return [(base_depth * 4, base_depth, 1)] * (num_units - 1) + [(base_depth * 4, base_depth, stride)]
 
 
+def init_random_params(rng, blocks, scope="resnet_v1_50", dtype=np.float32):
+    """Random-init weights of the architecture under slim's variable names (He-normal convs, BatchNorm
+    gamma ~ 1, small beta / moving_mean, moving_variance ~ 1): stands in for data/nets/resnet_v1_50.ckpt,
+    which is download-only."""
+    p = {}
+
+    def conv(name, k, ci, co):
+        p[name + "/weights"] = (rng.standard_normal((k, k, ci, co)) * np.sqrt(2.0 / (k * k * ci))).astype(dtype)
+        p[name + "/BatchNorm/gamma"] = (1 + 0.1 * rng.standard_normal(co)).astype(dtype)
+        p[name + "/BatchNorm/beta"] = (0.1 * rng.standard_normal(co)).astype(dtype)
+        p[name + "/BatchNorm/moving_mean"] = (0.1 * rng.standard_normal(co)).astype(dtype)
+        p[name + "/BatchNorm/moving_variance"] = (1 + 0.2 * rng.random(co)).astype(dtype)
+
+    conv(scope + "/conv1", 7, 3, 64)
+    cin = 64
+    for name, base, n, stride in blocks:
+        for i, (depth, db, s) in enumerate(block_units(base, n, stride)):
+            pre = "%s/%s/unit_%d/bottleneck_v1" % (scope, name, i + 1)
+            if depth != cin:
+                conv(pre + "/shortcut", 1, cin, depth)
+            conv(pre + "/conv1", 1, cin, db)
+            conv(pre + "/conv2", 3, db, db)
+            conv(pre + "/conv3", 1, db, depth)
+            cin = depth
+    return p
+
+
+def conv_flops_per_image(blocks, H, W, c0=64):
+    """Algorithmic 2*MAC of conv1 + the bottleneck blocks for one HxW image."""
+    fl = 0
+    h, w = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    fl += 2 * h * w * 49 * 3 * c0
+    h, w = (h + 1) // 2, (w + 1) // 2
+    cin = c0
+    for name, base, n, stride in blocks:
+        for depth, db, s in block_units(base, n, stride):
+            ho, wo = ((h - 1) // s + 1, (w - 1) // s + 1) if s > 1 else (h, w)
+            if depth != cin:
+                fl += 2 * ho * wo * cin * depth
+            fl += 2 * h * w * cin * db + 2 * ho * wo * 9 * db * db + 2 * ho * wo * db * depth
+            h, w, cin = ho, wo, depth
+    return fl
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
