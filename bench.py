@@ -103,7 +103,9 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=2):
                       "oracle/torch_ref.py; the reference TF1 path cannot run here)" % (steps, cfg["B"])}
 
 
-ROOFLINE_KERNEL_KEY = "gemm_f32_kernel<64, 128, 32, 64, 1, 32, false, true, false, 0, false> grid=2304"
+# v_linear_v forward GEMM: 128x64 tiles (cfg 5), NN layout, plain epilogue -> 144 x 16 = 2304 workgroups
+ROOFLINE_KERNEL_PREFIX = "gemm_f32_kernel<128, 64, 64, 32, 1, 32, false, true, false, 0, false"
+ROOFLINE_KERNEL_GRID = "grid=2304"
 
 
 def pmc_traffic():
@@ -115,9 +117,12 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return float(d[ROOFLINE_KERNEL_KEY]["hbm_bytes_per_launch"])
+        for k, v in d.items():
+            if k.startswith(ROOFLINE_KERNEL_PREFIX) and k.endswith(ROOFLINE_KERNEL_GRID):
+                return float(v["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def vfeat_bench(device, batch=32, iters=3):
@@ -191,6 +196,8 @@ def main():
     lib = _lib.load()
     if os.environ.get("VQA_GRU_CFG"):
         _lib.check(lib.vqa_gemm_set_gru_config(int(os.environ["VQA_GRU_CFG"])), "vqa_gemm_set_gru_config")
+    if os.environ.get("VQA_GEMM_CFG"):     # tuning only: forces ONE tile config on every plain GEMM
+        _lib.check(lib.vqa_gemm_set_config(int(os.environ["VQA_GEMM_CFG"])), "vqa_gemm_set_config")
 
     def step(i):
         ka, kj = eng.make_keep_masks(seed=99 + rank, step=i)       # fresh dropout masks every step
@@ -241,7 +248,7 @@ def main():
                                    "3000 answers (BASELINE configs[1])",
                        "global_batch": cfg["B"] * world, "Vq": cfg["Vq"], "table_images": cfg["N_img"],
                        "parallelism": "dp%d" % world if world > 1 else "single"},
-            "roofline": {"kernel": "gemm_f32_kernel<64,128,32,64,1,32,false,true,false,0> (v_linear_v forward GEMM, "
+            "roofline": {"kernel": "gemm_f32_kernel<128,64,64,32,1,32,false,true,false,0> (v_linear_v forward GEMM, "
                                    "M=18432 N=1024 K=2048, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),

@@ -17,6 +17,8 @@
 // ds_read_b128 per 4 MFMAs; an operand whose m/n is contiguous is staged as
 // [k][BR] and read with conflict-free ds_read_b32.  Both sides use the same
 // permutation, so every k is consumed exactly once.
+#include <type_traits>
+
 #include "vqa_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -146,6 +148,36 @@ struct Stager {
             }
         }
     }
+    // Steady-state form for tiles that lie wholly inside the k range: the per-lane byte offset is
+    // computed ONCE (rows past M / N are clamped to a valid row -- their accumulators are never
+    // stored) and the k advance rides in the buffer load's SCALAR offset, so a tile's loads cost no
+    // vector ALU work at all; what VALU the loop keeps competes with the MFMAs for the issue port.
+    static constexpr int COUNT = BR * BK / 4;
+    static constexpr bool EXACT = (NV * 256 == COUNT);
+    unsigned voff[NV];
+    __device__ __forceinline__ void init_full(int ld, int r0, int kbeg, int RLIM) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = EXACT ? (int)threadIdx.x + i * 256 : min((int)threadIdx.x + i * 256, COUNT - 1);
+            if (KC) {
+                const int row = idx / KQ, kq = (idx % KQ) * 4;
+                const int gr = min(r0 + row, RLIM - 1);
+                voff[i] = (unsigned)(((int64_t)gr * ld + kbeg + kq) * 4);
+            } else {
+                constexpr int QPR = BR / 4;
+                const int k = idx / QPR, rq = (idx % QPR) * 4;
+                const int gr = (r0 + rq < RLIM) ? r0 + rq : 0;
+                voff[i] = (unsigned)(((int64_t)(kbeg + k) * ld + gr) * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void load_full(__amdgpu_buffer_rsrc_t rs, unsigned soff) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0);
+            reg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+    }
     // implicit im2col: one k tile lies inside ONE filter tap (Ci % BK == 0), so the tap offset is
     // wave-uniform and each lane only adds it to its pre-decoded pixel coordinates.
     __device__ __forceinline__ void load_conv(__amdgpu_buffer_rsrc_t rs, const int (&iy0)[NV], const int (&ix0)[NV],
@@ -166,13 +198,13 @@ struct Stager {
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * 256;
             if (KC) {
-                if (idx < BR * KQ) {
+                if (EXACT || idx < BR * KQ) {
                     const int row = idx / KQ, kq = (idx % KQ) * 4;
                     *reinterpret_cast<float4*>(s + row * KC_LD + kq) = reg[i];
                 }
             } else {
                 constexpr int QPR = BR / 4;
-                if (idx < BK * QPR) {
+                if (EXACT || idx < BK * QPR) {
                     const int k = idx / QPR, rq = (idx % QPR) * 4;
                     *reinterpret_cast<float4*>(s + k * BR + rq) = reg[i];
                 }
@@ -196,7 +228,7 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
+template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
           bool EDGE = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -209,6 +241,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
 
     // The fused GRU-step kernels sit on the step's critical path and run beside a big GEMM on the
     // side stream: raise their wave priority so they win MFMA/VALU arbitration on a shared SIMD.
+    // (Staggering the priorities of co-resident workgroups, to stop their waves convoying into the
+    // same barrier, was measured and changes nothing: the MFMA arbiter does not follow s_setprio.)
     if (EPI != EPI_PLAIN) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wk = wave / (WAVES_M * WAVES_N);
@@ -237,30 +271,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     const bool va = p.vecA, vb = p.vecB;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, (int)p.b_bytes, 0x00020000);
+    // fragments are double-buffered in registers: chunk cc+1's LDS reads are issued before chunk
+    // cc's MFMAs, so a wave's own reads are covered by its own MFMAs
     auto compute_tile = [&](const float* As, const float* Bs) {
+        constexpr int NC = BK / 8 / WGK;
+        float4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int cc = 0; cc < BK / 8 / WGK; ++cc) {
-            const int c = cc * WGK + wk;   // the k wave groups interleave over the 8-wide chunks
-            float4 af[TM], bf[TN];
+        for (int a = 0; a < TM; ++a) af[0][a] = frag4<BM, BK, A_KC>(As, wm * WM + a * 32, wk, lane);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = frag4<BM, BK, A_KC>(As, wm * WM + a * 32, c, lane);
+        for (int b = 0; b < TN; ++b) bf[0][b] = frag4<BN, BK, B_KC>(Bs, wn * WN + b * 32, wk, lane);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = frag4<BN, BK, B_KC>(Bs, wn * WN + b * 32, c, lane);
+        for (int cc = 0; cc < NC; ++cc) {
+            const int cur = cc & 1, nx = cur ^ 1;
+            if (cc + 1 < NC) {
+                const int c = (cc + 1) * WGK + wk;   // the k wave groups interleave over the 8-wide chunks
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[nx][a] = frag4<BM, BK, A_KC>(As, wm * WM + a * 32, c, lane);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[nx][b] = frag4<BN, BK, B_KC>(Bs, wn * WN + b * 32, c, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].x, bf[cur][b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].y, bf[cur][b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].z, bf[cur][b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].w, bf[cur][b].w, acc[a][b], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     float* L0 = smem;
     float* L1 = smem + (A_FL + B_FL);
 
-    if (!DEEP) {
+    if (DEEP == 0) {
         // one tile of register prefetch: enough when >= 2-3 workgroups share a CU
         Stager<BM, BK, A_KC> sa;
         Stager<BN, BK, B_KC> sb;
@@ -298,9 +344,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             sb.store(L0 + A_FL);
         }
         __syncthreads();
-        // steady state without conditionals (the last tile is peeled): loads of tile t+1 are issued
-        // before tile t's MFMA loop and consumed (LDS store) after it
-        for (int t = 0; t + 1 < nt; ++t) {
+        int t = 0;
+        if (!CONV && !EDGE) {
+            // full tiles, two per trip so both LDS buffers are compile-time addresses
+            sa.init_full(p.lda, m0, kbeg, p.M);
+            sb.init_full(p.ldb, n0, kbeg, p.N);
+            const unsigned stepA = (unsigned)(A_KC ? BK : BK * p.lda) * 4u;
+            const unsigned stepB = (unsigned)(B_KC ? BK : BK * p.ldb) * 4u;
+            const int nfull = (kend - kbeg) / BK;
+            unsigned oa = stepA, ob = stepB;   // scalar byte offsets of tile t + 1
+            for (; t + 2 < nfull; t += 2) {
+                sa.load_full(rsA, oa);
+                sb.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                sa.store(L1);
+                sb.store(L1 + A_FL);
+                __syncthreads();
+                sa.load_full(rsA, oa);
+                sb.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L1, L1 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                sa.store(L0);
+                sb.store(L0 + A_FL);
+                __syncthreads();
+            }
+        }
+        // remaining tiles (all of them for the conv / edge loaders) without conditionals, the last
+        // one peeled: loads of tile t+1 are issued before tile t's MFMA loop and consumed after it
+        for (; t + 1 < nt; ++t) {
             float* cur = (t & 1) ? L1 : L0;
             float* nxt = (t & 1) ? L0 : L1;
             load_a(kbeg + (t + 1) * BK);
@@ -340,6 +416,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         int t = 0;
         // steady state, unrolled by 2 so every register index is static and free of conditionals:
         // entering a pair, L0 holds tile t and set 1 holds tile t+1 (in flight)
+        {   // full tiles: fixed per-lane offsets, the k advance in the loads' scalar offset
+            sa0.init_full(p.lda, m0, kbeg, p.M); sa1.init_full(p.lda, m0, kbeg, p.M);
+            sb0.init_full(p.ldb, n0, kbeg, p.N); sb1.init_full(p.ldb, n0, kbeg, p.N);
+            const unsigned stepA = (unsigned)(A_KC ? BK : BK * p.lda) * 4u;
+            const unsigned stepB = (unsigned)(B_KC ? BK : BK * p.ldb) * 4u;
+            const int nfull = (kend - kbeg) / BK;
+            unsigned oa = 2 * stepA, ob = 2 * stepB;   // scalar byte offsets of tile t + 2
+            for (; t + 3 < nfull; t += 2) {
+                sa0.load_full(rsA, oa); sb0.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                st1();
+                __syncthreads();
+                sa1.load_full(rsA, oa); sb1.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L1, L1 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                st0();
+                __syncthreads();
+            }
+        }
         for (; t + 3 < nt; t += 2) {
             ld0(t + 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -552,7 +652,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
+template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
           bool EDGE = false>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
@@ -592,7 +692,7 @@ int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max
     return VQA_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, bool DEEP>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP>
 int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int mb) {
     const EpiArgs ep{};
     if (tA == 0 && tB == 0)
@@ -668,6 +768,7 @@ int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st)
         case 10: return launch_one<64, 64, 32, 32, 1, 64, true, true, BKC, EPI>(a, ep, 1, st);
         case 11: return launch_one<64, 32, 32, 32, 2, 64, true, true, BKC, EPI>(a, ep, 1, st);
         case 13: return launch_one<64, 32, 32, 32, 2, 32, true, true, BKC, EPI>(a, ep, 1, st);
+        case 16: return launch_one<32, 32, 32, 32, 4, 32, true, true, BKC, EPI>(a, ep, 1, st);
         default: return VQA_ERR_ARG;
     }
 }
@@ -676,18 +777,22 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
-int g_gru_cfg = 11;     // tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config)
+// tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config): 32x32 tiles, 4-way in-block split-k, two
+// tiles of register prefetch -- 1024 / 512 workgroups per step kernel hide latency better than 64x32 tiles
+// (recurrence 622 -> 591 us forward, 607 -> 549 us backward at B 512, H 1024, T 14)
+int g_gru_cfg = 16;
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
-//  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 32, and
-//    enough split-k slabs for >= 512 workgroups (dWv 603 us = 128 TFLOP/s);
-//  * tall activations (M >= 2048): 64x128 tiles (v_linear_v forward 618 us = 125 TFLOP/s);
+//  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, and
+//    enough split-k slabs for >= 512 workgroups (dWv 575 us = 134 TFLOP/s);
+//  * tall activations (M >= 2048): 128x64 tiles (v_linear_v forward 567 us = 136 TFLOP/s), 64x64
+//    when K is short;
 //  * batch-sized M (512) or narrow N: 64x32 tiles with in-block split-k and two tiles of register
 //    prefetch (one workgroup per CU cannot hide a global load behind a single tile's MFMAs).
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
-    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 1 : 3; target = 512; }
-    else if (M >= 2048) { cfg = (N >= 512) ? 6 : 13; target = 256; }
+    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 0 : 3; target = 512; }
+    else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? 5 : 3) : 13; target = 256; }
     else { cfg = tB ? 11 : 13; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
@@ -730,7 +835,7 @@ extern "C" int vqa_gemm_set_config(int cfg) {
 }
 
 extern "C" int vqa_gemm_set_gru_config(int cfg) {
-    VQA_REQUIRE(cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13, VQA_ERR_ARG);
+    VQA_REQUIRE(cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || cfg == 16, VQA_ERR_ARG);
     g_gru_cfg = cfg;
     return VQA_OK;
 }
