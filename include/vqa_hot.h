@@ -108,6 +108,10 @@ int vqa_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* st
 int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace, int64_t workspace_floats,
                void* stream);
 int64_t vqa_colsum_workspace_floats(int M, int N);
+/* Three equally shaped reductions in one pair of launches (the d_gamma / d_beta / d_bias partials of one
+ * fc_layer, vlmap/modules.py:630-650); workspace >= 3 * vqa_colsum_workspace_floats(M, N). */
+int vqa_colsum3(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0, float* out1,
+                float* out2, float* workspace, int64_t workspace_floats, void* stream);
 /* z = a * b elementwise (pooled_linear_l * l_linear_l, vqa/model_vlmap_answer.py:177) */
 int vqa_mul(const float* a, const float* b, float* z, int64_t n, void* stream);
 /* da = dz*b ; db = dz*a */

@@ -217,6 +217,12 @@ def test_colsum_and_sumsq_and_mask():
     rng = np.random.default_rng(4)
     X = rng.standard_normal((7168, 96)).astype(np.float32)
     close(ops.colsum(dev(X)), X.astype(np.float64).sum(0), 1e-4, 1e-3)
+    for M, N in ((512, 1024), (37, 70), (1, 4)):      # two-stage, ragged and single-stage shapes
+        Xs = [rng.standard_normal((M, N)).astype(np.float32) for _ in range(3)]
+        outs = ops.colsum3(*[dev(x) for x in Xs])
+        for x, o in zip(Xs, outs):
+            close(o, x.astype(np.float64).sum(0), 1e-4, 1e-3)
+            np.testing.assert_array_equal(o.cpu().numpy(), ops.colsum(dev(x)).cpu().numpy())   # same summation order
     g = rng.standard_normal(1000003).astype(np.float32)
     buf = torch.zeros(1000004, device="cuda")[:1000003]
     buf.copy_(dev(g))

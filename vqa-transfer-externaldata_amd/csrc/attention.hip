@@ -21,7 +21,10 @@ namespace {
 
 constexpr int MAX_R = 1024;
 
-__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
+// 512 threads: twice the waves (and loads in flight) per sample of the 256-thread form; the kernel is a
+// pure stream over v, the keep mask and V (~480 KB per sample)
+constexpr int FWD_THREADS = 512;
+__global__ __launch_bounds__(FWD_THREADS) void attn_pool_fwd_kernel(
     const float* __restrict__ v, const float* __restrict__ qv, const float* __restrict__ V,
     const int32_t* __restrict__ nb, const float* __restrict__ w, const float* __restrict__ bias,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ att_out, float* __restrict__ pooled, int R,
@@ -35,13 +38,14 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
     const float* Vb = V + (int64_t)mem * R * D;
 
-    for (int h = threadIdx.x; h < H; h += 256) qw[h] = qv[(int64_t)b * H + h] * w[h];
+    for (int h = threadIdx.x; h < H; h += FWD_THREADS) qw[h] = qv[(int64_t)b * H + h] * w[h];
     __syncthreads();
 
     const int H4 = H / 4;
-    for (int r = wave; r < R; r += 4) {
+    for (int r = wave; r < R; r += FWD_THREADS / 64) {
         float acc = 0.f;
         const float* vr = vb + (int64_t)r * H;
+#pragma unroll 4
         for (int hu = lane; hu < H4; hu += 64) {
             const float4 x = reinterpret_cast<const float4*>(vr)[hu];
             const float4 q = reinterpret_cast<const float4*>(qw)[hu];
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(
     __syncthreads();
 
     const int D4 = D / 4;
-    for (int du = threadIdx.x; du < D4; du += 256) {
+    for (int du = threadIdx.x; du < D4; du += FWD_THREADS) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
+#pragma unroll 6
         for (int r = 0; r < R; ++r) {
             const float a = s[r];
             const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
         float* dsj = ds + j * R;
         for (int r = wave; r < R; r += 4) {
             float acc = 0.f;
+#pragma unroll 8
             for (int du = lane; du < D4; du += 64) {
                 const float4 x = reinterpret_cast<const float4*>(Vb + (int64_t)r * D)[du];
                 const float4 g = reinterpret_cast<const float4*>(dp)[du];
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
             qj[j] = (j < rep) ? reinterpret_cast<const float4*>(qv + (int64_t)(mem * rep + j) * H)[hu]
                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll 4
         for (int r = 0; r < R; ++r) {
             const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -208,7 +214,7 @@ extern "C" int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const floa
     VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
     if (B == 0) return VQA_OK;
     const size_t lds = (size_t)(H + R) * sizeof(float);
-    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B * rep), dim3(256), lds, (hipStream_t)stream, v, qv, V, nb, w, bias,
+    hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3(B * rep), dim3(FWD_THREADS), lds, (hipStream_t)stream, v, qv, V, nb, w, bias,
                        keepmask, keepmask ? 1.f / keep_prob : 1.f, att, pooled, R, H, D, rep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;

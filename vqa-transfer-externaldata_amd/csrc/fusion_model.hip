@@ -95,8 +95,8 @@ Layout make_layout(const vqa_dims_t& d) {
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * B), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
-    L.add("colsum_ws", max64(cw, 4));
-    L.add("colsum_ws1", max64(cw, 4));
+    L.add("colsum_ws", max64(3 * cw, 4));    // x3: vqa_colsum3 reduces three partial matrices per launch
+    L.add("colsum_ws1", max64(3 * cw, 4));
     L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
     L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * B * W), 4));
     return L;
@@ -253,9 +253,8 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
                         train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
                         train ? c.part(2) : nullptr, (int)G, rows, (int)N, c.st));
     if (train) {
-        TRY(colsum(c, c.part(0), G, N, (int)N, g->gamma));
-        TRY(colsum(c, c.part(1), G, N, (int)N, g->beta));
-        TRY(colsum(c, c.part(2), G, N, (int)N, g->b));
+        TRY(vqa_colsum3(c.part(0), c.part(1), c.part(2), (int)G, (int)N, (int)N, g->gamma, g->beta, g->b,
+                        c.colsum_ws(), c.colsum_ws_floats(), c.st));
         ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
         TRY(gemm(c, 1, 0, K, N, M, x, (int)K, c.f(d_pre), (int)N, g->w, (int)N));  // dW = x^T * d_pre
     }

@@ -17,7 +17,6 @@
 // ds_read_b128 per 4 MFMAs; an operand whose m/n is contiguous is staged as
 // [k][BR] and read with conflict-free ds_read_b32.  Both sides use the same
 // permutation, so every k is consumed exactly once.
-#include <type_traits>
 
 #include "vqa_common.h"
 
@@ -46,6 +45,7 @@ struct GemmArgs {
     int relu;                       // ReLU after scale / bias / addend
     // implicit-GEMM convolution (A = NHWC activations, row m = output pixel, k = (ky, kx, ci))
     int Hi, Wi, Ci, Ho, Wo, cstride, pad_t, pad_l, kw;
+    int conv_taps;                  // kh * kw
 };
 
 // XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
@@ -192,6 +192,14 @@ struct Stager {
             const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
             reg[i] = bload(rs, in ? (unsigned)((((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq) * 4) : OOB);
         }
+    }
+    // implicit im2col, steady-state form: per-lane pixel base and a bit mask of the filter taps that
+    // fall inside the image are computed once per output tile; a k tile then costs one AND, one
+    // ADD and one select per load (the tap's byte offset and bit are wave-uniform scalars).
+    __device__ __forceinline__ void load_conv_full(__amdgpu_buffer_rsrc_t rs, const unsigned (&cbase)[NV],
+                                                   const unsigned (&cmask)[NV], unsigned tap_off, unsigned tap_bit) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reg[i] = bload(rs, (cmask[i] & tap_bit) ? cbase[i] + tap_off : OOB);
     }
     __device__ __forceinline__ void store(float* s) const {
 #pragma unroll
@@ -345,6 +353,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         }
         __syncthreads();
         int t = 0;
+        if (CONV && p.conv_taps <= 32) {
+            // every k tile of a convolution is full (Ci % BK == 0): same two-per-trip loop as below,
+            // the A tile through the tap-mask loader, the filter matrix through scalar offsets
+            unsigned cbase[NVA], cmask[NVA];
+            const int kh = p.conv_taps / p.kw;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int idx = threadIdx.x + i * 256;
+                const int kq = (idx % (BK / 4)) * 4;
+                cbase[i] = (unsigned)(((int64_t)(pix[i] + iy0[i] * p.Wi + ix0[i]) * p.Ci + kq) * 4);
+                unsigned mk = 0;
+                if (pix[i] >= 0) {
+                    for (int ky = 0; ky < kh; ++ky)
+                        for (int kx = 0; kx < p.kw; ++kx)
+                            if ((unsigned)(iy0[i] + ky) < (unsigned)p.Hi && (unsigned)(ix0[i] + kx) < (unsigned)p.Wi)
+                                mk |= 1u << (ky * p.kw + kx);
+                }
+                cmask[i] = mk;
+            }
+            sb.init_full(p.ldb, n0, kbeg, p.N);
+            const unsigned stepB = (unsigned)(BK * p.ldb) * 4u;
+            unsigned ob = stepB;
+            int c0 = BK, ky = 0, kx = 0, tap = 0;     // position of tile t + 1 inside the (ky, kx, ci) k axis
+            auto advance = [&]() {
+                c0 += BK;
+                if (c0 >= p.Ci) { c0 = 0; ++tap; if (++kx == p.kw) { kx = 0; ++ky; } }
+            };
+            if (c0 >= p.Ci) { c0 = 0; tap = 1; if (++kx == p.kw) { kx = 0; ++ky; } }
+            for (; t + 2 < nt; t += 2) {
+                sa.load_conv_full(rsA, cbase, cmask, (unsigned)(((ky * p.Wi + kx) * p.Ci + c0) * 4), 1u << tap);
+                sb.load_full(rsB, ob);
+                ob += stepB; advance();
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                sa.store(L1);
+                sb.store(L1 + A_FL);
+                __syncthreads();
+                sa.load_conv_full(rsA, cbase, cmask, (unsigned)(((ky * p.Wi + kx) * p.Ci + c0) * 4), 1u << tap);
+                sb.load_full(rsB, ob);
+                ob += stepB; advance();
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L1, L1 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                sa.store(L0);
+                sb.store(L0 + A_FL);
+                __syncthreads();
+            }
+        }
         if (!CONV && !EDGE) {
             // full tiles, two per trip so both LDS buffers are compile-time addresses
             sa.init_full(p.lda, m0, kbeg, p.M);
@@ -816,7 +873,7 @@ GemmArgs make_args(int M, int N, int K, const float* A, int lda, const float* B,
     a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
     a.scale = nullptr; a.relu = 0;
     a.a_bytes = a.b_bytes = 0;   // filled by set_extents() once the layout is known
-    a.Hi = a.Wi = a.Ci = a.Ho = a.Wo = a.cstride = a.pad_t = a.pad_l = a.kw = 0;
+    a.Hi = a.Wi = a.Ci = a.Ho = a.Wo = a.cstride = a.pad_t = a.pad_l = a.kw = a.conv_taps = 0;
     return a;
 }
 
@@ -1005,17 +1062,20 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     a.scale = scale;
     a.relu = relu;
     if (plain) {
-        const int cfg = (Co >= 128) ? 6 : 3;
+        // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M
+        const int cfg = (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) ? g_force_cfg : 3;
         return launch_by_id(cfg, 0, 0, a, 1, st, 0);
     }
     VQA_REQUIRE(Ci % 32 == 0 && vqa_aligned16(x), VQA_ERR_ALIGN);   // one 32-deep k tile per filter tap
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.kw = kw;
+    a.conv_taps = kh * kw;
     const int64_t xb = (int64_t)B * Hi * Wi * Ci * 4, wb = (int64_t)K * Co * 4;
     VQA_REQUIRE(xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll && Co % 4 == 0 && vqa_aligned16(w), VQA_ERR_UNSUPPORTED);
     a.a_bytes = (unsigned)xb;
     a.b_bytes = (unsigned)wb;
     const EpiArgs ep{};
-    if (Co >= 128) return launch_one<64, 128, 32, 64, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
+    // 64x64 tiles also for wide layers: more workgroups per launch beat the 64x128 tile's operand reuse
+    // (ResNet-101 @448, batch 64: 1737 -> 1803 images/s)
     return launch_one<64, 64, 32, 32, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
 }

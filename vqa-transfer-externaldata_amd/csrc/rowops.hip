@@ -163,6 +163,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (ry == 0 && col < N) out[(int64_t)blockIdx.y * N + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
 }
 
+// three equally shaped matrices per launch (blockIdx.z): the (d_gamma, d_beta, d_bias) partials of one
+// LayerNorm block -- these reductions are launch-latency bound, so batching them is the whole gain
+struct Colsum3 { const float* X[3]; float* out[3]; };
+__global__ __launch_bounds__(256) void colsum3_kernel(Colsum3 a, int M, int N, int ldx, int64_t out_stride_rows,
+                                                      int rows_per_chunk) {
+    __shared__ float red[4][64];
+    const float* __restrict__ X = a.X[blockIdx.z];
+    float* __restrict__ out = a.out[blockIdx.z];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+    float s = 0.f;
+    if (col < N)
+        for (int m = m0 + ry; m < m1; m += 4) s += X[(int64_t)m * ldx + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < N)
+        out[(int64_t)blockIdx.y * out_stride_rows + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
 // ------------------------------------------------------------------ dropout keep-mask
 // Counter-based generator (splitmix64 finaliser on seed ^ counter): the mask of
 // element i depends only on (seed, offset + i), so forward, backward and the test
@@ -318,6 +338,31 @@ extern "C" int vqa_colsum(const float* X, int M, int N, int ldx, float* out, flo
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, ch2), dim3(256), 0, st, X, M, N, ldx, workspace, rpc);
     VQA_CHECK_LAUNCH();
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, ch2, N, N, out, ch2);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_colsum3(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0,
+                           float* out1, float* out2, float* workspace, int64_t workspace_floats, void* stream) {
+    VQA_REQUIRE(X0 && X1 && X2 && out0 && out1 && out2 && M >= 0 && N > 0 && ldx >= N, VQA_ERR_ARG);
+    hipStream_t st = (hipStream_t)stream;
+    const int ch = colsum_chunks(std::max(M, 1));
+    const int gx = (N + 63) / 64;
+    Colsum3 a{{X0, X1, X2}, {out0, out1, out2}};
+    if (ch == 1) {
+        hipLaunchKernelGGL(colsum3_kernel, dim3(gx, 1, 3), dim3(256), 0, st, a, M, N, ldx, (int64_t)N, std::max(M, 1));
+        VQA_CHECK_LAUNCH();
+        return VQA_OK;
+    }
+    VQA_REQUIRE(workspace && workspace_floats >= 3 * (int64_t)ch * N, VQA_ERR_WORKSPACE);
+    const int rpc = (int)cdiv(M, ch);
+    const int ch2 = (int)cdiv(M, rpc);
+    const int64_t zs = (int64_t)ch * N;
+    Colsum3 p1{{X0, X1, X2}, {workspace, workspace + zs, workspace + 2 * zs}};
+    hipLaunchKernelGGL(colsum3_kernel, dim3(gx, ch2, 3), dim3(256), 0, st, p1, M, N, ldx, (int64_t)N, rpc);
+    VQA_CHECK_LAUNCH();
+    Colsum3 p2{{workspace, workspace + zs, workspace + 2 * zs}, {out0, out1, out2}};
+    hipLaunchKernelGGL(colsum3_kernel, dim3(gx, 1, 3), dim3(256), 0, st, p2, ch2, N, N, (int64_t)N, ch2);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

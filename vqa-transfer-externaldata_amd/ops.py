@@ -89,6 +89,18 @@ def colsum(X):
     return out
 
 
+def colsum3(X0, X1, X2):
+    """Column sums of three equally shaped matrices in one pair of launches."""
+    lib = _lib.load()
+    M, N = X0.shape
+    assert X1.shape == X0.shape and X2.shape == X0.shape and X0.stride(0) == X1.stride(0) == X2.stride(0)
+    outs = [_f32(N, like=X0) for _ in range(3)]
+    ws = _f32(max(3 * int(lib.vqa_colsum_workspace_floats(M, N)), 4), like=X0)
+    _lib.check(lib.vqa_colsum3(_p(X0), _p(X1), _p(X2), M, N, X0.stride(0), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                               _p(ws), ws.numel(), _st(X0)), "vqa_colsum3")
+    return outs
+
+
 def ln_relu_bwd(dy, pre, mean, rstd, gamma, beta, rows=1, keepmask=None, keep_prob=1.0, want_params=True):
     lib = _lib.load()
     M, N = pre.shape
