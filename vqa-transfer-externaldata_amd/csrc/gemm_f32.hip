@@ -46,6 +46,7 @@ struct GemmArgs {
     // implicit-GEMM convolution (A = NHWC activations, row m = output pixel, k = (ky, kx, ci))
     int Hi, Wi, Ci, Ho, Wo, cstride, pad_t, pad_l, kw;
     int conv_taps;                  // kh * kw
+    int vec_epi;                    // plain epilogue may use 16-byte accesses
 };
 
 // XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
@@ -564,6 +565,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         // accumulate), so interleaving them would serialise 16 round trips.
         float* Cz = p.C + (int64_t)bz * p.slab_stride;
         const bool first = (bz == 0);
+        if (p.vec_epi) {
+            // 16-byte form (N, the leading dimensions and the pointers allow it): the accumulator
+            // tile goes through the wave's own 32 x 36 LDS patch (the operand tiles are dead after
+            // the loop's last barrier) so that every lane owns 4 consecutive columns of a row --
+            // addend loads and stores are line-contiguous float4 instead of 16 dword accesses with
+            // their address arithmetic; short-k GEMMs (1x1 convolutions) live in this epilogue.
+            constexpr int SLD = 36;
+            constexpr int RED0 = (WGK - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64;
+            float* stg = smem + RED0 + (wm * WAVES_N + wn) * 32 * SLD;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SLD + (lane & 31)] = acc[a][b][r];
+                    const int c4 = (lane & 7) * 4;
+                    const int gcol = n0 + wn * WN + b * 32 + c4;
+                    const int grow0 = m0 + wm * WM + a * 32 + (lane >> 3);
+                    if (gcol < p.N) {
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (p.bias != nullptr && first) bv = *reinterpret_cast<const float4*>(p.bias + gcol);
+                        if (p.scale != nullptr) sv = *reinterpret_cast<const float4*>(p.scale + gcol);
+                        float4 dv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int grow = grow0 + 8 * i;
+                            dv[i] = (p.D != nullptr && first && grow < p.M)
+                                        ? *reinterpret_cast<const float4*>(p.D + (int64_t)grow * p.ldd + gcol)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int grow = grow0 + 8 * i;
+                            const float4 v = *reinterpret_cast<const float4*>(stg + ((lane >> 3) + 8 * i) * SLD + c4);
+                            float4 o = make_float4(v.x * sv.x + bv.x + dv[i].x, v.y * sv.y + bv.y + dv[i].y,
+                                                   v.z * sv.z + bv.z + dv[i].z, v.w * sv.w + bv.w + dv[i].w);
+                            if (p.relu) {
+                                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                            }
+                            if (grow < p.M) *reinterpret_cast<float4*>(Cz + (int64_t)grow * p.ldc + gcol) = o;
+                        }
+                    }
+                }
+            if (lin + (int)gridDim.x < total) __syncthreads();   // persistent walk: the patches overlap the next tile's operands
+            continue;
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -714,7 +762,7 @@ template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, 
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
     constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
-    constexpr size_t stage = (EPI == EPI_PLAIN) ? 0 : (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
+    constexpr size_t stage = (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);   // epilogue transpose patches
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE>;
     static bool attr_done = false;
@@ -742,6 +790,9 @@ int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max
         const double m_fast = foot(a.tiles_m, a.tiles_n, BM, BN);
         a.m_fastest = (g_force_order >= 0) ? g_force_order : (m_fast < n_fast ? 1 : 0);
     }
+    a.vec_epi = (a.N % 4 == 0) && (a.ldc % 4 == 0) && vqa_aligned16(a.C) && (a.slab_stride % 4 == 0) &&
+                (a.D == nullptr || (a.ldd % 4 == 0 && vqa_aligned16(a.D))) &&
+                (a.bias == nullptr || vqa_aligned16(a.bias)) && (a.scale == nullptr || vqa_aligned16(a.scale));
     int blocks = a.tiles_m * a.tiles_n * split;
     if (max_blocks > 0 && WGK == 1 && EPI == EPI_PLAIN && blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ep);
