@@ -55,6 +55,34 @@ def test_gemm_matches_f64(M, N, K, layout):
     close(got, want, rtol=1e-5, atol=2e-6 * scale * 4, msg=layout)
 
 
+@pytest.mark.parametrize("cfg", list(range(16)))
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_gemm_every_tile_config(cfg, layout):
+    """Each tile configuration forced on one shape that is ragged in M (rows past M are clamped in the
+    steady-state loader), has a partial last k tile (masked loader) and needs several full tiles first."""
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    M, N, K = 200, 264, 1000
+    rng = np.random.default_rng(cfg * 3 + len(layout))
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    D = rng.standard_normal((M, N)).astype(np.float32)
+    want = A.astype(np.float64) @ B.astype(np.float64) + bias + D
+    try:
+        assert lib.vqa_gemm_set_config(cfg) == 0
+        if layout == "nn":
+            got = ops.gemm(dev(A), dev(B), bias=dev(bias), addend=dev(D), split_k=1)
+        elif layout == "nt":
+            got = ops.gemm(dev(A), dev(B.T), transB=True, bias=dev(bias), addend=dev(D), split_k=1)
+        else:
+            got = ops.gemm(dev(A.T), dev(B), transA=True, bias=dev(bias), addend=dev(D), split_k=1)
+        got = got.cpu().numpy()
+    finally:
+        lib.vqa_gemm_set_config(-1)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=3e-4, err_msg="cfg %d %s" % (cfg, layout))
+
+
 def test_gemm_identity_asymmetric_and_inplace_addend():
     # A = I with an asymmetric B catches a transposed C write; addend aliasing C (GRU in-place form)
     n = 96
