@@ -28,7 +28,6 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ exist_m, int use_train_mask,
                                                        float inv_batch, float* __restrict__ stats,
                                                        int32_t* __restrict__ pred, float* __restrict__ dz, int A) {
-    __shared__ float red[16];
     __shared__ float redv[4];
     __shared__ int redi[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -66,27 +65,29 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
         ArgMax other{__shfl_xor(am.v, o, 64), __shfl_xor(am.i, o, 64)};
         am = argmax_combine(am, other);
     }
-    if (lane == 0) { redv[wave] = am.v; redi[wave] = am.i; }
-    l_all = block_sum(l_all, red);       // (contains __syncthreads: redv/redi visible after it)
-    l_train = block_sum(l_train, red);
+    // every block-wide reduction of the row behind ONE barrier: per-wave partials to LDS, then each
+    // thread combines the four waves (fixed order, so the sums are deterministic)
+    __shared__ float part[4][9];
+    {
+        const float v[9] = {wave_sum(l_all), wave_sum(l_train), wave_max(mx_exist), wave_max(mx_train_exist),
+                            wave_max(mx_tobj), wave_max(mx_tattr), wave_max(mx_test), wave_max(mx_test_exist),
+                            wave_max(mx_train)};
+        if (lane == 0) {
+            redv[wave] = am.v; redi[wave] = am.i;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) part[wave][k] = v[k];
+        }
+    }
+    __syncthreads();
+    l_all = ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0];
+    l_train = ((part[0][1] + part[1][1]) + part[2][1]) + part[3][1];
+    auto bmax = [&](int k) { return fmaxf(fmaxf(part[0][k], part[1][k]), fmaxf(part[2][k], part[3][k])); };
+    mx_exist = bmax(2); mx_train_exist = bmax(3); mx_tobj = bmax(4); mx_tattr = bmax(5);
+    mx_test = bmax(6); mx_test_exist = bmax(7); mx_train = bmax(8);
     ArgMax best{redv[0], redi[0]};
     for (int k = 1; k < 4; ++k) best = argmax_combine(best, ArgMax{redv[k], redi[k]});
     int p = best.i;
     if (p < 0 || p >= A) p = 0;  // all-NaN row: tf.argmax returns 0
-    auto bmax = [&](float x) {
-        x = wave_max(x);
-        __syncthreads();
-        if (lane == 0) red[wave] = x;
-        __syncthreads();
-        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    };
-    mx_exist = bmax(mx_exist);
-    mx_train_exist = bmax(mx_train_exist);
-    mx_tobj = bmax(mx_tobj);
-    mx_tattr = bmax(mx_tattr);
-    mx_test = bmax(mx_test);
-    mx_test_exist = bmax(mx_test_exist);
-    mx_train = bmax(mx_train);
     if (threadIdx.x == 0) {
         const float tp = tb[p];
         const float tr = train_m[p], te = 1.f - tr, ob = obj_m[p], at = attr_m[p], ex = exist_m[p];
@@ -112,15 +113,17 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
 }
 
 // report[13]: means over the batch + guarded ratios  where(den == 0, den, num/den)
-__global__ __launch_bounds__(256) void report_reduce_kernel(const float* __restrict__ stats, int B,
-                                                            float* __restrict__ report) {
-    __shared__ float red[16];
+__global__ __launch_bounds__(1024) void report_reduce_kernel(const float* __restrict__ stats, int B,
+                                                             float* __restrict__ report) {
+    // one wave per statistic (16 waves >= VQA_STAT_COUNT): fixed summation order, no block-wide reductions
+    static_assert(VQA_STAT_COUNT <= 16, "one wave per statistic");
     __shared__ float mean[VQA_STAT_COUNT];
-    for (int k = 0; k < VQA_STAT_COUNT; ++k) {
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    if (k < VQA_STAT_COUNT) {
         float s = 0.f;
-        for (int b = threadIdx.x; b < B; b += 256) s += stats[(int64_t)b * VQA_STAT_COUNT + k];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) mean[k] = s / (float)B;
+        for (int b = lane; b < B; b += 64) s += stats[(int64_t)b * VQA_STAT_COUNT + k];
+        s = wave_sum(s);
+        if (lane == 0) mean[k] = s / (float)B;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -296,7 +299,7 @@ extern "C" int vqa_softmax_ce_fwd(const float* z, const int32_t* label, const fl
 
 extern "C" int vqa_report_reduce(const float* stats, int B, float* report, void* stream) {
     VQA_REQUIRE(stats && report && B > 0, VQA_ERR_ARG);
-    hipLaunchKernelGGL(report_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, B, report);
+    hipLaunchKernelGGL(report_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, B, report);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
