@@ -154,7 +154,7 @@ def test_full_size_properties_bs512():
     assert abs(float(dE.double().sum()) - float(dx.double().sum())) <= 1e-6 * float(dx.double().abs().sum()) + 1e-9
 
 
-@pytest.mark.parametrize("gru_cfg", [4, 7, 8, 9, 10, 11, 13, 16])
+@pytest.mark.parametrize("gru_cfg", [4, 7, 8, 9, 10, 11, 13, 16, 17])
 def test_fused_gru_tile_configs_match_oracle(gru_cfg):
     """Every tile configuration of the fused GRU-step GEMMs (in-block split-k 1/2/4) gives the oracle's
     final state and GRU gradients."""
@@ -167,7 +167,7 @@ def test_fused_gru_tile_configs_match_oracle(gru_cfg):
         eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
         run_engine(eng, batch, masks)
     finally:
-        lib.vqa_gemm_set_gru_config(16)       # the library default
+        lib.vqa_gemm_set_gru_config(-1)       # back to the library defaults
     loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
                                              to64(masks))
     grads, dx = O.backward(to64(p), to64(batch), to64(am), to64(masks), tape)

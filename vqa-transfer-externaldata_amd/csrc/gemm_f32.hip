@@ -93,11 +93,11 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int n_ok, bool vec) 
 }
 
 // Stage one BR x 16 (k-contiguous, KC) or 16 x BR (row-contiguous, RC) operand tile.
-template <int BR, int BK, bool KC>
+template <int BR, int BK, bool KC, int NT = 256>
 struct Stager {
     static constexpr int KC_LD = BK + 4;
     static constexpr int KQ = BK / 4;                      // float4 per k-contiguous row
-    static constexpr int NV = (BR * BK / 4 + 255) / 256;  // float4 per thread
+    static constexpr int NV = (BR * BK / 4 + NT - 1) / NT;  // float4 per thread
     float4 reg[NV];
 
     // g: operand base; ld: leading dim; r0: first row (m or n) of the tile; k0: first k;
@@ -105,7 +105,7 @@ struct Stager {
     __device__ __forceinline__ void load(const float* g, int ld, int r0, int k0, int RLIM, int KLIM, bool vec) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             if (KC) {
                 const int row = idx / KQ, kq = (idx % KQ) * 4;
                 const int gr = r0 + row, gk = k0 + kq;
@@ -134,7 +134,7 @@ struct Stager {
     __device__ __forceinline__ void load_fast(__amdgpu_buffer_rsrc_t rs, int ld, int r0, int k0, int RLIM, int KLIM) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             if (KC) {
                 const int row = idx / KQ, kq = (idx % KQ) * 4;
                 const int gr = r0 + row, gk = k0 + kq;
@@ -154,12 +154,12 @@ struct Stager {
     // stored) and the k advance rides in the buffer load's SCALAR offset, so a tile's loads cost no
     // vector ALU work at all; what VALU the loop keeps competes with the MFMAs for the issue port.
     static constexpr int COUNT = BR * BK / 4;
-    static constexpr bool EXACT = (NV * 256 == COUNT);
+    static constexpr bool EXACT = (NV * NT == COUNT);
     unsigned voff[NV];
     __device__ __forceinline__ void init_full(int ld, int r0, int kbeg, int RLIM) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = EXACT ? (int)threadIdx.x + i * 256 : min((int)threadIdx.x + i * 256, COUNT - 1);
+            const int idx = EXACT ? (int)threadIdx.x + i * NT : min((int)threadIdx.x + i * NT, COUNT - 1);
             if (KC) {
                 const int row = idx / KQ, kq = (idx % KQ) * 4;
                 const int gr = min(r0 + row, RLIM - 1);
@@ -187,7 +187,7 @@ struct Stager {
         const int ky = tap / kw, kx = tap - ky * kw;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             const int kq = (idx % KQ) * 4;
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
@@ -205,7 +205,7 @@ struct Stager {
     __device__ __forceinline__ void store(float* s) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * 256;
+            const int idx = threadIdx.x + i * NT;
             if (KC) {
                 if (EXACT || idx < BR * KQ) {
                     const int row = idx / KQ, kq = (idx % KQ) * 4;
@@ -238,11 +238,11 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
 }
 
 template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
-          bool EDGE = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
+          bool EDGE = false, int NT = 256>
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
-    static_assert(WAVES_M * WAVES_N * WGK == 4, "4 waves per block");
+    static_assert(WAVES_M * WAVES_N * WGK * 64 == NT, "one 32x32-tiled wave per (m, n, k-group) slot");
     static_assert((BK / 8) % WGK == 0, "k chunks split evenly over the k wave groups");
     constexpr int A_FL = tile_floats<BM, BK, A_KC>();
     constexpr int B_FL = tile_floats<BN, BK, B_KC>();
@@ -317,14 +317,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
 
     if (DEEP == 0) {
         // one tile of register prefetch: enough when >= 2-3 workgroups share a CU
-        Stager<BM, BK, A_KC> sa;
-        Stager<BN, BK, B_KC> sb;
-        constexpr int NVA = Stager<BM, BK, A_KC>::NV;
+        Stager<BM, BK, A_KC, NT> sa;
+        Stager<BN, BK, B_KC, NT> sb;
+        constexpr int NVA = Stager<BM, BK, A_KC, NT>::NV;
         int iy0[NVA], ix0[NVA], pix[NVA];
         if (CONV) {
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
-                const int idx = threadIdx.x + i * 256;
+                const int idx = threadIdx.x + i * NT;
                 const int m = m0 + idx / (BK / 4);
                 pix[i] = -1; iy0[i] = ix0[i] = 0;
                 if (idx < BM * (BK / 4) && m < p.M) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             const int kh = p.conv_taps / p.kw;
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
-                const int idx = threadIdx.x + i * 256;
+                const int idx = threadIdx.x + i * NT;
                 const int kq = (idx % (BK / 4)) * 4;
                 cbase[i] = (unsigned)(((int64_t)(pix[i] + iy0[i] * p.Wi + ix0[i]) * p.Ci + kq) * 4);
                 unsigned mk = 0;
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         // two tiles of register prefetch (two stager sets, loop unrolled by 2 so every register
         // index is static): with one workgroup per CU a tile's MFMA time (~0.5 us) is shorter than
         // the global-load latency, so the loads need two phases of cover.
-        Stager<BM, BK, A_KC> sa0, sa1;
-        Stager<BN, BK, B_KC> sb0, sb1;
+        Stager<BM, BK, A_KC, NT> sa0, sa1;
+        Stager<BN, BK, B_KC, NT> sb0, sb1;
         auto ld0 = [&](int tile) {
             sa0.load_fast(rsA, p.lda, m0, kbeg + tile * BK, p.M, kend);
             sb0.load_fast(rsB, p.ldb, n0, kbeg + tile * BK, p.N, kend);
@@ -758,13 +758,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
-          bool EDGE = false>
+          bool EDGE = false, int NT = 256>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
     constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
     constexpr size_t stage = (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);   // epilogue transpose patches
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE, NT>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {   // MI355X has 160 KiB of LDS per CU; > 64 KiB needs the opt-in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -795,26 +795,26 @@ int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max
                 (a.bias == nullptr || vqa_aligned16(a.bias)) && (a.scale == nullptr || vqa_aligned16(a.scale));
     int blocks = a.tiles_m * a.tiles_n * split;
     if (max_blocks > 0 && WGK == 1 && EPI == EPI_PLAIN && blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a, ep);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, st, a, ep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP>
+template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, int NT = 256>
 int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int mb) {
     const EpiArgs ep{};
     if (tA == 0 && tB == 0)
-        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, false, EPI_PLAIN>(a, ep, split, st, mb);
+        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, false, EPI_PLAIN, false, false, NT>(a, ep, split, st, mb);
     if (tA == 0 && tB == 1)
-        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, true, EPI_PLAIN>(a, ep, split, st, mb);
-    return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, false, false, EPI_PLAIN>(a, ep, split, st, mb);
+        return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, true, true, EPI_PLAIN, false, false, NT>(a, ep, split, st, mb);
+    return launch_one<BM, BN, WM, WN, WGK, BK, DEEP, false, false, EPI_PLAIN, false, false, NT>(a, ep, split, st, mb);
 }
 
 struct TileCfg { int BM, BN; };
-constexpr int NUM_CFG = 16;
+constexpr int NUM_CFG = 20;
 const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 128}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 128},
                                {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}, {128, 32},
-                               {128, 64}};
+                               {128, 64}, {128, 128}, {128, 128}, {256, 64}, {128, 128}};
 
 // operands that allow the buffer-load fast path (see Stager::load_fast); fills the descriptor extents
 bool fast_ok(int tA, int tB, GemmArgs& a) {
@@ -858,6 +858,10 @@ int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a_in, int split, hipSt
         case 13: return launch_cfg<64, 32, 32, 32, 2, 32, true>(tA, tB, a, split, st, mb);
         case 14: return launch_cfg<128, 32, 32, 32, 1, 64, true>(tA, tB, a, split, st, mb);
         case 15: return launch_cfg<128, 64, 32, 64, 1, 32, true>(tA, tB, a, split, st, mb);
+        case 16: return launch_cfg<128, 128, 64, 32, 1, 32, 0, 512>(tA, tB, a, split, st, mb);
+        case 17: return launch_cfg<128, 128, 32, 64, 1, 32, 0, 512>(tA, tB, a, split, st, mb);
+        case 18: return launch_cfg<256, 64, 64, 32, 1, 32, 0, 512>(tA, tB, a, split, st, mb);
+        case 19: return launch_cfg<128, 128, 64, 32, 1, 16, 0, 512>(tA, tB, a, split, st, mb);
         default: return VQA_ERR_ARG;
     }
 }
@@ -877,6 +881,7 @@ int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st)
         case 11: return launch_one<64, 32, 32, 32, 2, 64, true, true, BKC, EPI>(a, ep, 1, st);
         case 13: return launch_one<64, 32, 32, 32, 2, 32, true, true, BKC, EPI>(a, ep, 1, st);
         case 16: return launch_one<32, 32, 32, 32, 4, 32, true, true, BKC, EPI>(a, ep, 1, st);
+        case 17: return launch_one<64, 32, 32, 32, 4, 32, 1, true, BKC, EPI, false, false, 512>(a, ep, 1, st);
         default: return VQA_ERR_ARG;
     }
 }
@@ -885,21 +890,26 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
-// tile config of the fused GRU-step GEMMs (vqa_gemm_set_gru_config): 32x32 tiles, 4-way in-block split-k, two
-// tiles of register prefetch -- 1024 / 512 workgroups per step kernel hide latency better than 64x32 tiles
-// (recurrence 622 -> 591 us forward, 607 -> 549 us backward at B 512, H 1024, T 14)
-int g_gru_cfg = 16;
+// Tile config of the fused GRU-step GEMMs.  Small tiles with in-block split-k and two tiles of register
+// prefetch: 1024 / 512 workgroup-slots of waves per step kernel hide latency better than 64x32 x 4 waves
+// (recurrence at B 512, H 1024, T 14: 622 -> 585 us forward, 607 -> 529 us backward).  Forward: 64x32
+// tiles, 8 waves (4 k groups); backward: 32x32 tiles, 4 waves (4 k groups).
+// vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
+int g_gru_cfg = -1;
+inline int gru_cfg_fwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 17; }
+inline int gru_cfg_bwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 16; }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
-//  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, and
-//    enough split-k slabs for >= 512 workgroups (dWv 575 us = 134 TFLOP/s);
+//  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, EIGHT waves
+//    (64x32 per wave) and enough split-k slabs for >= 512 workgroups (dWv 554 us = 140 TFLOP/s; the
+//    4-wave form of the same tile: 600 us on the same box);
 //  * tall activations (M >= 2048): 128x64 tiles (v_linear_v forward 567 us = 136 TFLOP/s), 64x64
 //    when K is short;
 //  * batch-sized M (512) or narrow N: 64x32 tiles with in-block split-k and two tiles of register
 //    prefetch (one workgroup per CU cannot hide a global load behind a single tile's MFMAs).
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
-    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 0 : 3; target = 512; }
+    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
     else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? 5 : 3) : 13; target = 256; }
     else { cfg = tB ? 11 : 13; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
@@ -943,8 +953,8 @@ extern "C" int vqa_gemm_set_config(int cfg) {
 }
 
 extern "C" int vqa_gemm_set_gru_config(int cfg) {
-    VQA_REQUIRE(cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || cfg == 16, VQA_ERR_ARG);
-    g_gru_cfg = cfg;
+    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || cfg == 16 || cfg == 17, VQA_ERR_ARG);
+    g_gru_cfg = cfg;   // -1 restores the defaults
     return VQA_OK;
 }
 
@@ -1026,13 +1036,13 @@ extern "C" int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* W
         EpiArgs eg{};
         eg.H = H; eg.h_prev = hp; eg.o0 = r + t * BH + o; eg.o1 = u + t * BH + o; eg.o2 = rh + t * BH + o;
         GemmArgs ag = make_args(rows, 2 * H, H, hp, H, Wg_h, 2 * H, nullptr, 0, nullptr, xpt, 3 * H);
-        int rc = launch_gru<EPI_GATES>(g_gru_cfg, ag, eg, st);
+        int rc = launch_gru<EPI_GATES>(gru_cfg_fwd(), ag, eg, st);
         if (rc != VQA_OK) return rc;
         EpiArgs ec{};
         ec.H = H; ec.t = t; ec.len = len + row0; ec.h_prev = hp; ec.i0 = u + t * BH + o; ec.o0 = c + t * BH + o;
         ec.o1 = hs + (t + 1) * BH + o;
         GemmArgs ac = make_args(rows, H, H, rh + t * BH + o, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
-        rc = launch_gru<EPI_CAND>(g_gru_cfg, ac, ec, st);
+        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(), ac, ec, st);
         if (rc != VQA_OK) return rc;
     }
     return VQA_OK;
@@ -1076,7 +1086,7 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
         EpiArgs e1{};
         e1.H = H; e1.ldo = ld; e1.h_prev = hs + t * BH + o; e1.i0 = r + t * BH + o; e1.o0 = dxpt; e1.o1 = dh_acc;
         GemmArgs a1 = make_args(rows, H, H, dxpt + 2 * H, ld, Wc_h, H, nullptr, 0, nullptr, nullptr, 0);
-        int rc = launch_gru<EPI_BWD_RH>(g_gru_cfg, a1, e1, st);
+        int rc = launch_gru<EPI_BWD_RH>(gru_cfg_bwd(), a1, e1, st);
         if (rc != VQA_OK) return rc;
         // dh_{t-1} = (dr_pre|du_pre) * Wg_h^T + dh_acc ; epilogue: first half of step t-1
         if (t > 0) {
@@ -1087,7 +1097,7 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
             e2.i0 = u + (t - 1) * BH + o; e2.i1 = c + (t - 1) * BH + o; e2.o0 = dxpp + 2 * H; e2.o1 = dxpp + H;
             e2.o2 = dh_next;
             GemmArgs a2 = make_args(rows, H, 2 * H, dxpt, ld, Wg_h, 2 * H, nullptr, 0, nullptr, dh_acc, H);
-            rc = launch_gru<EPI_BWD_DH>(g_gru_cfg, a2, e2, st);
+            rc = launch_gru<EPI_BWD_DH>(gru_cfg_bwd(), a2, e2, st);
             if (rc != VQA_OK) return rc;
             dh_acc = dh_next;
         }
