@@ -45,6 +45,11 @@ def bench(fn, iters=20):
 
 def main():
     lib = _lib.load()
+    # bring the device to its loaded clock first: the first measurements of a cold process read 10-15 % slow
+    wa = torch.randn(8192, 4096, device="cuda"); wb = torch.randn(4096, 4096, device="cuda")
+    for _ in range(300):
+        ops.gemm(wa, wb)
+    torch.cuda.synchronize()
     splits = [0, 1, 2, 4, 8] if "--split" in sys.argv else [0]
     if "--persist-only" in sys.argv:
         splits = []
@@ -60,7 +65,7 @@ def main():
             for cfg in CFGS:
                 lib.vqa_gemm_set_config(cfg)
                 f = lambda: ops.gemm(A, B, transA=(lay == "tn"), transB=(lay == "nt"), split_k=sk, out=out)
-                us = bench(f)
+                us = min(bench(f), bench(f))
                 cells.append("%7.1f/%5.1f" % (us, 2.0 * M * N * K / us / 1e6))
             print("%-14s %-3s %6d %5d %6d sk%d | " % (name, lay, M, N, K, sk) + " ".join(cells))
     lib.vqa_gemm_set_config(-1)
