@@ -154,7 +154,7 @@ def test_full_size_properties_bs512():
     assert abs(float(dE.double().sum()) - float(dx.double().sum())) <= 1e-6 * float(dx.double().abs().sum()) + 1e-9
 
 
-@pytest.mark.parametrize("gru_cfg", [4, 7, 8, 9, 10, 11, 13, 16, 17])
+@pytest.mark.parametrize("gru_cfg", [4, 7, 8, 9, 10, 11, 13, 16, 17, 18])
 def test_fused_gru_tile_configs_match_oracle(gru_cfg):
     """Every tile configuration of the fused GRU-step GEMMs (in-block split-k 1/2/4) gives the oracle's
     final state and GRU gradients."""

@@ -885,6 +885,9 @@ int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st)
         case 13: return launch_one<64, 32, 32, 32, 2, 32, true, true, BKC, EPI>(a, ep, 1, st);
         case 16: return launch_one<32, 32, 32, 32, 4, 32, true, true, BKC, EPI>(a, ep, 1, st);
         case 17: return launch_one<64, 32, 32, 32, 4, 32, 1, true, BKC, EPI, false, false, 512>(a, ep, 1, st);
+        case 18:   // one 16-wave workgroup per CU: 64x64 tiles for the 2H-wide gate GEMM, 64x32 for the H-wide ones
+            if (EPI == EPI_GATES) return launch_one<64, 64, 32, 32, 4, 64, 1, true, BKC, EPI, false, false, 1024>(a, ep, 1, st);
+            return launch_one<64, 32, 32, 32, 8, 64, 1, true, BKC, EPI, false, false, 1024>(a, ep, 1, st);
         default: return VQA_ERR_ARG;
     }
 }
@@ -893,13 +896,13 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
-// Tile config of the fused GRU-step GEMMs.  Small tiles with in-block split-k and two tiles of register
-// prefetch: 1024 / 512 workgroup-slots of waves per step kernel hide latency better than 64x32 x 4 waves
-// (recurrence at B 512, H 1024, T 14: 622 -> 585 us forward, 607 -> 529 us backward).  Forward: 64x32
-// tiles, 8 waves (4 k groups); backward: 32x32 tiles, 4 waves (4 k groups).
+// Tile config of the fused GRU-step GEMMs: many waves with small per-wave tiles (32x32), in-block split-k and two
+// tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU
+// (recurrence at B 512, H 1024, T 14: 622 -> 560 us forward, 607 -> 528 us backward).  Forward: one 16-wave
+// workgroup per CU (cfg 18); backward: 32x32 tiles, 4 waves, 4 k groups (cfg 16).
 // vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
 int g_gru_cfg = -1;
-inline int gru_cfg_fwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 17; }
+inline int gru_cfg_fwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 18; }
 inline int gru_cfg_bwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 16; }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
@@ -956,7 +959,7 @@ extern "C" int vqa_gemm_set_config(int cfg) {
 }
 
 extern "C" int vqa_gemm_set_gru_config(int cfg) {
-    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || cfg == 16 || cfg == 17, VQA_ERR_ARG);
+    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || (cfg >= 16 && cfg <= 18), VQA_ERR_ARG);
     g_gru_cfg = cfg;   // -1 restores the defaults
     return VQA_OK;
 }
