@@ -312,6 +312,42 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // Fused epilogues: the side inputs (x-projection addend, previous state, gates ...) do not depend on
+    // this kernel's accumulators, so the k-group-0 waves fetch them BEFORE the k loop; their HBM
+    // latency (~2 us for the [T,B,3H] x-projection, written long before) hides under the loop
+    // instead of sitting between the last MFMA and the first store.
+    static_assert(EPI == EPI_PLAIN || (TM == 1 && TN == 1), "fused epilogues: one 32x32 tile per wave");
+    float4 e_d[4], e_x0[4], e_x1[4], e_x2[4];
+    int e_lim[4];
+    if (EPI != EPI_PLAIN && wk == 0) {
+        const int gcol = n0 + wn * WN + (lane & 7) * 4;
+        const int grow0 = m0 + wm * WM + (lane >> 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int grow = grow0 + 8 * i;
+            e_d[i] = e_x0[i] = e_x1[i] = e_x2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            e_lim[i] = 0;
+            if (!((grow < p.M) && (gcol < p.N))) continue;
+            if (p.D != nullptr) e_d[i] = *reinterpret_cast<const float4*>(p.D + (int64_t)grow * p.ldd + gcol);
+            const int64_t o = (int64_t)grow * ep.H + gcol;
+            if (EPI == EPI_GATES) {
+                if (gcol < ep.H) e_x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+            } else if (EPI == EPI_CAND) {
+                e_x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                e_x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                e_lim[i] = ep.len[grow];
+            } else if (EPI == EPI_BWD_RH) {
+                e_x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                e_x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                e_x2[i] = *reinterpret_cast<const float4*>(ep.o1 + o);
+            } else {
+                e_x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
+                e_x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
+                e_x2[i] = *reinterpret_cast<const float4*>(ep.i1 + o);
+                e_lim[i] = ep.len[grow];
+            }
+        }
+    }
     float* L0 = smem;
     float* L1 = smem + (A_FL + B_FL);
 
@@ -657,35 +693,18 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             const int c4 = (lane & 7) * 4;
             const int gcol = n0 + wn * WN + b * 32 + c4;
             const int grow0 = m0 + wm * WM + a * 32 + (lane >> 3);
-            float4 v[4], d[4], x0[4], x1[4], x2[4];
-            int lim[4];
+            float4 v[4];
             bool ok[4];
+            const float4 (&d)[4] = e_d;
+            const float4 (&x0)[4] = e_x0;
+            const float4 (&x1)[4] = e_x1;
+            const float4 (&x2)[4] = e_x2;
+            const int (&lim)[4] = e_lim;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int grow = grow0 + 8 * i;
                 ok[i] = (grow < p.M) && (gcol < p.N);
                 v[i] = *reinterpret_cast<const float4*>(stg + ((lane >> 3) + 8 * i) * STG_LD + c4);
-                d[i] = x0[i] = x1[i] = x2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                lim[i] = 0;
-                if (!ok[i]) continue;
-                if (p.D != nullptr) d[i] = *reinterpret_cast<const float4*>(p.D + (int64_t)grow * p.ldd + gcol);
-                const int64_t o = (int64_t)grow * H + gcol;
-                if (EPI == EPI_GATES) {
-                    if (gcol < H) x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
-                } else if (EPI == EPI_CAND) {
-                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
-                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
-                    lim[i] = ep.len[grow];
-                } else if (EPI == EPI_BWD_RH) {
-                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
-                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
-                    x2[i] = *reinterpret_cast<const float4*>(ep.o1 + o);
-                } else {
-                    x0[i] = *reinterpret_cast<const float4*>(ep.h_prev + o);
-                    x1[i] = *reinterpret_cast<const float4*>(ep.i0 + o);
-                    x2[i] = *reinterpret_cast<const float4*>(ep.i1 + o);
-                    lim[i] = ep.len[grow];
-                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
