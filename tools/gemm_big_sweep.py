@@ -15,7 +15,7 @@ M, N = 18432, 1024
 for K in (512, 1024, 2048, 4096, 8192):
     A = torch.randn(M, K, device="cuda"); B = torch.randn(K, N, device="cuda"); out = torch.empty(M, N, device="cuda")
     row = []
-    for cfg in (5, 20, 23):
+    for cfg in (5, 20, 21, 22):
         lib.vqa_gemm_set_config(cfg)
         us = bench(lambda: ops.gemm(A, B, out=out, split_k=1))
         row.append("cfg%d %.0fus %.1fTF" % (cfg, us, 2.0 * M * N * K / us / 1e6))
@@ -25,9 +25,9 @@ for K in (512, 1024, 2048, 4096, 8192):
 # dW shape (TN): K = B*R
 Kd, Md, Nd = 18432, 2048, 1024
 A = torch.randn(Kd, Md, device="cuda"); B = torch.randn(Kd, Nd, device="cuda"); out = torch.empty(Md, Nd, device="cuda")
-for cfg in (19, 20, 21, 22, 23):
+for cfg in (0, 19, 20, 21):
     lib.vqa_gemm_set_config(cfg)
-    for sk in (0, 2, 4, 8):
+    for sk in (0, 4, 8):
         try:
             us = bench(lambda: ops.gemm(A, B, transA=True, out=out, split_k=sk))
             print("TN cfg%d split%d %.0fus %.1fTF" % (cfg, sk, us, 2.0 * Md * Nd * Kd / us / 1e6), flush=True)
