@@ -75,7 +75,7 @@ int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, const float* A,
 int vqa_gemm_set_max_blocks(int n);
 int vqa_gemm_set_order(int order);   /* tuning: 0 n-fastest, 1 m-fastest, -1 automatic */
 int64_t vqa_gemm_workspace_floats(int transA, int transB, int M, int N, int K, int split_k);
-/* tuning hooks: force tile configuration `cfg` (0..22) for every later GEMM, -1 = automatic;
+/* tuning hooks: force tile configuration `cfg` (0..23) for every later GEMM, -1 = automatic;
  * tile configuration (4, 7..11, 13, 16..18) of the fused GRU-step GEMMs, -1 = defaults */
 int vqa_gemm_set_config(int cfg);
 int vqa_gemm_set_gru_config(int cfg);

@@ -55,7 +55,7 @@ def test_gemm_matches_f64(M, N, K, layout):
     close(got, want, rtol=1e-5, atol=2e-6 * scale * 4, msg=layout)
 
 
-@pytest.mark.parametrize("cfg", list(range(23)))
+@pytest.mark.parametrize("cfg", list(range(24)))
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_gemm_every_tile_config(cfg, layout):
     """Each tile configuration forced on one shape that is ragged in M (rows past M are clamped in the

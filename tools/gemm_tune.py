@@ -16,6 +16,12 @@ SHAPES = [
     ("gru_gates_fwd", "nn", 512, 2048, 1024),
     ("gru_cand_fwd", "nn", 512, 1024, 1024),
     ("head_fwd", "nn", 512, 3000, 2048),
+    ("fc_1024", "nn", 512, 1024, 1024),
+    ("fc_2048_1024", "nn", 512, 1024, 2048),
+    ("fc_1024_2048", "nn", 512, 2048, 1024),
+    ("fc_bwd_dx", "nt", 512, 1024, 1024),
+    ("fc_dw", "tn", 1024, 1024, 512),
+    ("fc_dw2", "tn", 2048, 3000, 512),
     ("gru_bwd_dh", "nt", 512, 1024, 2048),
     ("gru_bwd_drh", "nt", 512, 1024, 1024),
     ("dj", "nt", 512, 2048, 3000),

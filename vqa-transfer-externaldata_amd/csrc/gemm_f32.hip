@@ -830,10 +830,10 @@ int launch_cfg(int tA, int tB, const GemmArgs& a, int split, hipStream_t st, int
 }
 
 struct TileCfg { int BM, BN; };
-constexpr int NUM_CFG = 23;
+constexpr int NUM_CFG = 24;
 const TileCfg kCfg[NUM_CFG] = {{128, 128}, {128, 128}, {64, 64}, {64, 64}, {64, 64}, {128, 64}, {64, 128},
                                {64, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 32}, {64, 64}, {64, 32}, {128, 32},
-                               {128, 64}, {128, 128}, {128, 128}, {256, 64}, {128, 128}, {128, 64}, {64, 128}, {128, 64}};
+                               {128, 64}, {128, 128}, {128, 128}, {256, 64}, {128, 128}, {128, 64}, {64, 128}, {128, 64}, {64, 32}};
 
 // operands that allow the buffer-load fast path (see Stager::load_fast); fills the descriptor extents
 bool fast_ok(int tA, int tB, GemmArgs& a) {
@@ -884,6 +884,7 @@ int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a_in, int split, hipSt
         case 20: return launch_cfg<128, 64, 32, 32, 1, 32, 0, 512>(tA, tB, a, split, st, mb);
         case 21: return launch_cfg<64, 128, 32, 32, 1, 32, 0, 512>(tA, tB, a, split, st, mb);
         case 22: return launch_cfg<128, 64, 32, 32, 1, 16, 0, 512>(tA, tB, a, split, st, mb);
+        case 23: return launch_cfg<64, 32, 32, 32, 4, 32, 1, 512>(tA, tB, a, split, st, mb);
         default: return VQA_ERR_ARG;
     }
 }
@@ -930,13 +931,14 @@ inline int gru_cfg_bwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 16; }
 //    4-wave form of the same tile: 600 us on the same box);
 //  * tall activations (M >= 2048): EIGHT waves of 32x32 on a 64x128 tile (v_linear_v forward 565 us =
 //    137 TFLOP/s; 4 waves of 64x32 on the same tile area: 573), BK 16 on a 128x64 tile when K is short;
-//  * batch-sized M (512) or narrow N: 64x32 tiles with in-block split-k and two tiles of register
-//    prefetch (one workgroup per CU cannot hide a global load behind a single tile's MFMAs).
+//  * batch-sized M (512) or narrow N: 64x32 tiles, in-block split-k and two tiles of register prefetch
+//    (one workgroup per CU cannot hide a global load behind a single tile's MFMAs) -- 8 waves / 4 k groups
+//    (512x1024x1024: 14.4 us against 16.0 with 4 waves / 2 k groups), 4 waves for the wide answer head.
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
     if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
     else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? 21 : 22) : 13; target = 256; }
-    else { cfg = tB ? 11 : 13; target = 256; }
+    else { cfg = (!tB && N > 2048) ? 13 : 23; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
     if (split <= 0) {
