@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vqa_transfer_externaldata_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-T, B, H = 14, 512, 1024
+T, B, H = int(os.environ.get("GRU_T", 14)), int(os.environ.get("GRU_B", 512)), 1024
 g = torch.Generator(device="cuda").manual_seed(0)
 xp = torch.randn(T, B, 3 * H, device="cuda", generator=g) * 0.1
 Wg = torch.randn(H, 2 * H, device="cuda", generator=g) * 0.03

@@ -922,8 +922,9 @@ int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_bl
 // workgroup per CU (cfg 18); backward: 32x32 tiles, 4 waves, 4 k groups (cfg 16).
 // vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
 int g_gru_cfg = -1;
-inline int gru_cfg_fwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 18; }
-inline int gru_cfg_bwd() { return g_gru_cfg >= 0 ? g_gru_cfg : 16; }
+// Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
+inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 10 : 18); }
+inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : 16); }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
 //  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, EIGHT waves
@@ -1063,13 +1064,13 @@ extern "C" int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* W
         EpiArgs eg{};
         eg.H = H; eg.h_prev = hp; eg.o0 = r + t * BH + o; eg.o1 = u + t * BH + o; eg.o2 = rh + t * BH + o;
         GemmArgs ag = make_args(rows, 2 * H, H, hp, H, Wg_h, 2 * H, nullptr, 0, nullptr, xpt, 3 * H);
-        int rc = launch_gru<EPI_GATES>(gru_cfg_fwd(), ag, eg, st);
+        int rc = launch_gru<EPI_GATES>(gru_cfg_fwd(rows), ag, eg, st);
         if (rc != VQA_OK) return rc;
         EpiArgs ec{};
         ec.H = H; ec.t = t; ec.len = len + row0; ec.h_prev = hp; ec.i0 = u + t * BH + o; ec.o0 = c + t * BH + o;
         ec.o1 = hs + (t + 1) * BH + o;
         GemmArgs ac = make_args(rows, H, H, rh + t * BH + o, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
-        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(), ac, ec, st);
+        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(rows), ac, ec, st);
         if (rc != VQA_OK) return rc;
     }
     return VQA_OK;
@@ -1113,7 +1114,7 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
         EpiArgs e1{};
         e1.H = H; e1.ldo = ld; e1.h_prev = hs + t * BH + o; e1.i0 = r + t * BH + o; e1.o0 = dxpt; e1.o1 = dh_acc;
         GemmArgs a1 = make_args(rows, H, H, dxpt + 2 * H, ld, Wc_h, H, nullptr, 0, nullptr, nullptr, 0);
-        int rc = launch_gru<EPI_BWD_RH>(gru_cfg_bwd(), a1, e1, st);
+        int rc = launch_gru<EPI_BWD_RH>(gru_cfg_bwd(rows), a1, e1, st);
         if (rc != VQA_OK) return rc;
         // dh_{t-1} = (dr_pre|du_pre) * Wg_h^T + dh_acc ; epilogue: first half of step t-1
         if (t > 0) {
@@ -1124,7 +1125,7 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
             e2.i0 = u + (t - 1) * BH + o; e2.i1 = c + (t - 1) * BH + o; e2.o0 = dxpp + 2 * H; e2.o1 = dxpp + H;
             e2.o2 = dh_next;
             GemmArgs a2 = make_args(rows, H, 2 * H, dxpt, ld, Wg_h, 2 * H, nullptr, 0, nullptr, dh_acc, H);
-            rc = launch_gru<EPI_BWD_DH>(gru_cfg_bwd(), a2, e2, st);
+            rc = launch_gru<EPI_BWD_DH>(gru_cfg_bwd(rows), a2, e2, st);
             if (rc != VQA_OK) return rc;
             dh_acc = dh_next;
         }
