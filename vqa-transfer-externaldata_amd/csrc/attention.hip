@@ -99,17 +99,22 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_pool_fwd_kernel(
 }
 
 // Backward.  One workgroup per MEMORY walks its `rep` queries, so dv (the gradient of the shared
-// v block) is accumulated over the queries in registers and written once.
+// v block) is accumulated over the queries in registers and written once.  512 threads: the last
+// phase gives every float4 column of v to TWO threads that take alternate rows (dv rows are
+// independent; the per-query column sums are combined through LDS).
+constexpr int BWD_THREADS = 512;
 template <int REP>
-__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
+__global__ __launch_bounds__(BWD_THREADS) void attn_pool_bwd_kernel(
     const float* __restrict__ dpooled, const float* __restrict__ v, const float* __restrict__ qv,
     const float* __restrict__ V, const float* __restrict__ att, const float* __restrict__ w,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dv, float* __restrict__ dqv,
     float* __restrict__ part_dw, float* __restrict__ part_db, int R, int H, int D, int rep) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[D] | ds[REP][R]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[D] | ds[REP][R] | comb[REP][H]
     float* dp = lds;
     float* ds = lds + D;
+    float* comb = ds + ((REP * R + 3) / 4) * 4;
     const int mem = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = BWD_THREADS / 64;
     const float* vb = v + (int64_t)mem * R * H;
     const float* Vb = V + (int64_t)mem * R * D;
     const int D4 = D / 4;
@@ -117,11 +122,11 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     for (int j = 0; j < rep; ++j) {
         const int q = mem * rep + j;
         __syncthreads();
-        for (int d = threadIdx.x; d < D; d += 256) dp[d] = dpooled[(int64_t)q * D + d];
+        for (int d = threadIdx.x; d < D; d += BWD_THREADS) dp[d] = dpooled[(int64_t)q * D + d];
         __syncthreads();
         // datt[r] = <dpooled[q], V[mem,r]>
         float* dsj = ds + j * R;
-        for (int r = wave; r < R; r += 4) {
+        for (int r = wave; r < R; r += NW) {
             float acc = 0.f;
 #pragma unroll 8
             for (int du = lane; du < D4; du += 64) {
@@ -151,44 +156,61 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(
     __syncthreads();
 
     const int H4 = H / 4;
-    for (int hu = threadIdx.x; hu < H4; hu += 256) {
-        const float4 ww = reinterpret_cast<const float4*>(w)[hu];
+    const int half = threadIdx.x / (BWD_THREADS / 2), tcol = threadIdx.x % (BWD_THREADS / 2);
+    for (int hu0 = 0; hu0 < H4; hu0 += BWD_THREADS / 2) {
+        const int hu = hu0 + tcol;
+        const bool live = hu < H4;
+        float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 qj[REP], S[REP];
+        if (live) ww = reinterpret_cast<const float4*>(w)[hu];
 #pragma unroll
         for (int j = 0; j < REP; ++j) {
             S[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            qj[j] = (j < rep) ? reinterpret_cast<const float4*>(qv + (int64_t)(mem * rep + j) * H)[hu]
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            qj[j] = (live && j < rep) ? reinterpret_cast<const float4*>(qv + (int64_t)(mem * rep + j) * H)[hu]
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#pragma unroll 4
-        for (int r = 0; r < R; ++r) {
-            const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+#pragma unroll 2
+            for (int r = half; r < R; r += 2) {
+                const float4 x = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[hu];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < REP; ++j) {
+                    if (j < rep) {
+                        const float d = ds[j * R + r];
+                        float4 g = make_float4(d, d, d, d);
+                        if (keepmask != nullptr) {
+                            const uchar4 m =
+                                reinterpret_cast<const uchar4*>(keepmask + ((int64_t)(mem * rep + j) * R + r) * H)[hu];
+                            g.x *= m.x * inv_keep; g.y *= m.y * inv_keep; g.z *= m.z * inv_keep; g.w *= m.w * inv_keep;
+                        }
+                        S[j].x += g.x * x.x; S[j].y += g.y * x.y; S[j].z += g.z * x.z; S[j].w += g.w * x.w;
+                        acc.x += g.x * qj[j].x * ww.x; acc.y += g.y * qj[j].y * ww.y;
+                        acc.z += g.z * qj[j].z * ww.z; acc.w += g.w * qj[j].w * ww.w;
+                    }
+                }
+                reinterpret_cast<float4*>(dv + ((int64_t)mem * R + r) * H)[hu] = acc;
+            }
+        }
+        // odd-row partial sums -> LDS, the even-row thread of the same column finishes (fixed order)
+        __syncthreads();
+        if (live && half == 1) {
+#pragma unroll
+            for (int j = 0; j < REP; ++j)
+                if (j < rep) reinterpret_cast<float4*>(comb + (size_t)j * H)[hu] = S[j];
+        }
+        __syncthreads();
+        if (live && half == 0) {
 #pragma unroll
             for (int j = 0; j < REP; ++j) {
                 if (j < rep) {
-                    const float d = ds[j * R + r];
-                    float4 g = make_float4(d, d, d, d);
-                    if (keepmask != nullptr) {
-                        const uchar4 m =
-                            reinterpret_cast<const uchar4*>(keepmask + ((int64_t)(mem * rep + j) * R + r) * H)[hu];
-                        g.x *= m.x * inv_keep; g.y *= m.y * inv_keep; g.z *= m.z * inv_keep; g.w *= m.w * inv_keep;
-                    }
-                    S[j].x += g.x * x.x; S[j].y += g.y * x.y; S[j].z += g.z * x.z; S[j].w += g.w * x.w;
-                    acc.x += g.x * qj[j].x * ww.x; acc.y += g.y * qj[j].y * ww.y;
-                    acc.z += g.z * qj[j].z * ww.z; acc.w += g.w * qj[j].w * ww.w;
+                    const float4 o = reinterpret_cast<const float4*>(comb + (size_t)j * H)[hu];
+                    const float4 t = make_float4(S[j].x + o.x, S[j].y + o.y, S[j].z + o.z, S[j].w + o.w);
+                    const int64_t q = (int64_t)mem * rep + j;
+                    reinterpret_cast<float4*>(dqv + q * H)[hu] = make_float4(t.x * ww.x, t.y * ww.y, t.z * ww.z, t.w * ww.w);
+                    reinterpret_cast<float4*>(part_dw + q * H)[hu] =
+                        make_float4(t.x * qj[j].x, t.y * qj[j].y, t.z * qj[j].z, t.w * qj[j].w);
                 }
-            }
-            reinterpret_cast<float4*>(dv + ((int64_t)mem * R + r) * H)[hu] = acc;
-        }
-#pragma unroll
-        for (int j = 0; j < REP; ++j) {
-            if (j < rep) {
-                const int64_t q = (int64_t)mem * rep + j;
-                reinterpret_cast<float4*>(dqv + q * H)[hu] =
-                    make_float4(S[j].x * ww.x, S[j].y * ww.y, S[j].z * ww.z, S[j].w * ww.w);
-                reinterpret_cast<float4*>(part_dw + q * H)[hu] =
-                    make_float4(S[j].x * qj[j].x, S[j].y * qj[j].y, S[j].z * qj[j].z, S[j].w * qj[j].w);
             }
         }
     }
@@ -241,18 +263,19 @@ extern "C" int vqa_attn_pool_bwd_rep(const float* dpooled, const float* v, const
                 VQA_ERR_ALIGN);
     VQA_REQUIRE(keepmask == nullptr || (reinterpret_cast<uintptr_t>(keepmask) & 3u) == 0, VQA_ERR_ALIGN);
     if (B == 0) return VQA_OK;
-    const size_t lds = (size_t)(D + rep * R) * sizeof(float);
     const float ik = keepmask ? 1.f / keep_prob : 1.f;
     hipStream_t st = (hipStream_t)stream;
+    auto lds_for = [&](int REPt) { return (size_t)(D + ((REPt * R + 3) / 4) * 4 + REPt * H) * sizeof(float); };
+    VQA_REQUIRE(lds_for(rep == 1 ? 1 : rep <= 5 ? 5 : 8) <= 64 * 1024, VQA_ERR_UNSUPPORTED);
     if (rep == 1)
-        hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
-                           dv, dqv, part_dw, part_db, R, H, D, rep);
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(B), dim3(BWD_THREADS), lds_for(1), st, dpooled, v, qv, V, att, w,
+                           keepmask, ik, dv, dqv, part_dw, part_db, R, H, D, rep);
     else if (rep <= 5)
-        hipLaunchKernelGGL(attn_pool_bwd_kernel<5>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
-                           dv, dqv, part_dw, part_db, R, H, D, rep);
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<5>, dim3(B), dim3(BWD_THREADS), lds_for(5), st, dpooled, v, qv, V, att, w,
+                           keepmask, ik, dv, dqv, part_dw, part_db, R, H, D, rep);
     else
-        hipLaunchKernelGGL(attn_pool_bwd_kernel<8>, dim3(B), dim3(256), lds, st, dpooled, v, qv, V, att, w, keepmask, ik,
-                           dv, dqv, part_dw, part_db, R, H, D, rep);
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<8>, dim3(B), dim3(BWD_THREADS), lds_for(8), st, dpooled, v, qv, V, att, w,
+                           keepmask, ik, dv, dqv, part_dw, part_db, R, H, D, rep);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
