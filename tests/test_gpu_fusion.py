@@ -154,6 +154,29 @@ def test_full_size_properties_bs512():
     assert abs(float(dE.double().sum()) - float(dx.double().sum())) <= 1e-6 * float(dx.double().abs().sum()) + 1e-9
 
 
+def test_full_size_bs512_forward_matches_oracle_f64():
+    """BASELINE config 2 (bs 512, full dims) forward against the float64 oracle: logits within 1e-3
+    (north_star), argmax bit-exact, report scalars, and every trainable gradient (the big-tile GEMM paths)."""
+    dims = dict(Vq=4096, W=300, D=2048, H=1024, A=3000)
+    B, R, T, N = 512, 36, 14, 256
+    p, table, nbox, batch, am, masks = make_case(27, "vlmap_answer", B, R, T, N, dims, full_boxes=True)
+    eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
+                                             to64(masks), "vlmap_answer")
+    z = eng.tensor("logit").view(B, dims["A"]).cpu().numpy()
+    assert np.abs(z - mid["logit"]).max() <= 1e-3, np.abs(z - mid["logit"]).max()
+    np.testing.assert_array_equal(eng.tensor("pred").cpu().numpy(), out["pred"])
+    rep = eng.report()
+    for k in O.REPORT_KEYS:
+        assert abs(rep[k] - report[k]) <= 1e-4 * max(1.0, abs(report[k])), (k, rep[k], report[k])
+    grads, dx = O.backward(to64(p), to64(batch), to64(am), to64(masks), tape, "vlmap_answer")
+    for n in eng.train_names:
+        if n.endswith("score/fc/biases"):
+            continue                      # analytically zero: rounding noise on both sides
+        grad_close(eng.grads[n], grads[n], n)
+
+
 @pytest.mark.parametrize("gru_cfg", [4, 7, 8, 9, 10, 11, 13, 16, 17, 18])
 def test_fused_gru_tile_configs_match_oracle(gru_cfg):
     """Every tile configuration of the fused GRU-step GEMMs (in-block split-k 1/2/4) gives the oracle's
