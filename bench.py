@@ -79,9 +79,9 @@ def synth_inputs(cfg, seed, device, n_batches=4):
     return table, nbox, am, batches
 
 
-def cpu_baseline(params, table, nbox, am, batch, cfg, steps=2):
+def cpu_baseline(params, table, nbox, am, batch, cfg, steps=4):
     """Torch-CPU fp32 port of the same train step (oracle/torch_ref.py) on the host
-    cores, bounded sample: `steps` timed steps at the full bs-512 shape."""
+    cores, bounded sample: `steps` timed steps at the full bs-512 shape (about 10 s of CPU work at ~200 samples/s)."""
     from oracle import torch_ref as TR
     n = 512
     tab = table[:n].cpu().numpy()
