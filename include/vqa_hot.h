@@ -51,8 +51,12 @@ int vqa_gather_features(const float* table, const int32_t* nbox_table, const int
  * consumes one contiguous [B,W] slab per step). */
 int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, void* stream);
 /* backward: dE[q[b,t],:] += dx[t,b,:] (dE must be zeroed by the caller);
- * the IndexedSlices gradient of the gather. */
+ * the IndexedSlices gradient of the gather.  Deterministic (no atomics) for W <= 512. */
 int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq, void* stream);
+/* Same, skipping the zero-padded positions t >= len[b]: dynamic_rnn(sequence_length) makes their dx exactly
+ * zero (vlmap/modules.py:124-140), so the result is identical and the padding id is not a hot row. */
+int vqa_embed_bwd_len(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T, int W,
+                      int Vq, void* stream);
 
 /* ------------------------------------------------- GEMM (layers.fully_connected)
  * C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ D[M,N]),  f32 MFMA.

@@ -1,0 +1,61 @@
+"""Exercises the RCCL code path of the bucketed gradient reduction with ONE rank (a 1-GPU box cannot host two
+NCCL ranks): async all-reduce of the three buckets between the backward phases, wait, optimizer; the result must
+equal the un-reduced single-process step bit for bit (a 1-rank sum is the identity)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from vqa_transfer_externaldata_amd import fusion as F  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+cfg = dict(bench.CFG)
+cfg["N_img"] = 512
+params = bench.synth_params("vlmap_answer", cfg, seed=1)
+table, nbox, am, batches = bench.synth_inputs(cfg, seed=2, device=dev)
+
+
+class ForcedReducer:
+    """dp.BucketedAllReduce without its world_size == 1 shortcut."""
+    def __init__(self):
+        self.works = []
+
+    def start(self, bucket):
+        self.works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def run(reducer):
+    eng = F.FusionEngine(model_type="vlmap_answer", B=cfg["B"], R=cfg["R"], D=cfg["D"], H=cfg["H"], T=cfg["T"], W=cfg["W"],
+                         A=cfg["A"], Vq=cfg["Vq"], N_img=cfg["N_img"], params=params, device=dev, global_batch=cfg["B"])
+    eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
+    for i in range(int(os.environ.get('STEPS', 3))):
+        ka, kj = eng.make_keep_masks(seed=5, step=i)
+        eng.train_step(batches[i % len(batches)], ka, kj, 1e-3, allreduce=reducer)
+    torch.cuda.synchronize()
+    return eng, eng.train_flat.clone(), eng.report()["answer_train_loss"]
+
+
+e0, p0, l0 = run(None)
+e1, p1, l1 = run(ForcedReducer())
+for n in e0.train_names:
+    a, b = e0.params[n], e1.params[n]
+    if not torch.equal(a, b):
+        print("DIFF %-50s max |d| %.3e  (max |p| %.3e)  grad diff %.3e" % (n, float((a - b).abs().max()), float(a.abs().max()),
+              float((e0.grads[n] - e1.grads[n]).abs().max())))
+assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+assert l0 == l1
+print("1-rank RCCL bucketed reduction == plain step (bitwise); loss", l0)
+dist.destroy_process_group()

@@ -48,11 +48,69 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     for (int i = threadIdx.x & 63; i < W; i += 64) d[i] = s[i];
 }
 
+// Scatter-add of the embedding gradient WITHOUT atomics: one wave owns one vocabulary row, scans the
+// B*T token ids (a few tens of KB, cache resident) and adds the matching dx rows in ascending token
+// order -- deterministic.  Positions past a sequence's length (zero padding; their dx is exactly zero)
+// are skipped when `len` is given, so the padding id is not a hot row; the rows of a frequent word are
+// fetched four at a time (independent loads, fixed addition order).
+template <int NK>   // NK * 64 >= W
+__global__ __launch_bounds__(256) void embed_bwd_owner_kernel(const float* __restrict__ dx, const int32_t* __restrict__ q,
+                                                              const int32_t* __restrict__ len, float* __restrict__ dE,
+                                                              int B, int T, int W, int Vq) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= Vq) return;
+    float acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+    bool any = false;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        const int lim = (b < B) ? (len != nullptr ? min(len[b], T) : T) : 0;
+        for (int t = 0; t < T; ++t) {
+            int id = -1;
+            if (t < lim) id = min(max(q[b * T + t], 0), Vq - 1);
+            unsigned long long m = __ballot(id == v);
+            while (m) {
+                int j[4];
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    j[u] = -1;
+                    if (m) { j[u] = __ffsll((long long)m) - 1; m &= m - 1; ++cnt; }
+                }
+                float r[4][NK];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* s = dx + ((int64_t)t * B + b0 + max(j[u], 0)) * W;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k)
+                        r[u][k] = (j[u] >= 0 && lane + 64 * k < W) ? s[lane + 64 * k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < cnt) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) acc[k] += r[u][k];
+                    }
+                any = true;
+            }
+        }
+    }
+    if (!any) return;
+    float* d = dE + (int64_t)v * W;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+        if (lane + 64 * k < W) d[lane + 64 * k] += acc[k];
+}
+
+// wide embeddings (W > 512): atomic form
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ q,
-                                                        float* __restrict__ dE, int B, int T, int W, int Vq) {
+                                                        const int32_t* __restrict__ len, float* __restrict__ dE, int B,
+                                                        int T, int W, int Vq) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= B * T) return;
     const int t = tok / B, b = tok % B;
+    if (len != nullptr && t >= len[b]) return;
     int id = q[b * T + t];
     id = min(max(id, 0), Vq - 1);
     const float* s = dx + (int64_t)tok * W;
@@ -227,14 +285,23 @@ extern "C" int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int 
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
-extern "C" int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq,
-                             void* stream) {
+extern "C" int vqa_embed_bwd_len(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T,
+                                 int W, int Vq, void* stream) {
     VQA_REQUIRE(dx_tm && q && dE && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
     if (B * T == 0) return VQA_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, dx_tm, q, dE, B, T,
-                       W, Vq);
+    hipStream_t st = (hipStream_t)stream;
+    if (W <= 320)
+        hipLaunchKernelGGL(embed_bwd_owner_kernel<5>, dim3((Vq + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
+    else if (W <= 512)
+        hipLaunchKernelGGL(embed_bwd_owner_kernel<8>, dim3((Vq + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
+    else
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
+}
+extern "C" int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq,
+                             void* stream) {
+    return vqa_embed_bwd_len(dx_tm, q, nullptr, dE, B, T, W, Vq, stream);
 }
 
 extern "C" int vqa_mul(const float* a, const float* b, float* z, int64_t n, void* stream) {

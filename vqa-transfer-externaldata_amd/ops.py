@@ -61,11 +61,12 @@ def embed_fwd(E, q):
     return x
 
 
-def embed_bwd(dx_tm, q, Vq):
+def embed_bwd(dx_tm, q, Vq, lens=None):
+    """lens (i32 [B]): skip the zero-padded positions t >= lens[b] (their dx is exactly zero)."""
     lib = _lib.load()
     T, B, W = dx_tm.shape
     dE = torch.zeros(Vq, W, dtype=torch.float32, device=dx_tm.device)
-    _lib.check(lib.vqa_embed_bwd(_p(dx_tm), _p(q), _p(dE), B, T, W, Vq, _st(dx_tm)), "vqa_embed_bwd")
+    _lib.check(lib.vqa_embed_bwd_len(_p(dx_tm), _p(q), _p(lens), _p(dE), B, T, W, Vq, _st(dx_tm)), "vqa_embed_bwd_len")
     return dE
 
 
@@ -250,11 +251,12 @@ def add_inplace(acc, x):
     return acc
 
 
-def embed_bwd_into(dx_tm, q, dE):
-    """dE[q[b,t],:] += dx_tm[t,b,:] (scatter-add into an existing gradient buffer)."""
+def embed_bwd_into(dx_tm, q, dE, lens=None):
+    """dE[q[b,t],:] += dx_tm[t,b,:] (scatter-add into an existing gradient buffer); lens as in embed_bwd."""
     lib = _lib.load()
     T, B, W = dx_tm.shape
-    _lib.check(lib.vqa_embed_bwd(_p(dx_tm), _p(q), _p(dE), B, T, W, dE.shape[0], _st(dx_tm)), "vqa_embed_bwd")
+    _lib.check(lib.vqa_embed_bwd_len(_p(dx_tm), _p(q), _p(lens), _p(dE), B, T, W, dE.shape[0], _st(dx_tm)),
+               "vqa_embed_bwd_len")
 
 
 def gru_seq_fwd(xp, Wg_h, Wc_h, lens, T, B, H):

@@ -287,7 +287,7 @@ class PretrainEngine:
             self._touched.add("gru")
             dx = ops.gemm(dxp[:, :2 * H], Wg[:W], transB=True)
             ops.gemm(dxp[:, 2 * H:], Wc[:W], transB=True, addend=dx, out=dx)
-            ops.embed_bwd_into(dx.view(L, Bn, W), kt["blanks"], self.grads["L_GloVe/embed_map"])
+            ops.embed_bwd_into(dx.view(L, Bn, W), kt["blanks"], self.grads["L_GloVe/embed_map"], lens=kt["lens"])
             slice_sq.append(ops.sumsq(dx.view(-1)))
             # word set -> wordset_ft -> tanh -> wordset_map
             dwf = head_bwd("wordset")
