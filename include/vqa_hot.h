@@ -51,7 +51,10 @@ int vqa_gather_features(const float* table, const int32_t* nbox_table, const int
  * consumes one contiguous [B,W] slab per step). */
 int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, void* stream);
 /* backward: dE[q[b,t],:] += dx[t,b,:] (dE must be zeroed by the caller);
- * the IndexedSlices gradient of the gather.  Deterministic (no atomics) for W <= 512. */
+ * the IndexedSlices gradient of the gather.  Float atomics by default (order of the adds, hence the last bit,
+ * varies run to run -- as in the reference); after vqa_set_deterministic(1) an atomic-free, run-to-run bitwise
+ * reproducible form is used for W <= 512 (about 30 us slower at bs 512). */
+int vqa_set_deterministic(int on);   /* process-wide; every other kernel is deterministic already */
 int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T, int W, int Vq, void* stream);
 /* Same, skipping the zero-padded positions t >= len[b]: dynamic_rnn(sequence_length) makes their dx exactly
  * zero (vlmap/modules.py:124-140), so the result is identical and the padding id is not a hot row. */

@@ -10,7 +10,9 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from vqa_transfer_externaldata_amd import fusion as F  # noqa: E402
+from vqa_transfer_externaldata_amd import _lib, fusion as F  # noqa: E402
+
+_lib.load().vqa_set_deterministic(1)     # atomic-free embedding scatter-add: makes a bitwise comparison meaningful
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")

@@ -52,6 +52,7 @@ SIGNATURES = {
     "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_set_deterministic": (_I, [_I]),
     "vqa_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _P]),
     "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "vqa_gemm_f32_ex": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _I, _P]),

@@ -48,62 +48,79 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict_
     for (int i = threadIdx.x & 63; i < W; i += 64) d[i] = s[i];
 }
 
-// Scatter-add of the embedding gradient WITHOUT atomics: one wave owns one vocabulary row, scans the
-// B*T token ids (a few tens of KB, cache resident) and adds the matching dx rows in ascending token
-// order -- deterministic.  Positions past a sequence's length (zero padding; their dx is exactly zero)
-// are skipped when `len` is given, so the padding id is not a hot row; the rows of a frequent word are
-// fetched four at a time (independent loads, fixed addition order).
+// Deterministic mode (vqa_set_deterministic): scatter-add of the embedding gradient WITHOUT atomics -- one wave
+// owns up to EMB_ROWS vocabulary rows, scans the B*T token ids once (a few tens of KB, cache resident) and adds the matching dx rows
+// into its LDS accumulators in ascending token order -- deterministic, and a frequent word costs no
+// atomic contention (its rows are fetched eight at a time: independent loads, fixed addition order).
+// Positions past a sequence's length (zero padding; their dx is exactly zero) are skipped when `len`
+// is given, so the padding id is not a hot row.
+constexpr int EMB_ROWS = 16;
 template <int NK>   // NK * 64 >= W
 __global__ __launch_bounds__(256) void embed_bwd_owner_kernel(const float* __restrict__ dx, const int32_t* __restrict__ q,
                                                               const int32_t* __restrict__ len, float* __restrict__ dE,
-                                                              int B, int T, int W, int Vq) {
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (v >= Vq) return;
-    float acc[NK];
+                                                              int B, int T, int W, int Vq, int nw_log2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][EMB_ROWS][NK * 64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave w of nw_log2-many owns rows {w, w + NW, w + 2 NW, ...}: frequent words (small ids in a
+    // frequency-sorted vocabulary) land on different waves
+    const int w = blockIdx.x * 4 + wave, NW = 1 << nw_log2;
+    if (w >= NW) return;                                          // no workgroup barrier below
+    float* acc = lds + (size_t)wave * EMB_ROWS * NK * 64;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) acc[k] = 0.f;
-    bool any = false;
+    for (int i = 0; i < EMB_ROWS * NK; ++i) acc[i * 64 + lane] = 0.f;
+    unsigned touched = 0;
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int b = b0 + lane;
         const int lim = (b < B) ? (len != nullptr ? min(len[b], T) : T) : 0;
         for (int t = 0; t < T; ++t) {
-            int id = -1;
-            if (t < lim) id = min(max(q[b * T + t], 0), Vq - 1);
-            unsigned long long m = __ballot(id == v);
+            int rid = -1;
+            if (t < lim) {
+                const int id = min(max(q[b * T + t], 0), Vq - 1);
+                if ((id & (NW - 1)) == w) rid = id >> nw_log2;
+            }
+            unsigned long long m = __ballot(rid >= 0);
             while (m) {
-                int j[4];
+                int j[8], rr[8];
                 int cnt = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    j[u] = -1;
-                    if (m) { j[u] = __ffsll((long long)m) - 1; m &= m - 1; ++cnt; }
-                }
-                float r[4][NK];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float* s = dx + ((int64_t)t * B + b0 + max(j[u], 0)) * W;
-#pragma unroll
-                    for (int k = 0; k < NK; ++k)
-                        r[u][k] = (j[u] >= 0 && lane + 64 * k < W) ? s[lane + 64 * k] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u < cnt) {
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) acc[k] += r[u][k];
+                for (int u = 0; u < 8; ++u) {
+                    j[u] = 0; rr[u] = 0;
+                    if (m) {
+                        j[u] = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        rr[u] = __shfl(rid, j[u], 64);
+                        ++cnt;
                     }
-                any = true;
+                }
+                float r[8][NK];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* s = dx + ((int64_t)t * B + b0 + j[u]) * W;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) r[u][k] = (u < cnt && lane + 64 * k < W) ? s[lane + 64 * k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) {
+                        float* a = acc + rr[u] * NK * 64 + lane;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) a[64 * k] += r[u][k];
+                        touched |= 1u << rr[u];
+                    }
             }
         }
     }
-    if (!any) return;
-    float* d = dE + (int64_t)v * W;
+    for (int rl = 0; rl < EMB_ROWS; ++rl) {
+        if (!((touched >> rl) & 1u)) continue;
+        float* d = dE + (int64_t)(w + (rl << nw_log2)) * W;
+        const float* a = acc + rl * NK * 64 + lane;
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
-        if (lane + 64 * k < W) d[lane + 64 * k] += acc[k];
+        for (int k = 0; k < NK; ++k)
+            if (lane + 64 * k < W) d[lane + 64 * k] += a[64 * k];
+    }
 }
 
-// wide embeddings (W > 512): atomic form
+// default: float atomics, one wave per token
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ q,
                                                         const int32_t* __restrict__ len, float* __restrict__ dE, int B,
                                                         int T, int W, int Vq) {
@@ -285,17 +302,51 @@ extern "C" int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int 
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
+namespace {
+int g_deterministic = 0;
+}
+extern "C" int vqa_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return VQA_OK;
+}
 extern "C" int vqa_embed_bwd_len(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T,
                                  int W, int Vq, void* stream) {
     VQA_REQUIRE(dx_tm && q && dE && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
     if (B * T == 0) return VQA_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (W <= 320)
-        hipLaunchKernelGGL(embed_bwd_owner_kernel<5>, dim3((Vq + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
-    else if (W <= 512)
-        hipLaunchKernelGGL(embed_bwd_owner_kernel<8>, dim3((Vq + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
-    else
+    if (!g_deterministic || W > 512) {
+        // float atomics: the L2 serialises a frequent word's adds per address at ~10 ns each, so skew costs
+        // little; the summation order (hence the last bit) varies from run to run, as it does in the reference
         hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);
+        VQA_CHECK_LAUNCH();
+        return VQA_OK;
+    }
+    int nw_log2 = 0;
+    while ((EMB_ROWS << nw_log2) < Vq) ++nw_log2;
+    const int grid = ((1 << nw_log2) + 3) / 4;
+    if (W <= 320) {
+        auto kern = embed_bwd_owner_kernel<5>;
+        constexpr int lds = 4 * EMB_ROWS * 5 * 64 * (int)sizeof(float);     // 80 KiB > the 64 KiB default limit
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess)
+                return VQA_ERR_LAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, dx_tm, q, len, dE, B, T, W, Vq, nw_log2);
+    } else {
+        auto kern = embed_bwd_owner_kernel<8>;
+        constexpr int lds = 4 * EMB_ROWS * 8 * 64 * (int)sizeof(float);     // 128 KiB
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess)
+                return VQA_ERR_LAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, dx_tm, q, len, dE, B, T, W, Vq, nw_log2);
+    }
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -97,8 +97,12 @@ def _pad4(n):
 
 class FusionEngine:
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
-                 keep_att=0.8, keep_joint=0.5, global_batch=None):
+                 keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None):
+        """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
+        from float atomics to an atomic-free kernel, ~30 us slower at bs 512; process-wide library setting)."""
         self.lib = _lib.load()
+        if deterministic is not None:
+            _lib.check(self.lib.vqa_set_deterministic(1 if deterministic else 0), "vqa_set_deterministic")
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
         self.device = torch.device(device)
