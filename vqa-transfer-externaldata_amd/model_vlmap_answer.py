@@ -209,13 +209,19 @@ class Model(object):
     def set_batch(self, batch):
         self.batch = batch
 
+    _DEVICE_KEYS = (("image_idx", torch.int64), ("q_intseq", torch.int32), ("q_intseq_len", torch.int32),
+                    ("answer_target", torch.float32))
+
+    def to_device_batch(self, batch):
+        """The batch dict with its four model inputs moved to the device (other entries -- ids, image_id -- kept)."""
+        out = dict(batch)
+        for k, dt in self._DEVICE_KEYS:
+            out[k] = self._to_dev(batch[k], dt)
+        return out
+
     def _device_batch(self):
         b = self.batch
-        db = {"image_idx": self._to_dev(b["image_idx"], torch.int64),
-              "q_intseq": self._to_dev(b["q_intseq"], torch.int32),
-              "q_intseq_len": self._to_dev(b["q_intseq_len"], torch.int32),
-              "answer_target": self._to_dev(b["answer_target"], torch.float32)}
-        return db
+        return {k: self._to_dev(b[k], dt) for k, dt in self._DEVICE_KEYS}
 
     # ---------------------------------------------------------------- build = forward
     def build(self):

@@ -78,7 +78,9 @@ class Trainer(object):
         log.infov("using model class: {}".format(Model))
         config.global_batch = None
         first = self._shard(next(self._iters["train"]))
-        self._pending_train_batch = first[0]
+        self._dev_batches, self._dev_batch_bytes = {}, 0
+        self._dev_batch_budget = int(getattr(config, "device_batch_cache_gb", 32)) << 30
+        self._pending_train_batch, self._pending_global = first[0], None
         config.global_batch = first[1]
         self.model = Model(first[0], config, is_train=True, image_features=image_features)
 
@@ -126,9 +128,24 @@ class Trainer(object):
     def _next(self, split):
         if split == "train" and self._pending_train_batch is not None:
             b, self._pending_train_batch = self._pending_train_batch, None
+            if self._pending_global is not None:
+                self.config.global_batch, self._pending_global = self._pending_global, None
             return b
         it = self._iters.get(split) or self._iters["train"]
-        batch, n_global = self._shard(next(it))
+        raw = next(it)
+        # The input pipeline caches its padded batches (dataset.cache() after padded_batch in the reference) and
+        # yields the same dict objects every epoch, so this rank's shard of each batch is kept ON THE DEVICE
+        # after its first use: 6.2 MB per bs-512 batch, ~5 GB for all of VQA v2 train against 288 GB of HBM --
+        # from the second epoch on a step needs no host assembly and no host-to-device copy at all.
+        hit = self._dev_batches.get(id(raw))
+        if hit is not None and hit[0] is raw:
+            batch, n_global = hit[1], hit[2]
+        else:
+            batch, n_global = self._shard(raw)
+            if self._dev_batch_bytes < self._dev_batch_budget:
+                batch = self.model.to_device_batch(batch)
+                self._dev_batches[id(raw)] = (raw, batch, n_global)
+                self._dev_batch_bytes += sum(v.numel() * v.element_size() for v in batch.values() if torch.is_tensor(v))
         self.config.global_batch = n_global
         return batch
 
@@ -144,6 +161,12 @@ class Trainer(object):
         self.model.build()
         self.model.backward(reducer=self._allreduce)       # buckets reduced while backward still runs
         self.model.apply_gradients(self._lr())
+        # everything above is only ENQUEUED: assemble (and, first epoch, upload) the next batch while the GPU
+        # works, and only then wait for this step's report
+        gb = self.config.global_batch
+        nxt = self._next("train")
+        self._pending_train_batch, self._pending_global = nxt, self.config.global_batch
+        self.config.global_batch = gb
         loss, report = self._report_values()
         self.global_step += 1
         _end_time = time.time()
