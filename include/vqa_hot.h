@@ -156,6 +156,20 @@ int vqa_gru_seq_bwd(float* dh_T, const float* Wg_h, const float* Wc_h, const int
                     const float* r, const float* u, const float* c, float* dxp, float* dh_scratch, int T, int B,
                     int H, void* stream);
 
+/* The same over the live prefix only: rows sorted by length (longest first), live_rows = HOST int[T] with
+ * live_rows[t] = #rows with len > t.  Step t runs on rows [0, live_rows[t]); finished rows are filled in
+ * afterwards (state carried, r*h and pre-activation gradients zero) exactly as the masked recurrence leaves them
+ * (tf.nn.dynamic_rnn(sequence_length=...), vlmap/modules.py:124-140).  Results are identical; the work shrinks
+ * with the sequences still running. */
+int vqa_gru_seq_fwd_live(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, const int32_t* live_rows,
+                         float* hs, float* r, float* u, float* c, float* rh, int T, int B, int H, void* stream);
+int vqa_gru_seq_bwd_live(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                         const int32_t* live_rows, const float* hs, const float* r, const float* u, const float* c,
+                         float* dxp, float* dh_scratch, int T, int B, int H, void* stream);
+/* helpers of the above: hs[t+1,b] = hs[len[b],b], rh[t,b] = 0 and dxp[t,b] = 0 for every t >= len[b] */
+int vqa_gru_fill_finished(float* hs, float* rh, const int32_t* len, int T, int B, int H, void* stream);
+int vqa_gru_zero_finished(float* dxp, const int32_t* len, int T, int B, int H, void* stream);
+
 /* The same restricted to batch rows [row0, row0+rows): samples are independent, so disjoint
  * row windows may run concurrently on different streams. */
 int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,
@@ -269,6 +283,9 @@ typedef struct {
     const float *train_mask, *obj_mask, *attr_mask, *exist_mask; /* [A] */
     const uint8_t* keep_att;            /* [B,R,H] 0/1 or NULL (no dropout) */
     const uint8_t* keep_joint;          /* [B,2H] 0/1 or NULL */
+    const int32_t* live_rows;           /* HOST int[T] or NULL.  Non-NULL promises that the batch rows are sorted by
+                                         * q_intseq_len, longest first, and live_rows[t] = #rows with len > t; the
+                                         * recurrence then skips finished sequences (vqa_gru_seq_*_live). */
 } vqa_batch_t;
 
 int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims);

@@ -16,8 +16,10 @@ from vqa_transfer_externaldata_amd import dataset_vlmap as DV  # noqa: E402
 ds = DV.Dataset(split="train", data=DV.synthetic_dataset(B, Vq, n_ws, A, R=R, D=D, max_len=L, seed=0), seed=0)
 batch = next(DV.create_ops(B, ds, is_train=True, shuffle=False))
 batch = {k: v for k, v in batch.items() if v.dtype.kind in "fi" and k != "image_id"}
+sort_info = {} if os.environ.get("SORT", "1") == "0" else {k: v for k, v in PT.add_length_sort(dict(batch)).items() if k.endswith("/sort")}
 eng = PT.PretrainEngine(n=n, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=n_ws, params=p)
 db = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+db.update(sort_info)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for i in range(3):
     eng.train_step(db, eng.make_keep_masks(B, 1, i), 1e-3)

@@ -7,7 +7,8 @@ from vqa_transfer_externaldata_amd import input_ops_vqa as io, trainer
 
 Vq, A, N_img, R, D, B = 16384, 3000, 2048, 36, 2048, 512
 tmp = tempfile.mkdtemp()
-c = trainer.parse_config(["--batch_size", str(B), "--max_train_iter", "100000", "--model_type", "vlmap_answer"])
+c = trainer.parse_config(["--batch_size", str(B), "--max_train_iter", "100000", "--model_type", "vlmap_answer",
+                          "--sort_by_length", os.environ.get("SORT", "1")])
 c.vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
 c.answer_dict = {"vocab": ["a%d" % i for i in range(A)], "dict": {"a%d" % i: i for i in range(A)}, "num_train_answer": 2250,
                  "is_object": [i % 2 for i in range(A)], "is_attribute": [1 - i % 2 for i in range(A)]}

@@ -39,7 +39,8 @@ class Batch(C.Structure):
     _fields_ = [("table", C.c_void_p), ("nbox_table", C.c_void_p), ("image_idx", C.c_void_p),
                 ("q_intseq", C.c_void_p), ("q_intseq_len", C.c_void_p), ("answer_target", C.c_void_p),
                 ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
-                ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p)]
+                ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p),
+                ("live_rows", C.c_void_p)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -64,6 +65,10 @@ SIGNATURES = {
     "vqa_gru_seq_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_seq_fwd_live": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_seq_bwd_live": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_fill_finished": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_zero_finished": (_I, [_P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_act_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

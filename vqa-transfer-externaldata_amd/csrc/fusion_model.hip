@@ -323,7 +323,10 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         ProbeScope ps("gru.fwd", c.st);
         Side& g2 = gru_stream();
         const int64_t B0 = (B / 2 / 64) * 64;   // first half (multiple of the 64-row tile)
-        if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
+        if (bt->live_rows != nullptr) {          // rows sorted by length: skip finished sequences
+            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
+                                     c.f("gru_c"), c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
+        } else if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
             TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
                                      c.f("gru_rh"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
             TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
@@ -442,7 +445,10 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         ProbeScope ps("gru.bwd", c.st);
         Side& g2 = gru_stream();
         const int64_t B0 = (B / 2 / 64) * 64;
-        if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
+        if (bt->live_rows != nullptr) {
+            TRY(vqa_gru_seq_bwd_live(dh, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
+                                     c.f("gru_c"), dxp, c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
+        } else if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
             TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
                                      dxp, c.f("d_h1"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
             TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),

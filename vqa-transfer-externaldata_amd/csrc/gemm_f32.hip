@@ -1079,6 +1079,92 @@ extern "C" int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* W
 // Back-propagation through time.  dh_T [B,H] is the gradient wrt the final state (consumed:
 // used as scratch); dxp [T,B,3H] receives (dr_pre | du_pre | dc_pre) per step; dh0 [B,H]
 // scratch/returns the gradient wrt the initial state.
+// Recurrence over the LIVE prefix only.  Contract: the batch rows are sorted by length, longest first, and
+// live_rows[t] (HOST array of T ints) = number of rows with len > t.  Step t then runs on rows [0, live_rows[t])
+// -- the gate / candidate GEMMs shrink with the sequences that are still running (real questions average ~6 of
+// 14 tokens) -- and finished rows are filled in afterwards exactly as the masked recurrence leaves them.
+extern "C" int vqa_gru_seq_fwd_live(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                                    const int32_t* live_rows, float* hs, float* r, float* u, float* c, float* rh,
+                                    int T, int B, int H, void* stream) {
+    VQA_REQUIRE(xp && Wg_h && Wc_h && len && live_rows && hs && r && u && c && rh && T >= 0 && B > 0 && H > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0, VQA_ERR_ALIGN);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t BH = (int64_t)B * H;
+    int prev = B;
+    for (int t = 0; t < T; ++t) {
+        const int rows = live_rows[t];
+        VQA_REQUIRE(rows >= 0 && rows <= prev, VQA_ERR_ARG);      // non-increasing
+        prev = rows;
+        if (rows == 0) break;
+        float* xpt = xp + (int64_t)t * B * 3 * H;
+        const float* hp = hs + t * BH;
+        EpiArgs eg{};
+        eg.H = H; eg.h_prev = hp; eg.o0 = r + t * BH; eg.o1 = u + t * BH; eg.o2 = rh + t * BH;
+        GemmArgs ag = make_args(rows, 2 * H, H, hp, H, Wg_h, 2 * H, nullptr, 0, nullptr, xpt, 3 * H);
+        int rc = launch_gru<EPI_GATES>(gru_cfg_fwd(rows), ag, eg, st);
+        if (rc != VQA_OK) return rc;
+        EpiArgs ec{};
+        ec.H = H; ec.t = t; ec.len = len; ec.h_prev = hp; ec.i0 = u + t * BH; ec.o0 = c + t * BH;
+        ec.o1 = hs + (t + 1) * BH;
+        GemmArgs ac = make_args(rows, H, H, rh + t * BH, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
+        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(rows), ac, ec, st);
+        if (rc != VQA_OK) return rc;
+    }
+    return vqa_gru_fill_finished(hs, rh, len, T, B, H, stream);
+}
+
+extern "C" int vqa_gru_seq_bwd_live(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                                    const int32_t* live_rows, const float* hs, const float* r, const float* u,
+                                    const float* c, float* dxp, float* dh_scratch, int T, int B, int H, void* stream) {
+    VQA_REQUIRE(dh_T && Wg_h && Wc_h && len && live_rows && hs && r && u && c && dxp && dh_scratch && T >= 0 && B > 0 &&
+                    H > 0,
+                VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0, VQA_ERR_ALIGN);
+    if (T == 0) return VQA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t BH = (int64_t)B * H;
+    const int ld = 3 * H;
+    // both state-gradient buffers start as dL/dh_final: a row is first touched at its own last step
+    if (hipMemcpyAsync(dh_scratch, dh_T, (size_t)BH * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return VQA_ERR_LAUNCH;
+    int rc = vqa_gru_zero_finished(dxp, len, T, B, H, stream);
+    if (rc != VQA_OK) return rc;
+    float* cur = dh_T;
+    float* other = dh_scratch;
+    int entered = 0;   // rows [0, entered) already carry a running dh_acc in `cur`
+    for (int t = T - 1; t >= 0; --t) {
+        const int rows = live_rows[t];
+        VQA_REQUIRE(rows >= entered && rows <= B, VQA_ERR_ARG);
+        float* dxpt = dxp + (int64_t)t * B * ld;
+        if (rows > entered) {   // rows whose LAST step is t: first half of the step from dL/dh_final, in place
+            const int64_t o = (int64_t)entered * H;
+            rc = vqa_gru_bwd_a(cur + o, hs + t * BH + o, u + t * BH + o, c + t * BH + o, len + entered, t,
+                               dxpt + (int64_t)entered * ld + 2 * H, ld, dxpt + (int64_t)entered * ld + H, ld, cur + o,
+                               rows - entered, H, stream);
+            if (rc != VQA_OK) return rc;
+            entered = rows;
+        }
+        if (rows == 0) continue;
+        EpiArgs e1{};
+        e1.H = H; e1.ldo = ld; e1.h_prev = hs + t * BH; e1.i0 = r + t * BH; e1.o0 = dxpt; e1.o1 = cur;
+        GemmArgs a1 = make_args(rows, H, H, dxpt + 2 * H, ld, Wc_h, H, nullptr, 0, nullptr, nullptr, 0);
+        rc = launch_gru<EPI_BWD_RH>(gru_cfg_bwd(rows), a1, e1, st);
+        if (rc != VQA_OK) return rc;
+        if (t > 0) {
+            float* dxpp = dxp + (int64_t)(t - 1) * B * ld;
+            EpiArgs e2{};
+            e2.H = H; e2.t = t - 1; e2.ldo = ld; e2.len = len; e2.h_prev = hs + (t - 1) * BH;
+            e2.i0 = u + (t - 1) * BH; e2.i1 = c + (t - 1) * BH; e2.o0 = dxpp + 2 * H; e2.o1 = dxpp + H;
+            e2.o2 = other;
+            GemmArgs a2 = make_args(rows, H, 2 * H, dxpt, ld, Wg_h, 2 * H, nullptr, 0, nullptr, cur, H);
+            rc = launch_gru<EPI_BWD_DH>(gru_cfg_bwd(rows), a2, e2, st);
+            if (rc != VQA_OK) return rc;
+            float* x = cur; cur = other; other = x;
+        }
+    }
+    return VQA_OK;
+}
+
 extern "C" int vqa_gru_seq_bwd(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len,
                                const float* hs, const float* r, const float* u, const float* c, float* dxp,
                                float* dh_scratch, int T, int B, int H, void* stream) {

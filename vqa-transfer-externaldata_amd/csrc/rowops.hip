@@ -222,6 +222,30 @@ __global__ __launch_bounds__(256) void gru_bwd_b_kernel(const float* __restrict_
     }
 }
 
+// Finished sequences (t >= len[b]) when the recurrence skipped them (vqa_gru_seq_*_live): forward, their state
+// is carried (hs[t+1] = hs[len]) and r*h zeroed so the weight-gradient GEMMs over all T*B rows see defined values;
+// backward, their pre-activation gradients are zero.
+__global__ __launch_bounds__(256) void gru_fill_finished_kernel(float* __restrict__ hs, float* __restrict__ rh,
+                                                                const int32_t* __restrict__ len, int T, int B, int H) {
+    const int b = blockIdx.x, t = blockIdx.y;
+    const int L = min(max(len[b], 0), T);
+    if (t < L) return;
+    const float4* src = reinterpret_cast<const float4*>(hs + ((int64_t)L * B + b) * H);
+    float4* dst = reinterpret_cast<float4*>(hs + ((int64_t)(t + 1) * B + b) * H);
+    float4* z = reinterpret_cast<float4*>(rh + ((int64_t)t * B + b) * H);
+    for (int i = threadIdx.x; i < H / 4; i += 256) {
+        dst[i] = src[i];
+        z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void gru_zero_finished_kernel(float* __restrict__ dxp, const int32_t* __restrict__ len,
+                                                                int T, int B, int H3) {
+    const int b = blockIdx.x, t = blockIdx.y;
+    if (t < len[b]) return;
+    float4* z = reinterpret_cast<float4*>(dxp + ((int64_t)t * B + b) * H3);
+    for (int i = threadIdx.x; i < H3 / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------ column sums
 // partial[y][n] = sum over the rows of chunk y.  Block = 64 columns x 4 row lanes.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
@@ -450,6 +474,23 @@ extern "C" int vqa_gru_bwd_b(const float* drh, const float* h_prev, const float*
     if (B == 0) return VQA_OK;
     hipLaunchKernelGGL(gru_bwd_b_kernel, dim3(grid_for((int64_t)B * H)), dim3(256), 0, (hipStream_t)stream, drh,
                        h_prev, r, dr_pre, ld_dr, dh_acc, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gru_fill_finished(float* hs, float* rh, const int32_t* len, int T, int B, int H, void* stream) {
+    VQA_REQUIRE(hs && rh && len && T >= 0 && B >= 0 && H > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0 && vqa_aligned16(hs) && vqa_aligned16(rh), VQA_ERR_ALIGN);
+    if (T == 0 || B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_fill_finished_kernel, dim3(B, T), dim3(256), 0, (hipStream_t)stream, hs, rh, len, T, B, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_gru_zero_finished(float* dxp, const int32_t* len, int T, int B, int H, void* stream) {
+    VQA_REQUIRE(dxp && len && T >= 0 && B >= 0 && H > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0 && vqa_aligned16(dxp), VQA_ERR_ALIGN);
+    if (T == 0 || B == 0) return VQA_OK;
+    hipLaunchKernelGGL(gru_zero_finished_kernel, dim3(B, T), dim3(256), 0, (hipStream_t)stream, dxp, len, T, B, 3 * H);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

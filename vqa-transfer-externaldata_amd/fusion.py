@@ -272,7 +272,11 @@ class FusionEngine:
             assert keep_att.dtype == torch.uint8 and keep_att.numel() == d.B * d.R * d.H
         if keep_joint is not None:
             assert keep_joint.dtype == torch.uint8 and keep_joint.numel() == d.B * 2 * d.H
-        self._batch_keepalive = (batch, keep_att, keep_joint)
+        live = batch.get("live_rows")
+        if live is not None:      # host int32[T]: rows sorted by length, longest first (input_ops_vqa.sort_by_length)
+            live = np.ascontiguousarray(live, dtype=np.int32)
+            assert live.shape == (d.T,) and (np.diff(live) <= 0).all() and 0 <= live[-1] and live[0] <= d.B
+        self._batch_keepalive = (batch, keep_att, keep_joint, live)
         am = self._amask
         return _lib.Batch(
             table=self._table.data_ptr(), nbox_table=self._nbox.data_ptr(),
@@ -281,7 +285,8 @@ class FusionEngine:
             train_mask=am["train"].data_ptr(), obj_mask=am["obj"].data_ptr(), attr_mask=am["attr"].data_ptr(),
             exist_mask=am["exist"].data_ptr(),
             keep_att=keep_att.data_ptr() if keep_att is not None else None,
-            keep_joint=keep_joint.data_ptr() if keep_joint is not None else None)
+            keep_joint=keep_joint.data_ptr() if keep_joint is not None else None,
+            live_rows=live.ctypes.data if live is not None else None)
 
     def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True):
         self._bs = self._batch_struct(batch, keep_att, keep_joint)

@@ -81,6 +81,28 @@ def synthetic_split(num_examples, num_images, vocab_size, num_answers, max_len=1
                      ans_scores, ans_off, num_answers)
 
 
+def sort_by_length(batch):
+    """The batch with its rows ordered by question length, longest first, plus `live_rows` (int32 [T]:
+    live_rows[t] = number of questions longer than t) and `sort_order` (the permutation applied).  Every
+    per-sample entry is permuted consistently, so losses, reports and results keyed by `id` are unchanged; the
+    engine then runs each GRU step on the still-running prefix only (vqa_gru_seq_*_live)."""
+    lens = np.asarray(batch["q_intseq_len"])
+    B, T = np.asarray(batch["q_intseq"]).shape
+    order = np.argsort(-lens.astype(np.int64), kind="stable")
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, np.ndarray) and v.shape[:1] == (B,):
+            out[k] = np.ascontiguousarray(v[order])
+        elif isinstance(v, (list, tuple)) and len(v) == B:
+            out[k] = [v[i] for i in order]
+        else:
+            out[k] = v
+    sl = np.clip(lens[order], 0, T)
+    out["live_rows"] = (sl[None, :] > np.arange(T)[:, None]).sum(1).astype(np.int32)
+    out["sort_order"] = order
+    return out
+
+
 def create(batch_size, data_dir, split, is_train=True, scope="vqa", shuffle=True, seed=0, data=None,
            repeat=1000):
     """Iterator of batch dicts; `data` (a SplitData) overrides the files under data_dir."""

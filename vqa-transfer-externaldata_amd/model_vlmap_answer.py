@@ -221,7 +221,10 @@ class Model(object):
 
     def _device_batch(self):
         b = self.batch
-        return {k: self._to_dev(b[k], dt) for k, dt in self._DEVICE_KEYS}
+        db = {k: self._to_dev(b[k], dt) for k, dt in self._DEVICE_KEYS}
+        if b.get("live_rows") is not None:      # rows sorted by length (input_ops_vqa.sort_by_length)
+            db["live_rows"] = b["live_rows"]
+        return db
 
     # ---------------------------------------------------------------- build = forward
     def build(self):

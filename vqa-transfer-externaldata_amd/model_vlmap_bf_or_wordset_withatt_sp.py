@@ -86,6 +86,9 @@ class Model(object):
                 out[k] = t.to(self.device)
         for k in ("image_ft", "spatial_ft"):
             out[k] = out[k].float()
+        if getattr(self.config, "sort_by_length", 1):
+            host = PT.add_length_sort({k: v for k, v in self.batch.items() if k.endswith(("/blanks", "/blanks_len"))})
+            out.update({k: v for k, v in host.items() if k.endswith("/sort")})
         for k in list(out):
             if k.endswith("_blank_fill/normal_boxes"):
                 out[k] = out[k].float()

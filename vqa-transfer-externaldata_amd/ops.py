@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -259,24 +260,41 @@ def embed_bwd_into(dx_tm, q, dE, lens=None):
                "vqa_embed_bwd_len")
 
 
-def gru_seq_fwd(xp, Wg_h, Wc_h, lens, T, B, H):
-    """Fused recurrence.  xp [T,B,3H] (x-projections + biases); returns hs [T+1,B,H] and the tape."""
+def _live_ptr(live_rows, T):
+    live = np.ascontiguousarray(live_rows, dtype=np.int32)
+    assert live.shape == (T,)
+    return live
+
+
+def gru_seq_fwd(xp, Wg_h, Wc_h, lens, T, B, H, live_rows=None):
+    """Fused recurrence.  xp [T,B,3H] (x-projections + biases); returns hs [T+1,B,H] and the tape.
+    live_rows (host int32 [T], rows sorted by length, longest first): run each step on the live prefix only."""
     lib = _lib.load()
     hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=xp.device)
     r, u, c, rh = (_f32(T, B, H, like=xp) for _ in range(4))
-    _lib.check(lib.vqa_gru_seq_fwd(_p(xp), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(rh), T, B, H,
-                                   _st(xp)), "vqa_gru_seq_fwd")
+    if live_rows is None:
+        _lib.check(lib.vqa_gru_seq_fwd(_p(xp), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(rh), T, B,
+                                       H, _st(xp)), "vqa_gru_seq_fwd")
+    else:
+        live = _live_ptr(live_rows, T)
+        _lib.check(lib.vqa_gru_seq_fwd_live(_p(xp), _p(Wg_h), _p(Wc_h), _p(lens), live.ctypes.data, _p(hs), _p(r), _p(u),
+                                            _p(c), _p(rh), T, B, H, _st(xp)), "vqa_gru_seq_fwd_live")
     return hs, (r, u, c, rh)
 
 
-def gru_seq_bwd(dh_T, Wg_h, Wc_h, lens, hs, tape, T, B, H):
-    """Returns dxp [T,B,3H] = (dr_pre | du_pre | dc_pre); dh_T is consumed."""
+def gru_seq_bwd(dh_T, Wg_h, Wc_h, lens, hs, tape, T, B, H, live_rows=None):
+    """Returns dxp [T,B,3H] = (dr_pre | du_pre | dc_pre); dh_T is consumed.  live_rows as in gru_seq_fwd."""
     lib = _lib.load()
     r, u, c, rh = tape
     dxp = _f32(T, B, 3 * H, like=hs)
     scratch = _f32(B, H, like=hs)
-    _lib.check(lib.vqa_gru_seq_bwd(_p(dh_T), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(dxp),
-                                   _p(scratch), T, B, H, _st(hs)), "vqa_gru_seq_bwd")
+    if live_rows is None:
+        _lib.check(lib.vqa_gru_seq_bwd(_p(dh_T), _p(Wg_h), _p(Wc_h), _p(lens), _p(hs), _p(r), _p(u), _p(c), _p(dxp),
+                                       _p(scratch), T, B, H, _st(hs)), "vqa_gru_seq_bwd")
+    else:
+        live = _live_ptr(live_rows, T)
+        _lib.check(lib.vqa_gru_seq_bwd_live(_p(dh_T), _p(Wg_h), _p(Wc_h), _p(lens), live.ctypes.data, _p(hs), _p(r),
+                                            _p(u), _p(c), _p(dxp), _p(scratch), T, B, H, _st(hs)), "vqa_gru_seq_bwd_live")
     return dxp
 
 

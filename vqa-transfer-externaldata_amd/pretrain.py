@@ -75,6 +75,25 @@ def init_random_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024):
     return p
 
 
+def add_length_sort(batch):
+    """Host-side: for each blank-fill category the permutation that orders the B*n captions by length (longest
+    first), its inverse and live_rows[t] = #captions longer than t.  The engine then embeds / encodes the
+    captions in that order, runs every GRU step on the live prefix only, and un-permutes the final states."""
+    for k in ("obj", "attr"):
+        kl, kb = k + "_blank_fill/blanks_len", k + "_blank_fill/blanks"
+        if kl not in batch or torch.is_tensor(batch[kl]):
+            continue
+        lens = np.asarray(batch[kl]).reshape(-1).astype(np.int64)
+        L = int(np.asarray(batch[kb]).shape[-1])
+        perm = np.argsort(-lens, kind="stable")
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(len(perm))
+        sl = np.clip(lens[perm], 0, L)
+        batch[k + "_blank_fill/sort"] = {"perm": perm, "inv": inv,
+                                         "live_rows": (sl[None, :] > np.arange(L)[:, None]).sum(1).astype(np.int32)}
+    return batch
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -203,15 +222,21 @@ class PretrainEngine:
             blanks = batch[k + "_blank_fill/blanks"].reshape(Bn, -1).to(torch.int32).contiguous()
             L = blanks.shape[1]
             lens = batch[k + "_blank_fill/blanks_len"].reshape(Bn).to(torch.int32).contiguous()
+            srt = batch.get(k + "_blank_fill/sort")
+            live = None
+            if srt is not None:        # captions in length order: the recurrence skips finished ones (add_length_sort)
+                perm = torch.as_tensor(srt["perm"], device=self.device)
+                kt["inv"], kt["perm"], live = torch.as_tensor(srt["inv"], device=self.device), perm, srt["live_rows"]
+                blanks, lens = blanks.index_select(0, perm).contiguous(), lens.index_select(0, perm).contiguous()
             x_tm = ops.embed_fwd(p["L_GloVe/embed_map"], blanks)                           # [L, Bn, W]
             Wg, Wc = p["encode_L_blank/rnn/gru_cell/gates/kernel"], p["encode_L_blank/rnn/gru_cell/candidate/kernel"]
             xp = torch.empty(L * Bn, 3 * H, dtype=torch.float32, device=self.device)
             x2 = x_tm.view(L * Bn, W)
             ops.gemm(x2, Wg[:W], bias=p["encode_L_blank/rnn/gru_cell/gates/bias"], out=xp[:, :2 * H])
             ops.gemm(x2, Wc[:W], bias=p["encode_L_blank/rnn/gru_cell/candidate/bias"], out=xp[:, 2 * H:])
-            hs, gtape = ops.gru_seq_fwd(xp, Wg[W:], Wc[W:], lens, L, Bn, H)
-            kt.update(blanks=blanks, lens=lens, x_tm=x_tm, hs=hs, gtape=gtape, L=L)
-            head(hs[L], ki, mk(k + "/bf_joint"), "blank_fill")
+            hs, gtape = ops.gru_seq_fwd(xp, Wg[W:], Wc[W:], lens, L, Bn, H, live_rows=live)
+            kt.update(blanks=blanks, lens=lens, x_tm=x_tm, hs=hs, gtape=gtape, L=L, live=live)
+            head(hs[L] if live is None else hs[L].index_select(0, kt["inv"]), ki, mk(k + "/bf_joint"), "blank_fill")
             # word set: tanh(embedding) -> FC + LN + tanh
             wsid = batch[k + "_blank_fill/wordsets"].reshape(Bn, 1).to(torch.int32).contiguous()
             wse = ops.embed_fwd(p["wordset_map/learn"], wsid).view(Bn, W)
@@ -271,7 +296,10 @@ class PretrainEngine:
             dbf = head_bwd("blank_fill")
             L = kt["L"]
             Wg, Wc = p["encode_L_blank/rnn/gru_cell/gates/kernel"], p["encode_L_blank/rnn/gru_cell/candidate/kernel"]
-            dxp = ops.gru_seq_bwd(dbf, Wg[W:], Wc[W:], kt["lens"], kt["hs"], kt["gtape"], L, Bn, H).view(L * Bn, 3 * H)
+            if kt.get("live") is not None:
+                dbf = dbf.index_select(0, kt["perm"]).contiguous()      # into the length-sorted caption order
+            dxp = ops.gru_seq_bwd(dbf, Wg[W:], Wc[W:], kt["lens"], kt["hs"], kt["gtape"], L, Bn, H,
+                                  live_rows=kt.get("live")).view(L * Bn, 3 * H)
             x2 = kt["x_tm"].view(L * Bn, W)
             hs_prev = kt["hs"][:L].reshape(L * Bn, H)
             rh = kt["gtape"][3].view(L * Bn, H)

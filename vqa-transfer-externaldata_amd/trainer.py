@@ -78,6 +78,8 @@ class Trainer(object):
         log.infov("using model class: {}".format(Model))
         config.global_batch = None
         first = self._shard(next(self._iters["train"]))
+        if getattr(config, "sort_by_length", 1):
+            first = (input_ops_vqa.sort_by_length(first[0]), first[1])
         self._dev_batches, self._dev_batch_bytes = {}, 0
         self._dev_batch_budget = int(getattr(config, "device_batch_cache_gb", 32)) << 30
         self._pending_train_batch, self._pending_global = first[0], None
@@ -142,6 +144,9 @@ class Trainer(object):
             batch, n_global = hit[1], hit[2]
         else:
             batch, n_global = self._shard(raw)
+            if getattr(self.config, "sort_by_length", 1):
+                # longest question first: every GRU step then runs on the still-running rows only
+                batch = input_ops_vqa.sort_by_length(batch)
             if self._dev_batch_bytes < self._dev_batch_budget:
                 batch = self.model.to_device_batch(batch)
                 self._dev_batches[id(raw)] = (raw, batch, n_global)
@@ -296,6 +301,11 @@ def build_parser():
     parser.add_argument("--vlmap_word_weight_dir", type=str, default=None, help=" ")
     parser.add_argument("--ft_vlmap", action="store_true", default=False)
     parser.add_argument("--seed", type=int, default=123, help=" ")
+    parser.add_argument("--sort_by_length", type=int, default=1,
+                        help="order every batch by question length so the GRU skips finished sequences (not in the "
+                             "reference; results are unchanged)")
+    parser.add_argument("--device_batch_cache_gb", type=int, default=32,
+                        help="keep the cached padded batches on the device up to this many GiB (not in the reference)")
     parser.add_argument("--debug", type=int, default=0, help="0: normal, 1: debug")
     return parser
 
