@@ -923,7 +923,7 @@ int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_bl
 // vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
 int g_gru_cfg = -1;
 // Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
-inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 10 : 18); }
+inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 10 : rows > 256 ? 18 : 16); }
 inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : 16); }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
