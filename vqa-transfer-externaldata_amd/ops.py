@@ -115,7 +115,8 @@ def ln_relu_bwd(dy, pre, mean, rstd, gamma, beta, rows=1, keepmask=None, keep_pr
                                    _p(dpre), _p(pg), _p(pb), _p(pbias), G, rows, N, _st(pre)), "vqa_ln_relu_bwd")
     if not want_params:
         return dpre, None, None, None
-    return dpre, colsum(pg), colsum(pb), colsum(pbias)
+    dgamma, dbeta, dbias = colsum3(pg, pb, pbias)
+    return dpre, dgamma, dbeta, dbias
 
 
 def attn_pool_fwd(v, qv, V, nb, w, bias, keepmask=None, keep_prob=1.0):
@@ -192,7 +193,8 @@ def ln_act_bwd(dy, pre, mean, rstd, gamma, beta, rows=1, act="relu", keepmask=No
     _lib.check(lib.vqa_ln_act_bwd(_p(dy), _p(pre), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(keepmask), keep_prob,
                                   _p(dpre), _p(pg), _p(pb), _p(pbias), G, rows, N, 0 if act == "relu" else 1,
                                   _st(pre)), "vqa_ln_act_bwd")
-    return dpre, colsum(pg), colsum(pb), colsum(pbias)
+    dgamma, dbeta, dbias = colsum3(pg, pb, pbias)        # one pair of launches instead of three
+    return dpre, dgamma, dbeta, dbias
 
 
 def attn_pool_fwd_rep(v, qv, V, nb, w, bias, rep, keepmask=None, keep_prob=1.0):
