@@ -311,11 +311,14 @@ int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* params, cons
  *   y = [relu]( conv(x, w) * scale[co] + shift[co] + residual )
  * x [B,Hi,Wi,Ci], w HWIO [kh,kw,Ci,Co] (TF layout), explicit top/left zero padding, output
  * [B,Ho,Wo,Co]; scale/shift/residual may be NULL.  1x1/stride-1 -> plain MFMA GEMM, otherwise an
- * implicit GEMM (needs Ci % 32 == 0).  Replaces slim conv2d/conv2d_same + batch_norm(is_training=
+ * implicit GEMM (needs Ci % 32 == 0, or Ci == 4 with kh*kw*4 a multiple of 32).  Replaces slim conv2d/conv2d_same + batch_norm(is_training=
  * False) + relu of resnet_v1 (vlmap/modules.py:143-191) and modules.conv2d (:552-572). */
 int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co,
                     int stride, int pad_t, int pad_l, int Ho, int Wo, const float* scale, const float* shift,
                     const float* residual, int relu, float* y, void* stream);
+/* y [B,Hi,Wi,4] = (x [B,Hi,Wi,3] - mean_host, 0): 16-byte pixels, so that conv1 (7x7/2 on RGB, vlmap/modules.py:170-190)
+ * runs through vqa_conv2d_nhwc as an implicit GEMM with Ci = 4 and an 8-wide zero-padded filter row (K = 7*8*4). */
+int vqa_pad_c3c4_nhwc(const float* x, int B, int Hi, int Wi, const float* mean_host, float* y, void* stream);
 /* explicit im2col for the 3-channel conv1 (7x7/2): col [B*Ho*Wo, Kpad], zero in the K padding;
  * mean_host (3 floats on the HOST, may be NULL) is subtracted from in-bounds pixels only
  * (the RGB mean subtraction of vlmap/modules.py:170-174 precedes the zero padding). */

@@ -99,6 +99,7 @@ SIGNATURES = {
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
     "vqa_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "vqa_im2col_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _P]),
+    "vqa_pad_c3c4_nhwc": (_I, [_P, _I, _I, _I, C.POINTER(C.c_float), _P, _P]),
     "vqa_maxpool3x3s2_same_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "vqa_subsample_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "vqa_crop_and_resize_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),

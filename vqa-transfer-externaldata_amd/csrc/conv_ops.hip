@@ -117,7 +117,27 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restric
     }
 }
 
+// y[b,h,w,0:3] = x[b,h,w,0:3] - mean, y[b,h,w,3] = 0: one 16-byte pixel per lane, so that a filter ROW of conv1
+// (7 taps x 3 channels) becomes 8 x 4 = 32 contiguous floats and conv1 runs as an implicit GEMM (no im2col)
+__global__ __launch_bounds__(256) void pad_c3c4_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t npix,
+                                                       float m0, float m1, float m2) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+        const float* s = x + i * 3;
+        reinterpret_cast<float4*>(y)[i] = make_float4(s[0] - m0, s[1] - m1, s[2] - m2, 0.f);
+    }
+}
+
 }  // namespace
+
+extern "C" int vqa_pad_c3c4_nhwc(const float* x, int B, int Hi, int Wi, const float* mean_host, float* y, void* stream) {
+    VQA_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_aligned16(y), VQA_ERR_ALIGN);
+    const int64_t npix = (int64_t)B * Hi * Wi;
+    hipLaunchKernelGGL(pad_c3c4_kernel, dim3(grid_for(npix, 65536)), dim3(256), 0, (hipStream_t)stream, x, y, npix,
+                       mean_host ? mean_host[0] : 0.f, mean_host ? mean_host[1] : 0.f, mean_host ? mean_host[2] : 0.f);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
 
 extern "C" int vqa_im2col_nhwc(const float* x, int B, int Hi, int Wi, int Ci, int kh, int kw, int stride, int pad_t,
                                int pad_l, int Ho, int Wo, const float* mean_host, float* col, int Kpad, void* stream) {

@@ -183,15 +183,30 @@ struct Stager {
     // wave-uniform and each lane only adds it to its pre-decoded pixel coordinates.
     __device__ __forceinline__ void load_conv(__amdgpu_buffer_rsrc_t rs, const int (&iy0)[NV], const int (&ix0)[NV],
                                               const int (&pix)[NV], int k0, int Hi, int Wi, int Ci, int kw) {
-        const int tap = k0 / Ci, c0 = k0 - tap * Ci;
-        const int ky = tap / kw, kx = tap - ky * kw;
+        if (Ci >= BK) {
+            const int tap = k0 / Ci, c0 = k0 - tap * Ci;
+            const int ky = tap / kw, kx = tap - ky * kw;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * NT;
-            const int kq = (idx % KQ) * 4;
-            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-            const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
-            reg[i] = bload(rs, in ? (unsigned)((((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq) * 4) : OOB);
+            for (int i = 0; i < NV; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int kq = (idx % KQ) * 4;
+                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+                reg[i] = bload(rs, in ? (unsigned)((((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c0 + kq) * 4) : OOB);
+            }
+        } else {
+            // few channels (conv1 on 4-channel pixels): a k tile spans BK / Ci filter taps, so the tap -- and the
+            // in-image test -- is per lane; Ci % 4 == 0 keeps every 16-byte load inside one tap
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int k = k0 + (idx % KQ) * 4;
+                const int tap = k / Ci, c = k - tap * Ci;
+                const int ky = tap / kw, kx = tap - ky * kw;
+                const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+                const bool in = (pix[i] >= 0) && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+                reg[i] = bload(rs, in ? (unsigned)((((int64_t)(pix[i] + iy * Wi + ix)) * Ci + c) * 4) : OOB);
+            }
         }
     }
     // implicit im2col, steady-state form: per-lane pixel base and a bit mask of the filter taps that
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         }
         __syncthreads();
         int t = 0;
-        if (CONV && p.conv_taps <= 32) {
+        if (CONV && p.conv_taps <= 32 && p.Ci % BK == 0) {
             // every k tile of a convolution is full (Ci % BK == 0): same two-per-trip loop as below,
             // the A tile through the tap-mask loader, the filter matrix through scalar offsets
             unsigned cbase[NVA], cmask[NVA];
@@ -1241,7 +1256,8 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
         const int cfg = (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) ? g_force_cfg : 3;
         return launch_by_id(cfg, 0, 0, a, 1, st, 0);
     }
-    VQA_REQUIRE(Ci % 32 == 0 && vqa_aligned16(x), VQA_ERR_ALIGN);   // one 32-deep k tile per filter tap
+    // one 32-deep k tile per filter tap, or 4-channel pixels with a K that is a whole number of tiles (conv1)
+    VQA_REQUIRE((Ci % 32 == 0 || (Ci == 4 && K % 32 == 0)) && vqa_aligned16(x), VQA_ERR_ALIGN);
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
     a.kw = kw;
     a.conv_taps = kh * kw;

@@ -86,8 +86,12 @@ def _st(t):
 class ConvBN:
     """conv weights (HWIO) + BatchNorm folded to scale/shift, resident on the device."""
 
-    def __init__(self, params, prefix, eps, device, wname="/weights", bn="/BatchNorm/", pad_k_to=None):
+    def __init__(self, params, prefix, eps, device, wname="/weights", bn="/BatchNorm/", pad_k_to=None, pad_taps_to=None):
         w = np.asarray(params[prefix + wname], np.float32)
+        if pad_taps_to is not None:       # zero taps / channels: [kh,kw,ci,co] -> [KH,KW,CI,co]
+            wp = np.zeros(tuple(pad_taps_to) + (w.shape[3],), np.float32)
+            wp[:w.shape[0], :w.shape[1], :w.shape[2]] = w
+            w = wp
         self.kh, self.kw, self.ci, self.co = w.shape
         g, b, m, v = (np.asarray(params[prefix + bn + k], np.float64)
                       for k in ("gamma", "beta", "moving_mean", "moving_variance"))
@@ -153,7 +157,7 @@ class ResNetV1:
             raise _lib.VqaHotError("ResNetV1 needs a GPU (no CPU fallback)")
         self.device = torch.device(device)
         self.blocks = blocks
-        self.conv1 = ConvBN(params, scope + "/conv1", SLIM_BN_EPS, self.device, pad_k_to=148)   # K = 147 -> 148
+        self.conv1 = ConvBN(params, scope + "/conv1", SLIM_BN_EPS, self.device, pad_taps_to=(7, 8, 4))   # [7,7,3,Co] -> [7,8,4,Co]
         self.units = []
         cin = self.conv1.co
         for name, base, n, stride in blocks:
@@ -174,14 +178,12 @@ class ResNetV1:
         B, H, W, Cc = images.shape
         assert Cc == 3 and images.dtype == torch.float32 and images.is_contiguous()
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1          # conv2d_same(7, stride 2): pad 3/3, VALID
-        col = torch.empty(B * Ho * Wo, 148, dtype=torch.float32, device=images.device)
-        _lib.check(lib.vqa_im2col_nhwc(_p(images), B, H, W, 3, 7, 7, 2, 3, 3, Ho, Wo, self._mean, _p(col), 148,
-                                       _st(images)), "vqa_im2col_nhwc")
-        cb = self.conv1
-        one = ConvBN.__new__(ConvBN)
-        one.kh = one.kw = 1
-        one.ci, one.co, one.w, one.scale, one.shift = 148, cb.co, cb.w, cb.scale, cb.shift
-        y = conv2d(col.view(1, B * Ho * Wo, 1, 148), one, relu=True).view(B, Ho, Wo, cb.co)
+        # conv1 as an implicit GEMM: mean-subtracted RGB padded to 16-byte pixels (the zero padding of the
+        # convolution is the loader's out-of-range zero, so the mean is only subtracted inside the image), filter
+        # rows padded from 7 to 8 taps -> one k tile = one filter row, K = 7 * 8 * 4 = 224
+        x4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=images.device)
+        _lib.check(lib.vqa_pad_c3c4_nhwc(_p(images), B, H, W, self._mean, _p(x4), _st(images)), "vqa_pad_c3c4_nhwc")
+        y = conv2d(x4, self.conv1, stride=2, pad=(3, 3), out_hw=(Ho, Wo), relu=True)
         return max_pool_3x3_s2_same(y)
 
     def bottleneck(self, x, u):
