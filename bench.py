@@ -125,7 +125,7 @@ def pmc_traffic():
     return None
 
 
-def vfeat_bench(device, batch=64, iters=3):
+def vfeat_bench(device, batch=128, iters=3):
     """vfeat imgs/sec (second half of BASELINE.json's metric): slim-style ResNet-101 blocks 1-4 on
     synthetic 448x448 images + 1x1 crop_and_resize of 36 boxes -> [36, 2048] per image (BASELINE
     configs[2] extractor; random-init He weights, identity-ish BN statistics)."""
