@@ -345,8 +345,8 @@ int vqa_probe_read(float* ms_out, int capacity, int* n_out);
 int vqa_probe_disable(void);
 
 /* The same in dependency-ordered phases (bit mask): 1 = head..attention..v_linear_v / q_linear_v /
- * score gradients, 2 = GRU BPTT + embedding gradient + slice sum of squares, 4 = GRU weight / bias
- * gradients.  A data-parallel caller launches one phase, starts the all-reduce of the bucket that
+ * score gradients, 2 = GRU BPTT + embedding gradient + slice sum of squares, 4 = GRU gate weight / bias
+ * gradients, 8 = GRU candidate weight / bias gradients (15 = everything).  A data-parallel caller launches one phase, starts the all-reduce of the bucket that
  * phase completed, and launches the next phase meanwhile. */
 int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_params_t* params, const vqa_params_t* grads,
                                const vqa_batch_t* batch, void* workspace, int64_t workspace_bytes,

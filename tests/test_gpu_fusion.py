@@ -276,7 +276,7 @@ def test_repeated_runs_are_bitwise_identical():
 
 
 def test_phased_backward_equals_monolithic_and_bucket_layout():
-    """vqa_fusion_backward_phases(1|2|4 in order) == vqa_fusion_backward, and the flat layout puts the
+    """vqa_fusion_backward_phases(1|2|4|8 in order) == vqa_fusion_backward, and the flat layout puts the
     buckets where FusionEngine.backward(reducer=...) slices them."""
     dims, B, R, T, N = MED, 48, 36, 14, 64
     for mt in ("vlmap_answer", "standard"):
@@ -303,9 +303,10 @@ def test_phased_backward_equals_monolithic_and_bucket_layout():
         assert torch.equal(ref[eng.n_train], eng.grad_flat[eng.n_train])         # slice sum of squares
         cnt = eng._train_tab[eng.train_names[0]][1]
         assert torch.allclose(ref[:cnt], eng.grad_flat[:cnt], rtol=1e-4, atol=1e-7)   # atomics: order varies
-        # buckets: rest, embed, tail, gru -- disjoint and covering the whole buffer
+        # buckets: rest, embed, tail, GRU gates, GRU candidate -- disjoint and covering the whole buffer
         offs, lens = seen[0::2], seen[1::2]
-        assert offs == [eng.gru_end, 0, eng.n_train, emb] and sum(lens) == eng.grad_flat.numel()
+        assert offs == [eng.gru_end, 0, eng.n_train, eng.gru_mid, emb] and sum(lens) == eng.grad_flat.numel()
+        assert emb < eng.gru_mid < eng.gru_end
         gru_names = [n for n in eng.train_names if n.startswith("encode_L/")]
         for n in gru_names:
             off = eng._train_tab[n][0]

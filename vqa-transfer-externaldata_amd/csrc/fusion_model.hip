@@ -372,13 +372,14 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
 extern "C" int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_params_t* G,
                                    const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
                                    float* embed_slice_sq, void* stream) {
-    return vqa_fusion_backward_phases(dims, P, G, bt, workspace, workspace_bytes, embed_slice_sq, 7, stream);
+    return vqa_fusion_backward_phases(dims, P, G, bt, workspace, workspace_bytes, embed_slice_sq, 15, stream);
 }
 
 // phases (bit mask), in dependency order:
 //   1  head .. attention .. v_linear_v / q_linear_v / score gradients      (complete after this phase)
 //   2  GRU back-propagation through time, dx, embedding scatter-add, slice sum of squares
-//   4  GRU weight / bias gradients
+//   4  GRU gate weight / bias gradients (the larger half, 10.8 MB at H 1024)
+//   8  GRU candidate weight / bias gradients (5.4 MB) -- the only all-reduce nothing is left to overlap with
 // so a data-parallel caller can start all-reducing each gradient bucket while the next phase runs.
 extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_params_t* G,
                                           const vqa_batch_t* bt, void* workspace, int64_t workspace_bytes,
@@ -469,16 +470,16 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
     }   // phase 2
 
-    if (phases & 4) {
-    if (G->gru_wg != nullptr) {
+    if ((phases & 4) && G->gru_wg != nullptr) {
         TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
+        TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
+    }   // phase 3: gates
+    if ((phases & 8) && G->gru_wg != nullptr) {
         TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)W, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
         TRY(gemm(c, 1, 0, H, H, T * B, c.f("gru_rh"), (int)H, dxp + 2 * H, (int)(3 * H), G->gru_wc + W * H, (int)H));
-        TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
         TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
-    }
-    }   // phase 3
+    }   // phase 4: candidate
     return VQA_OK;
 }
 

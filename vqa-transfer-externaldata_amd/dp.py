@@ -74,7 +74,8 @@ class BucketedAllReduce:
     the collective stream waits (event) for the compute stream at the point of the call, i.e. for the phase
     that produced the bucket, and runs beside the next phase; finish() makes the compute stream wait for
     all of them before the optimizer.  Buckets: everything-but-GRU/embedding (9-60 MB), embedding table
-    (19.7 MB at Vq = 16384) + slice sum of squares, GRU weights (16.3 MB)."""
+    (19.7 MB at Vq = 16384) + slice sum of squares, GRU gate weights (10.8 MB), GRU candidate weights (5.4 MB, the
+    only one with nothing left to hide behind)."""
 
     def __init__(self, group=None):
         self.group = group

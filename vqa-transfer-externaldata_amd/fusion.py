@@ -135,6 +135,10 @@ class FusionEngine:
         gru = [n for n in self.train_names if n.startswith("encode_L/")]
         assert self.train_names[1:1 + len(gru)] == gru, "flat layout: encode_L/* must follow the embedding"
         self.gru_end = self.embed_floats + sum(_pad4(int(np.prod(self.shapes[n]))) for n in gru)
+        # ... and inside it [candidate/* | gates/*]: the gate half is reduced while the candidate half is computed
+        cand = [n for n in gru if "/candidate/" in n]
+        assert gru[:len(cand)] == cand, "flat layout: candidate/* precede gates/*"
+        self.gru_mid = self.embed_floats + sum(_pad4(int(np.prod(self.shapes[n]))) for n in cand)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.train_flat = torch.zeros(self.n_train, **f32)
         self.frozen_flat = torch.zeros(max(self.n_frozen, 4), **f32)
@@ -305,21 +309,23 @@ class FusionEngine:
         """All gradients into grad_flat.  With a bucketed `reducer` (dp.BucketedAllReduce) the three
         dependency-ordered phases are launched one by one and each finished bucket's all-reduce is started
         right away, so it overlaps the next phase: [everything but GRU/embedding] during BPTT, the
-        embedding bucket (+ slice sum of squares) during the GRU weight-gradient GEMMs; only the GRU
-        bucket's reduction is exposed."""
+        embedding bucket (+ slice sum of squares) and the GRU gate bucket during the GRU weight-gradient GEMMs;
+        only the GRU candidate bucket's reduction (5.4 MB) is exposed."""
         # only the embedding gradient is scatter-added; everything else is overwritten
         self.grad_flat[:self.embed_floats].zero_()
         if reducer is None:
-            self._backward_phases(7)
+            self._backward_phases(15)
             return
-        e, g, n = self.embed_floats, self.gru_end, self.n_train
+        e, m, g, n = self.embed_floats, self.gru_mid, self.gru_end, self.n_train
         self._backward_phases(1)
         reducer.start(self.grad_flat[g:n])
         self._backward_phases(2)
         reducer.start(self.grad_flat[:e])
         reducer.start(self.grad_flat[n:])
         self._backward_phases(4)
-        reducer.start(self.grad_flat[e:g])
+        reducer.start(self.grad_flat[m:g])        # GRU gates (10.8 MB) reduce under the candidate GEMMs
+        self._backward_phases(8)
+        reducer.start(self.grad_flat[e:m])        # GRU candidate (5.4 MB): the only exposed reduction
         reducer.finish()
 
     def optimizer_step(self, lr):
