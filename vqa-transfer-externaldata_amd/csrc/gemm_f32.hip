@@ -332,13 +332,21 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     // latency (~2 us for the [T,B,3H] x-projection, written long before) hides under the loop
     // instead of sitting between the last MFMA and the first store.
     static_assert(EPI == EPI_PLAIN || (TM == 1 && TN == 1), "fused epilogues: one 32x32 tile per wave");
-    float4 e_d[4], e_x0[4], e_x1[4], e_x2[4];
-    int e_lim[4];
-    if (EPI != EPI_PLAIN && wk == 0) {
+    // ... and every k group finishes ITS share of the 32 rows of its (m, n) sub-tile (rows wk*RPG .. +RPG): the
+    // partial tiles of all groups meet in LDS and each wave sums, activates and stores RPG rows, instead of group
+    // 0 doing all 32 while the other waves of the workgroup have already retired.
+    constexpr int RPG = (EPI != EPI_PLAIN) ? 32 / WGK : 32;   // rows per k group
+    constexpr int NI = RPG >= 8 ? RPG / 8 : 1;                // 8-row slabs per wave (a lane owns 4 columns of a row)
+    const int e_lr = lane >> 3;
+    const bool e_act = (RPG >= 8) || (e_lr < RPG);
+    const int e_row0 = wk * RPG + e_lr;                       // row inside the 32x32 sub-tile (+ 8 i)
+    float4 e_d[NI], e_x0[NI], e_x1[NI], e_x2[NI];
+    int e_lim[NI];
+    if (EPI != EPI_PLAIN && e_act) {
         const int gcol = n0 + wn * WN + (lane & 7) * 4;
-        const int grow0 = m0 + wm * WM + (lane >> 3);
+        const int grow0 = m0 + wm * WM + e_row0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int grow = grow0 + 8 * i;
             e_d[i] = e_x0[i] = e_x1[i] = e_x2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             e_lim[i] = 0;
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         __syncthreads();
     }
 
-    if (WGK > 1) {
+    if (WGK > 1 && EPI == EPI_PLAIN) {
         // in-block split-k: groups 1..WGK-1 park their partial tiles in LDS (the operand tiles are
         // dead after the loop's last barrier), group 0 sums them.  Lane-contiguous => conflict-free.
         constexpr int PER_WAVE = TM * TN * 16 * 64;
@@ -691,86 +699,93 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         continue;   // next tile (the loop's last barrier already fenced the LDS tiles)
     }
 
-    // Fused GRU epilogues: the accumulator tile is transposed through LDS (own 32 x 36 region per
-    // wave, no barrier needed) so every lane owns 4 consecutive columns of a row: all side inputs
-    // and outputs move as 16-byte, line-contiguous accesses, loads first, then math, then stores.
+    // Fused GRU epilogues: every wave parks its accumulator tile, TRANSPOSED, in its own 32 x 36 LDS patch
+    // ([k group][sub-tile]; the operand tiles are dead after the loop's last barrier), so a lane owns 4 consecutive
+    // columns of a row: side inputs and outputs move as 16-byte, line-contiguous accesses.  After one barrier
+    // wave (wk, wm, wn) sums the WGK partial patches of ITS rows in group order (deterministic) and finishes them.
     constexpr int STG_LD = 36;
-    constexpr int RED_FL = (WGK - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64;
-    float* stg = smem + RED_FL + (wm * WAVES_N + wn) * 32 * STG_LD;
+    constexpr int SUBS = WAVES_M * WAVES_N;
+    const int sub = wm * WAVES_N + wn;
+    float* stg = smem + (wk * SUBS + sub) * 32 * STG_LD;
     const int H = ep.H;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int r = 0; r < 16; ++r)
+        stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (lane & 31)] = acc[0][0][r];
+    if (WGK > 1) __syncthreads();
+    if (e_act) {
+        const int c4 = (lane & 7) * 4;
+        const int gcol = n0 + wn * WN + c4;
+        const int grow0 = m0 + wm * WM + e_row0;
+        float4 v[NI];
+        bool ok[NI];
+        const float4 (&d)[NI] = e_d;
+        const float4 (&x0)[NI] = e_x0;
+        const float4 (&x1)[NI] = e_x1;
+        const float4 (&x2)[NI] = e_x2;
+        const int (&lim)[NI] = e_lim;
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
+        for (int i = 0; i < NI; ++i) {
+            const int grow = grow0 + 8 * i;
+            ok[i] = (grow < p.M) && (gcol < p.N);
+            const float* src = smem + sub * 32 * STG_LD + (e_row0 + 8 * i) * STG_LD + c4;
+            float4 t = *reinterpret_cast<const float4*>(src);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (lane & 31)] = acc[a][b][r];
-            const int c4 = (lane & 7) * 4;
-            const int gcol = n0 + wn * WN + b * 32 + c4;
-            const int grow0 = m0 + wm * WM + a * 32 + (lane >> 3);
-            float4 v[4];
-            bool ok[4];
-            const float4 (&d)[4] = e_d;
-            const float4 (&x0)[4] = e_x0;
-            const float4 (&x1)[4] = e_x1;
-            const float4 (&x2)[4] = e_x2;
-            const int (&lim)[4] = e_lim;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int grow = grow0 + 8 * i;
-                ok[i] = (grow < p.M) && (gcol < p.N);
-                v[i] = *reinterpret_cast<const float4*>(stg + ((lane >> 3) + 8 * i) * STG_LD + c4);
+            for (int g = 1; g < WGK; ++g) {
+                const float4 q = *reinterpret_cast<const float4*>(src + g * SUBS * 32 * STG_LD);
+                t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
             }
+            v[i] = t;
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!ok[i]) continue;
-                const int grow = grow0 + 8 * i;
-                const int64_t o = (int64_t)grow * H + gcol;
-                const float vv[4] = {v[i].x + d[i].x, v[i].y + d[i].y, v[i].z + d[i].z, v[i].w + d[i].w};
-                const float a0[4] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w};
-                const float a1[4] = {x1[i].x, x1[i].y, x1[i].z, x1[i].w};
-                const float a2[4] = {x2[i].x, x2[i].y, x2[i].z, x2[i].w};
-                float r0[4], r1[4], r2[4];
+        for (int i = 0; i < NI; ++i) {
+            if (!ok[i]) continue;
+            const int grow = grow0 + 8 * i;
+            const int64_t o = (int64_t)grow * H + gcol;
+            const float vv[4] = {v[i].x + d[i].x, v[i].y + d[i].y, v[i].z + d[i].z, v[i].w + d[i].w};
+            const float a0[4] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w};
+            const float a1[4] = {x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+            const float a2[4] = {x2[i].x, x2[i].y, x2[i].z, x2[i].w};
+            float r0[4], r1[4], r2[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (EPI == EPI_GATES) {
-                        r0[j] = sigmoidf_stable(vv[j]);
-                        r1[j] = r0[j] * a0[j];
-                    } else if (EPI == EPI_CAND) {
-                        r0[j] = tanhf(vv[j]);
-                        r1[j] = (ep.t < lim[i]) ? (a1[j] * a0[j] + (1.f - a1[j]) * r0[j]) : a0[j];
-                    } else if (EPI == EPI_BWD_RH) {
-                        r0[j] = vv[j] * a0[j] * a1[j] * (1.f - a1[j]);
-                        r1[j] = a2[j] + vv[j] * a1[j];
-                    } else {
-                        const bool live = ep.t < lim[i];
-                        r0[j] = live ? vv[j] * (1.f - a1[j]) * (1.f - a2[j] * a2[j]) : 0.f;
-                        r1[j] = live ? vv[j] * (a0[j] - a2[j]) * a1[j] * (1.f - a1[j]) : 0.f;
-                        r2[j] = live ? vv[j] * a1[j] : vv[j];
-                    }
-                }
-                const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]);
-                const float4 q1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            for (int j = 0; j < 4; ++j) {
                 if (EPI == EPI_GATES) {
-                    if (gcol < H) {
-                        *reinterpret_cast<float4*>(ep.o0 + o) = q0;       // r
-                        *reinterpret_cast<float4*>(ep.o2 + o) = q1;       // r * h_prev
-                    } else {
-                        *reinterpret_cast<float4*>(ep.o1 + o - H) = q0;   // u
-                    }
+                    r0[j] = sigmoidf_stable(vv[j]);
+                    r1[j] = r0[j] * a0[j];
                 } else if (EPI == EPI_CAND) {
-                    *reinterpret_cast<float4*>(ep.o0 + o) = q0;           // c
-                    *reinterpret_cast<float4*>(ep.o1 + o) = q1;           // h_new
+                    r0[j] = tanhf(vv[j]);
+                    r1[j] = (ep.t < lim[i]) ? (a1[j] * a0[j] + (1.f - a1[j]) * r0[j]) : a0[j];
                 } else if (EPI == EPI_BWD_RH) {
-                    *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dr_pre
-                    *reinterpret_cast<float4*>(ep.o1 + o) = q1;                                // dh_acc
+                    r0[j] = vv[j] * a0[j] * a1[j] * (1.f - a1[j]);
+                    r1[j] = a2[j] + vv[j] * a1[j];
                 } else {
-                    *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dc_pre
-                    *reinterpret_cast<float4*>(ep.o1 + (int64_t)grow * ep.ldo + gcol) = q1;   // du_pre
-                    *reinterpret_cast<float4*>(ep.o2 + o) = make_float4(r2[0], r2[1], r2[2], r2[3]);
+                    const bool live = ep.t < lim[i];
+                    r0[j] = live ? vv[j] * (1.f - a1[j]) * (1.f - a2[j] * a2[j]) : 0.f;
+                    r1[j] = live ? vv[j] * (a0[j] - a2[j]) * a1[j] * (1.f - a1[j]) : 0.f;
+                    r2[j] = live ? vv[j] * a1[j] : vv[j];
                 }
+            }
+            const float4 q0 = make_float4(r0[0], r0[1], r0[2], r0[3]);
+            const float4 q1 = make_float4(r1[0], r1[1], r1[2], r1[3]);
+            if (EPI == EPI_GATES) {
+                if (gcol < H) {
+                    *reinterpret_cast<float4*>(ep.o0 + o) = q0;       // r
+                    *reinterpret_cast<float4*>(ep.o2 + o) = q1;       // r * h_prev
+                } else {
+                    *reinterpret_cast<float4*>(ep.o1 + o - H) = q0;   // u
+                }
+            } else if (EPI == EPI_CAND) {
+                *reinterpret_cast<float4*>(ep.o0 + o) = q0;           // c
+                *reinterpret_cast<float4*>(ep.o1 + o) = q1;           // h_new
+            } else if (EPI == EPI_BWD_RH) {
+                *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dr_pre
+                *reinterpret_cast<float4*>(ep.o1 + o) = q1;                                // dh_acc
+            } else {
+                *reinterpret_cast<float4*>(ep.o0 + (int64_t)grow * ep.ldo + gcol) = q0;   // dc_pre
+                *reinterpret_cast<float4*>(ep.o1 + (int64_t)grow * ep.ldo + gcol) = q1;   // du_pre
+                *reinterpret_cast<float4*>(ep.o2 + o) = make_float4(r2[0], r2[1], r2[2], r2[3]);
             }
         }
+    }
     }   // tile loop
 }
 
@@ -795,8 +810,9 @@ template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, 
           bool EDGE = false, int NT = 256>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
-    constexpr size_t red = (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float);
-    constexpr size_t stage = (size_t)(BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);   // epilogue transpose patches
+    constexpr size_t red = (EPI == EPI_PLAIN) ? (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float) : 0;
+    // epilogue transpose patches: one per (m, n) wave slot, and per k group as well for the fused epilogues
+    constexpr size_t stage = (size_t)(EPI == EPI_PLAIN ? 1 : WGK) * (BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE, NT>;
     static bool attr_done = false;
@@ -932,14 +948,15 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
 // Tile config of the fused GRU-step GEMMs: many waves with small per-wave tiles (32x32), in-block split-k and two
-// tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU
-// (recurrence at B 512, H 1024, T 14: 622 -> 560 us forward, 607 -> 528 us backward).  Forward: one 16-wave
-// workgroup per CU (cfg 18); backward: 32x32 tiles, 4 waves, 4 k groups (cfg 16).
+// tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU, and
+// every k group finishes its share of the rows in the epilogue (recurrence at B 512, H 1024, T 14: 622 -> 523 us
+// forward, 607 -> 487 us backward).  Default: one 16-wave workgroup per CU (cfg 18), 32x32 tiles / 4 waves
+// (cfg 16) once the live prefix is down to 256 rows, plain 4-wave tiles for tall batches.
 // vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
 int g_gru_cfg = -1;
 // Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
 inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 10 : rows > 256 ? 18 : 16); }
-inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : 16); }
+inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 256 ? 18 : 16); }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
 //  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, EIGHT waves
