@@ -4,12 +4,18 @@ GPU (BASELINE.json configs[1]) -- one pass of the hot path (forward, backward,
 global-norm clip, Adam) over one synthetic batch per step, inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of
-     the flat gradient buffer; weak scaling = 512 samples per GPU)
+
+N > 1: one rank per GPU, RCCL all-reduce of the gradient buckets overlapped with
+backward; weak scaling = 512 samples per GPU.  Either the driver launches the ranks
+(`python -m torch.distributed.run ... bench.py --gpus N`, WORLD_SIZE set) or a plain
+`python bench.py --gpus N` starts them itself: the parent spawns torch.distributed.run
+as a CHILD process before it touches the GPU (a process that has initialised the GPU is
+never re-exec'ed) and forwards rank 0's JSON line.
 
 Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel (the
 v_linear_v forward GEMM, timed with HIP events on its own stream inside the timed
-region) and a `cpu_baseline` (torch-CPU port of the same step on the host cores).
+region), a `cpu_baseline` (torch-CPU port of the same step on the host cores), the
+extractor throughput `vfeat` and the end-to-end leg `e2e` (BASELINE configs[2]).
 """
 from __future__ import annotations
 
@@ -17,11 +23,10 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -32,9 +37,41 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA peak 
 CFG = dict(B=512, R=36, D=2048, H=1024, T=14, W=300, A=3000, Vq=16384, N_img=8192, num_train_answer=2250)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vfeat", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--probe", type=str, default="v_linear_v.fwd_gemm")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as children of a fresh
+    torch.distributed.run process.  Nothing in this parent has touched the GPU (torch is not even imported)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
+
+
 def synth_params(model_type, cfg, seed):
     """Random-init weights of the architecture: Xavier-uniform FCs, GRU
     gate bias 1.0, embeddings U(-0.01, 0.01)."""
+    import torch
     from vqa_transfer_externaldata_amd import fusion as F
     g = torch.Generator().manual_seed(seed)
     shapes = F.variable_shapes(model_type, cfg["Vq"], cfg["W"], cfg["D"], cfg["H"], cfg["A"])
@@ -52,15 +89,21 @@ def synth_params(model_type, cfg, seed):
     return p
 
 
-def synth_inputs(cfg, seed, device, n_batches=4):
-    g = torch.Generator(device=device).manual_seed(seed)
-    N, R, D, B, T, A = cfg["N_img"], cfg["R"], cfg["D"], cfg["B"], cfg["T"], cfg["A"]
-    table = torch.randn(N, R, D, generator=g, device=device).relu_()
-    nbox = torch.full((N,), R, dtype=torch.int32, device=device)
+def synth_answer_masks(cfg, g, device):
+    import torch
+    A = cfg["A"]
     am = {"train": (torch.arange(A, device=device) < cfg["num_train_answer"]).float()}
     is_obj = torch.rand(A, generator=g, device=device) < 0.5
     am["obj"], am["attr"] = is_obj.float(), (~is_obj).float()
     am["exist"] = torch.ones(A, device=device)
+    return am
+
+
+def synth_batches(cfg, g, device, n_batches, B=None, N=None):
+    import torch
+    B = B or cfg["B"]
+    N = N or cfg["N_img"]
+    T, A = cfg["T"], cfg["A"]
     batches = []
     scores = torch.tensor([0.3, 0.6, 0.9, 1.0], device=device)
     for _ in range(n_batches):
@@ -76,12 +119,24 @@ def synth_inputs(cfg, seed, device, n_batches=4):
             "q_intseq_len": torch.full((B,), T, dtype=torch.int32, device=device),
             "answer_target": tgt,
         })
-    return table, nbox, am, batches
+    return batches
+
+
+def synth_inputs(cfg, seed, device, n_batches=4):
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    N, R, D = cfg["N_img"], cfg["R"], cfg["D"]
+    table = torch.randn(N, R, D, generator=g, device=device).relu_()
+    nbox = torch.full((N,), R, dtype=torch.int32, device=device)
+    am = synth_answer_masks(cfg, g, device)
+    return table, nbox, am, synth_batches(cfg, g, device, n_batches)
 
 
 def cpu_baseline(params, table, nbox, am, batch, cfg, steps=4):
     """Torch-CPU fp32 port of the same train step (oracle/torch_ref.py) on the host
     cores, bounded sample: `steps` timed steps at the full bs-512 shape (about 10 s of CPU work at ~200 samples/s)."""
+    import numpy as np
+    import torch
     from oracle import torch_ref as TR
     n = 512
     tab = table[:n].cpu().numpy()
@@ -104,31 +159,38 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=4):
 
 
 # v_linear_v forward GEMM: 64x128 tiles, 8 waves of 32x32 (cfg 21), NN layout, plain epilogue -> 288 x 8 = 2304 workgroups
-ROOFLINE_KERNEL_PREFIX = "gemm_f32_kernel<64, 128, 32, 32, 1, 32, 0, true, false, 0, false, false, 512"
-ROOFLINE_KERNEL_GRID = "grid=2304"
+ROOFLINE_KERNEL = "gemm_f32_kernel<64,128,32,32,1,32,0,true,false,0,false,false,512>"
+PMC_TRAFFIC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the roofline kernel, from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same bench,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; Infinity-Cache hits are included in
-    the fabric-side counter).  None when the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
+    """HBM-side bytes per launch of the roofline kernel.  NOT measured in this run: read from the committed
+    rocprofv3 PMC passes (profiles/r*_pmc_traffic.json: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
+    same bench, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; Infinity-Cache hits are included
+    in the fabric-side counter).  Returns (bytes, source) -- (None, None) when no profile names the kernel."""
+    want = ROOFLINE_KERNEL.replace(" ", "")
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
         for k, v in d.items():
-            if k.startswith(ROOFLINE_KERNEL_PREFIX) and k.endswith(ROOFLINE_KERNEL_GRID):
-                return float(v["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+            if k.startswith("_"):
+                continue
+            kk = k.replace(" ", "")
+            if kk.startswith(want[:-1]) and kk.endswith("grid=2304"):
+                try:
+                    return float(v["hbm_bytes_per_launch"]), "profiles/" + name
+                except (KeyError, TypeError, ValueError):
+                    pass
+    return None, None
 
 
-def vfeat_bench(device, batch=128, iters=3):
-    """vfeat imgs/sec (second half of BASELINE.json's metric): slim-style ResNet-101 blocks 1-4 on
-    synthetic 448x448 images + 1x1 crop_and_resize of 36 boxes -> [36, 2048] per image (BASELINE
-    configs[2] extractor; random-init He weights, identity-ish BN statistics)."""
+def _vfeat_setup(device, batch):
+    import numpy as np
+    import torch
     from vqa_transfer_externaldata_amd import vfeat as VF
     rng = np.random.default_rng(1234)
     params = VF.init_random_params(rng, VF.BLOCKS_R101_FULL)
@@ -138,41 +200,102 @@ def vfeat_bench(device, batch=128, iters=3):
     ys = torch.sort(torch.rand(batch, 36, 2, generator=g, device=device), dim=-1).values
     xs = torch.sort(torch.rand(batch, 36, 2, generator=g, device=device), dim=-1).values
     box = torch.stack([ys[..., 0], xs[..., 0], ys[..., 1], xs[..., 1]], dim=-1).contiguous()
-    b = {"image": img, "normal_box": box}
-    model.build(b)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    return model, {"image": img, "normal_box": box}
+
+
+def vfeat_bench(device, batch=128, iters=10, warmup=3):
+    """vfeat imgs/sec (second half of BASELINE.json's metric): slim-style ResNet-101 blocks 1-4 on
+    synthetic 448x448 images + 1x1 crop_and_resize of 36 boxes -> [36, 2048] per image (BASELINE
+    configs[2] extractor; random-init He weights).  Every iteration is timed on its own (device
+    synchronised on both sides); the headline is the MEDIAN, min and max are reported beside it."""
+    import numpy as np
+    import torch
+    from vqa_transfer_externaldata_amd import vfeat as VF
+    model, b = _vfeat_setup(device, batch)
+    for _ in range(warmup):
         v = model.build(b)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        v = model.build(b)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = np.array(ts)
+    dt = float(np.median(ts))
     fl = VF.conv_flops_per_image(VF.BLOCKS_R101_FULL, 448, 448)
-    return {"imgs_per_sec": batch / dt, "batch": batch, "image": "448x448x3", "net": "resnet_v1_101 blocks1-4 + "
+    return {"imgs_per_sec": batch / dt, "imgs_per_sec_best": batch / float(ts.min()),
+            "imgs_per_sec_worst": batch / float(ts.max()), "iters": iters, "warmup": warmup,
+            "batch": batch, "image": "448x448x3", "net": "resnet_v1_101 blocks1-4 + "
             "1x1 crop_and_resize of 36 boxes", "gflop_per_image": fl / 1e9, "tflops": batch * fl / dt / 1e12,
             "frac_f32_mfma_peak": batch * fl / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "out_shape": list(v.shape)}
 
 
+def e2e_bench(device, params, steps=5, warmup=2, B=256):
+    """BASELINE configs[2]: ResNet-101 vfeat extractor + model_vlmap_answer, bs 256, one GPU.  One step =
+    256 synthetic 448x448 images with 36 boxes each through the extractor (vqa/vfeat_extractor_tf_record_memft.py:77-147:
+    conv stack -> 1x1 ROI crop -> rows of the [N,36,2048] feature table) and then one train step of the fusion
+    model on those 256 images' questions reading the freshly written table rows.  Both stages are inside the timed
+    region; the table stays in HBM (the reference round-trips it through an HDF5 file between two programs)."""
+    import torch
+    from vqa_transfer_externaldata_amd import fusion as F
+    cfg = dict(CFG, B=B, N_img=B)
+    model, vb = _vfeat_setup(device, B)
+    g = torch.Generator(device=device).manual_seed(77)
+    am = synth_answer_masks(cfg, g, device)
+    batches = synth_batches(cfg, g, device, 2, B=B, N=B)
+    table = torch.zeros(B, cfg["R"], cfg["D"], device=device)
+    nbox = torch.full((B,), cfg["R"], dtype=torch.int32, device=device)
+    rows = torch.arange(B, device=device)
+    eng = F.FusionEngine(model_type="vlmap_answer", B=B, R=cfg["R"], D=cfg["D"], H=cfg["H"], T=cfg["T"], W=cfg["W"],
+                         A=cfg["A"], Vq=cfg["Vq"], N_img=B, params=params, device=device)
+    eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
+
+    def step(i):
+        v = model.build(vb)                                  # [B,36,2048]
+        table.index_copy_(0, rows, v)                        # the extractor's write into the dense table
+        ka, kj = eng.make_keep_masks(seed=5, step=i)
+        eng.train_step(batches[i % 2], ka, kj, 1e-3)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = eng.report()["answer_train_loss"]
+    return {"samples_per_sec": B / dt, "ms_per_step": dt * 1e3, "batch": B, "steps": steps, "warmup": warmup,
+            "workload": "256 images 448x448 -> resnet_v1_101 b1-4 + 36-box 1x1 ROI crop -> feature-table rows -> "
+                        "model_vlmap_answer train step on the same 256 (image, question) pairs (BASELINE configs[2])",
+            "final_train_loss": loss}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-vfeat", action="store_true")
-    ap.add_argument("--probe", type=str, default="v_linear_v.fwd_gemm")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
+    ndev = torch.cuda.device_count()       # does not initialise the GPU
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("VQA_BENCH_BACKEND", "nccl")      # "gloo" = rehearsal on a 1-GPU box
         if backend == "nccl":
+            if ndev < world:
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set VQA_BENCH_BACKEND=gloo to rehearse "
+                                 "several ranks on one GPU)" % (world, ndev))
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    ndev = torch.cuda.device_count()
     local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -192,7 +315,7 @@ def main():
                          W=cfg["W"], A=cfg["A"], Vq=cfg["Vq"], N_img=cfg["N_img"], params=params, device=device,
                          global_batch=cfg["B"] * world)
     eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
-    reducer = PAR.BucketedAllReduce() if world > 1 else None
+    reducer = PAR.BucketedAllReduce(timing=True) if world > 1 else None
     lib = _lib.load()
     if os.environ.get("VQA_GRU_CFG"):
         _lib.check(lib.vqa_gemm_set_gru_config(int(os.environ["VQA_GRU_CFG"])), "vqa_gemm_set_gru_config")
@@ -209,6 +332,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if reducer is not None:
+        reducer.reset_timing()
     _lib.check(lib.vqa_probe_enable(args.probe.encode(), max(args.steps, 1)), "vqa_probe_enable")
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -235,6 +360,7 @@ def main():
         # algorithmic FLOPs of the probed kernel: v_linear_v fwd = 2*B*R*D*H
         flops = 2.0 * cfg["B"] * cfg["R"] * cfg["D"] * cfg["H"]
         achieved = flops / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         out = {
             "metric": "VQA train samples/sec (img+question) at bs512",
             "value": cfg["B"] * world * args.steps / dt,
@@ -243,21 +369,31 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else "none"),
             "config": {"workload": "model_vlmap_answer train step (fwd+bwd+clip+Adam), bs 512 per GPU, "
                                    "36x2048 precomputed region features resident in HBM, 14-token questions, "
                                    "3000 answers (BASELINE configs[1])",
                        "global_batch": cfg["B"] * world, "Vq": cfg["Vq"], "table_images": cfg["N_img"],
                        "parallelism": "dp%d" % world if world > 1 else "single"},
-            "roofline": {"kernel": "gemm_f32_kernel<64,128,32,32,1,32,0,true,false,0,false,false,512> (v_linear_v forward GEMM, "
-                                   "M=18432 N=1024 K=2048, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"kernel": ROOFLINE_KERNEL + " (v_linear_v forward GEMM, M=18432 N=1024 K=2048, "
+                                   "v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_unit": "bytes/launch (L2<->fabric, PMC; algorithmic minimum 235e6)",
+                         "traffic_source": ("%s (committed rocprofv3 --pmc passes of this bench, not measured in "
+                                            "this run)" % traffic_src) if traffic_src else None,
                          "kernel_ms": kern_ms, "samples": n.value},
             "final_train_loss": loss,
         }
+        if reducer is not None:
+            ex = reducer.exposed_ms()
+            out["allreduce_exposed_ms_per_step"] = float(np.mean(ex)) if len(ex) else None
+            out["allreduce_bytes_per_step"] = int(eng.grad_flat.numel() * 4)
         if world == 1 and not args.no_vfeat:
             out["vfeat"] = vfeat_bench(device)
+        if world == 1 and not args.no_e2e:
+            out["e2e"] = e2e_bench(device, params)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, table, nbox, am, batches[0], cfg)
         print(json.dumps(out), flush=True)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VQA_HOT_ABI_VERSION 1
+#define VQA_HOT_ABI_VERSION 2
 
 enum {
     VQA_OK = 0,
@@ -60,6 +60,12 @@ int vqa_embed_bwd(const float* dx_tm, const int32_t* q, float* dE, int B, int T,
  * zero (vlmap/modules.py:124-140), so the result is identical and the padding id is not a hot row. */
 int vqa_embed_bwd_len(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T, int W,
                       int Vq, void* stream);
+/* Same with the summation form chosen per call instead of by the process-wide default: deterministic = 1 atomic-free
+ * and run-to-run bitwise reproducible, 0 float atomics, -1 whatever vqa_set_deterministic() last selected.  The
+ * whole-model entry points use this with (vqa_dims_t.flags & VQA_FLAG_DETERMINISTIC), so two engines in one process
+ * never share the setting. */
+int vqa_embed_bwd_len_det(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T, int W,
+                          int Vq, int deterministic, void* stream);
 
 /* ------------------------------------------------- GEMM (layers.fully_connected)
  * C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ D[M,N]),  f32 MFMA.
@@ -255,7 +261,9 @@ typedef struct {
     float keep_att;          /* 0.8  vlmap/modules.py:82 */
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
+    int32_t flags;           /* VQA_FLAG_* bit mask, per call (no process-wide state) */
 } vqa_dims_t;
+#define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
 
 /* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
 typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;

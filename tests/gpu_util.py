@@ -22,10 +22,11 @@ def make_case(seed, model_type, B, R, T, N, dims, dtype=np.float32, full_boxes=F
     return p, table, nbox, batch, am, masks
 
 
-def make_engine(model_type, p, table, nbox, am, B, R, T, dims, global_batch=None):
+def make_engine(model_type, p, table, nbox, am, B, R, T, dims, global_batch=None, **kw):
     from vqa_transfer_externaldata_amd import fusion as F
     eng = F.FusionEngine(model_type=model_type, B=B, R=R, T=T, N_img=table.shape[0],
-                         params={k: v.astype(np.float32) for k, v in p.items()}, global_batch=global_batch, **dims)
+                         params={k: v.astype(np.float32) for k, v in p.items()}, global_batch=global_batch, **dims,
+                         **kw)
     eng.bind_inputs(table=dev(table.astype(np.float32)), nbox_table=dev(nbox),
                     answer_masks={k: dev(v.astype(np.float32)) for k, v in am.items()})
     return eng

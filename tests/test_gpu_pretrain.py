@@ -85,3 +85,68 @@ def test_train_steps_reduce_loss_and_export_bridge(tmp_path):
     assert np.all(w[:, 1] == 0) and b[1] == -100.0
     with pytest.raises(ValueError, match="Do not overwrite"):
         PT.export_word_weights(eng.state_dict(), vocab, adict, d)
+
+
+def test_full_size_cfg5_bs512_matches_oracle_f64():
+    """BASELINE configs[4] as configured: bs 512 images = 2560 blank-fill rows per category, D 2048, H 1024, A 4000
+    (3000 objects + 1000 attributes), captions <= 10 tokens -- forward report, logits and attention against the
+    float64 NumPy oracle, the classifier / GRU / embedding gradients against the float64 torch-autograd restatement
+    (vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:54-94, 323-609, 675-706)."""
+    cfg = dict(B=512, n=5, R=36, D=2048, H=1024, L=10, W=300, Vq=5000, n_ws=2000, A=4000)
+    PT, eng, p, batch, masks, db, dm = _setup(9, **cfg)
+    db.update({k: v for k, v in PT.add_length_sort(dict(batch)).items() if k.endswith("/sort")})
+    eng.forward(db, dm)
+    eng.backward()
+    torch.cuda.synchronize()
+    rep = eng.fetch_report()
+    to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
+    p64, b64, m64 = to64(p), to64(batch), to64(masks)
+    total, report, mid = PO.forward(p64, b64, m64, cfg["n"])
+    for k in report:
+        assert abs(rep[k] - report[k]) <= 2e-4 * max(1.0, abs(report[k])), (k, rep[k], report[k])
+    for k in PO.KINDS:
+        for head, key in (("blank_fill", "/bf_logit"), ("wordset", "/ws_logit")):
+            z = eng._tape["kinds"][k][head]["z"].cpu().numpy().reshape(mid[k + key].shape)
+            assert np.abs(z - mid[k + key]).max() < 1e-3, (k, head, np.abs(z - mid[k + key]).max())
+            # top-1 bit-exact, except where float64 itself sees a tie within the logit tolerance (10 240 rows x 4000)
+            a, b = z.argmax(-1), mid[k + key].argmax(-1)
+            gap = np.take_along_axis(mid[k + key], b[..., None], -1)[..., 0] - np.take_along_axis(mid[k + key], a[..., None], -1)[..., 0]
+            assert np.all((a == b) | (gap < 2e-4)) and np.mean(a != b) < 2e-3, (k, head, int((a != b).sum()))
+        att = eng._tape["kinds"][k]["att"].cpu().numpy()
+        assert np.abs(att - mid[k + "/att"]).max() < 1e-5
+    del mid
+    _, _, grads, slices = PO.torch_loss_and_grads(p64, b64, m64, cfg["n"])
+    for name in ("classifier/fc/weights", "classifier/fc/biases", "encode_L_blank/rnn/gru_cell/gates/kernel",
+                 "encode_L_blank/rnn/gru_cell/candidate/kernel", "encode_L_blank/rnn/gru_cell/gates/bias",
+                 "joint_fc/fc/weights", "pooled_linear_l/fc/weights", "spat_v_linear_v/fc/weights",
+                 "L_GloVe/embed_map", "wordset_map/learn"):
+        g = eng.grads[name].cpu().numpy().astype(np.float64)
+        sc = max(np.abs(grads[name]).max(), 1e-12)
+        assert np.abs(g - grads[name]).max() <= 1e-3 * sc + 1e-8, (name, np.abs(g - grads[name]).max(), sc)
+    sq = sum(float((v ** 2).sum()) for v in slices.values())
+    assert abs(float(eng.grad_flat[eng.n_train]) - sq) <= 1e-3 * sq + 1e-12
+
+
+def test_checkpoint_resume_continues_the_adam_trajectory():
+    """state_dict keeps the Adam moments and the step count: 2 steps + save/load + 2 steps == 4 uninterrupted steps."""
+    cfg = dict(B=8, n=5, R=36, D=128, H=64, L=8, W=300, Vq=100, n_ws=30, A=60)
+    PT, eng, p, batch, masks, db, dm = _setup(12, **cfg)
+    for _ in range(4):
+        eng.train_step(db, dm, 2e-3)
+    want = {k: v.cpu().numpy().copy() for k, v in eng.params.items()}
+    _, eng2, _, _, _, _, _ = _setup(12, **cfg)
+    for _ in range(2):
+        eng2.train_step(db, dm, 2e-3)
+    sd = eng2.state_dict()
+    assert "classifier/fc/weights/Adam" in sd and "classifier/fc/weights/Adam_1" in sd and int(sd["global_step"]) == 2
+    zeros = {k: np.zeros_like(np.asarray(v)) for k, v in p.items()}
+    eng3 = PT.PretrainEngine(n=cfg["n"], R=cfg["R"], D=cfg["D"], H=cfg["H"], W=cfg["W"], A=cfg["A"], Vq=cfg["Vq"],
+                             n_ws=cfg["n_ws"], params=zeros)
+    eng3.load_state_dict(sd)
+    assert eng3.step_count == 2
+    for _ in range(2):
+        eng3.train_step(db, dm, 2e-3)
+    torch.cuda.synchronize()
+    for k, v in eng3.params.items():
+        # bitwise up to the atomically scatter-added embedding gradients (order of the adds varies run to run)
+        np.testing.assert_allclose(v.cpu().numpy(), want[k], rtol=0, atol=2e-6, err_msg=k)

@@ -12,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from vqa_transfer_externaldata_amd import _lib, fusion as F  # noqa: E402
 
-_lib.load().vqa_set_deterministic(1)     # atomic-free embedding scatter-add: makes a bitwise comparison meaningful
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
@@ -41,7 +40,8 @@ class ForcedReducer:
 
 def run(reducer):
     eng = F.FusionEngine(model_type="vlmap_answer", B=cfg["B"], R=cfg["R"], D=cfg["D"], H=cfg["H"], T=cfg["T"], W=cfg["W"],
-                         A=cfg["A"], Vq=cfg["Vq"], N_img=cfg["N_img"], params=params, device=dev, global_batch=cfg["B"])
+                         A=cfg["A"], Vq=cfg["Vq"], N_img=cfg["N_img"], params=params, device=dev, global_batch=cfg["B"],
+                         deterministic=True)     # atomic-free embedding scatter-add: a bitwise comparison is meaningful
     eng.bind_inputs(table=table, nbox_table=nbox, answer_masks=am)
     for i in range(int(os.environ.get('STEPS', 3))):
         ka, kj = eng.make_keep_masks(seed=5, step=i)

@@ -21,7 +21,10 @@ class Dims(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
                 ("W", C.c_int32), ("A", C.c_int32), ("Vq", C.c_int32), ("N_img", C.c_int64),
                 ("model_type", C.c_int32), ("keep_att", C.c_float), ("keep_joint", C.c_float),
-                ("inv_global_batch", C.c_float)]
+                ("inv_global_batch", C.c_float), ("flags", C.c_int32)]
+
+
+FLAG_DETERMINISTIC = 1
 
 
 class Fc(C.Structure):
@@ -53,6 +56,7 @@ SIGNATURES = {
     "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_embed_bwd_len_det": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_set_deterministic": (_I, [_I]),
     "vqa_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _P]),
     "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
@@ -115,6 +119,8 @@ SIGNATURES = {
                                  _P, _P]),
 }
 
+ABI_VERSION = 2      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
+
 _lib = None
 
 
@@ -132,8 +138,9 @@ def load():
         fn = getattr(lib, name)            # AttributeError if the ABI and the header drift apart
         fn.restype = res
         fn.argtypes = args
-    if lib.vqa_hot_version() != 1:
-        raise VqaHotError("libvqahot.so ABI version %d != 1" % lib.vqa_hot_version())
+    if lib.vqa_hot_version() != ABI_VERSION:
+        raise VqaHotError("libvqahot.so ABI version %d != %d (rebuild: python -c 'import __graft_entry__ as g; "
+                          "g.build()')" % (lib.vqa_hot_version(), ABI_VERSION))
     _lib = lib
     return lib
 

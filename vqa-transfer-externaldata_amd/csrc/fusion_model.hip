@@ -465,7 +465,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
     TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
     if (G->embed != nullptr)
-        TRY(vqa_embed_bwd_len(dx, bt->q_intseq, bt->q_intseq_len, G->embed, (int)B, (int)T, (int)W, dims->Vq, c.st));
+        TRY(vqa_embed_bwd_len_det(dx, bt->q_intseq, bt->q_intseq_len, G->embed, (int)B, (int)T, (int)W, dims->Vq,
+                                  (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
     if (embed_slice_sq != nullptr)
         TRY(vqa_sumsq(dx, T * B * W, nullptr, embed_slice_sq, c.f("sumsq_ws"), c.L.find("sumsq_ws")->n, c.st));
     }   // phase 2

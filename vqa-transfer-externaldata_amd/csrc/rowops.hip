@@ -357,10 +357,15 @@ extern "C" int vqa_set_deterministic(int on) {
 }
 extern "C" int vqa_embed_bwd_len(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T,
                                  int W, int Vq, void* stream) {
+    return vqa_embed_bwd_len_det(dx_tm, q, len, dE, B, T, W, Vq, -1, stream);
+}
+extern "C" int vqa_embed_bwd_len_det(const float* dx_tm, const int32_t* q, const int32_t* len, float* dE, int B, int T,
+                                     int W, int Vq, int deterministic, void* stream) {
     VQA_REQUIRE(dx_tm && q && dE && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
     if (B * T == 0) return VQA_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!g_deterministic || W > 512) {
+    const bool det = deterministic < 0 ? g_deterministic != 0 : deterministic != 0;
+    if (!det || W > 512) {
         // float atomics: the L2 serialises a frequent word's adds per address at ~10 ns each, so skew costs
         // little; the summation order (hence the last bit) varies from run to run, as it does in the reference
         hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, st, dx_tm, q, len, dE, B, T, W, Vq);

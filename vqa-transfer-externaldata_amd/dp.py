@@ -14,6 +14,8 @@ shards are weighted by their sample counts automatically.
 """
 from __future__ import annotations
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -77,19 +79,48 @@ class BucketedAllReduce:
     (19.7 MB at Vq = 16384) + slice sum of squares, GRU gate weights (10.8 MB), GRU candidate weights (5.4 MB, the
     only one with nothing left to hide behind)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, timing=False):
         self.group = group
         self._works = []
+        self.timing = timing          # bench.py: measure the time the compute stream spends blocked in finish()
+        self._events = []             # (before, after) event pairs on the compute stream, one per finish()
+        self._host_ms = []            # gloo rehearsal path: the reduction is synchronous, timed on the host
+        self._host_acc = 0.0
 
     def start(self, bucket):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
         if bucket.is_cuda and dist.get_backend(self.group) == "gloo":
+            t0 = time.perf_counter()
             allreduce_flat_(bucket, self.group)            # rehearsal path: synchronous host staging
+            self._host_acc += (time.perf_counter() - t0) * 1e3
             return
         self._works.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
+        """Makes the compute stream wait for every bucket started since the last finish().  With timing on, two
+        events bracket the waits on the compute stream: nothing else is enqueued between them, so their distance
+        is exactly the reduction time that backward did NOT hide (the exposed all-reduce time of the step)."""
+        ev = None
+        if self.timing and self._works and self._works[0] is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+        if self.timing and self._host_acc:
+            self._host_ms.append(self._host_acc)
+        self._host_acc = 0.0
         self._works = []
+
+    def reset_timing(self):
+        self._events, self._host_ms, self._host_acc = [], [], 0.0
+
+    def exposed_ms(self):
+        """Per-step exposed reduction time in ms (synchronises the recorded events)."""
+        if self._events:
+            torch.cuda.synchronize()
+            return [a.elapsed_time(b) for a, b in self._events]
+        return list(self._host_ms)

@@ -99,10 +99,9 @@ class FusionEngine:
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None):
         """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
-        from float atomics to an atomic-free kernel, ~30 us slower at bs 512; process-wide library setting)."""
+        from float atomics to an atomic-free kernel, ~30 us slower at bs 512).  Per engine: the choice travels in
+        vqa_dims_t.flags with every call, no process-wide library state is touched."""
         self.lib = _lib.load()
-        if deterministic is not None:
-            _lib.check(self.lib.vqa_set_deterministic(1 if deterministic else 0), "vqa_set_deterministic")
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
         self.device = torch.device(device)
@@ -111,7 +110,8 @@ class FusionEngine:
         self.dims = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N_img,
                               model_type=0 if model_type == "vlmap_answer" else 1,
                               keep_att=keep_att, keep_joint=keep_joint,
-                              inv_global_batch=1.0 / float(global_batch or B))
+                              inv_global_batch=1.0 / float(global_batch or B),
+                              flags=_lib.FLAG_DETERMINISTIC if deterministic else 0)
         self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
         names = sorted(self.shapes)
         embed = self.sc["embed"]
@@ -357,24 +357,50 @@ class FusionEngine:
         self.optimizer_step(lr)
 
     # ------------------------------------------------------------------ results
-    def report(self):
-        r = self.tensor("report")[:13].cpu().numpy()
+    def report(self, global_rows=None, group=None):
+        """The 13 report scalars of the reference (vqa/model_vlmap_answer.py:275-288) for the batch this engine
+        ran.  Under data parallelism pass global_rows (= sum of the shard sizes): the per-sample statistics are
+        summed over the shard, SUM-all-reduced, and the means / guarded ratios are taken over the GLOBAL batch by
+        the same kernel -- every rank then reports what one process on the whole batch would."""
+        import torch.distributed as dist
+        if global_rows is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            r = self.tensor("report")[:13].cpu().numpy()
+        else:
+            d = self.dims
+            s = self.tensor("stats").view(d.B, 16).sum(0)
+            if dist.get_backend(group) == "gloo":
+                h = s.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                s = h.to(self.device)
+            else:
+                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+            mean = (s / float(global_rows)).contiguous()
+            out = torch.zeros(16, dtype=torch.float32, device=self.device)
+            _lib.check(self.lib.vqa_report_reduce(C.c_void_p(mean.data_ptr()), 1, C.c_void_p(out.data_ptr()),
+                                                  self._stream()), "vqa_report_reduce")
+            r = out[:13].cpu().numpy()
         return {self.lib.vqa_report_key(i).decode(): float(r[i]) for i in range(13)}
 
     def loss(self):
         return self.tensor("report")[0]
 
-    def make_keep_masks(self, seed, step):
+    def make_keep_masks(self, seed, step, row_offset=0, global_rows=None):
         """Reproducible dropout keep-masks for (seed, step) -- the explicit stand-in for
-        tf.nn.dropout's internal RNG (vlmap/modules.py:82, model_vlmap_answer.py:180)."""
+        tf.nn.dropout's internal RNG (vlmap/modules.py:82, model_vlmap_answer.py:180).
+        The mask stream is indexed by the GLOBAL batch row: a data-parallel shard passes its first global row
+        (row_offset) and the global batch size, and draws exactly the bits one process running the whole batch
+        would draw for those rows -- ranks never reuse each other's bits."""
         d = self.dims
+        Bg = int(global_rows) if global_rows is not None else d.B
         n_att, n_j = d.B * d.R * d.H, d.B * 2 * d.H
         if not hasattr(self, "_keep_att"):
             self._keep_att = torch.empty(n_att, dtype=torch.uint8, device=self.device)
             self._keep_joint = torch.empty(n_j, dtype=torch.uint8, device=self.device)
-        off = step * (n_att + n_j)
-        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_att.data_ptr()), n_att, seed, off,
-                                             d.keep_att, self._stream()), "vqa_dropout_mask")
-        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_joint.data_ptr()), n_j, seed, off + n_att,
-                                             d.keep_joint, self._stream()), "vqa_dropout_mask")
+        off = step * (Bg * d.R * d.H + Bg * 2 * d.H)
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_att.data_ptr()), n_att, seed,
+                                             off + row_offset * d.R * d.H, d.keep_att, self._stream()),
+                   "vqa_dropout_mask")
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_joint.data_ptr()), n_j, seed,
+                                             off + Bg * d.R * d.H + row_offset * 2 * d.H, d.keep_joint,
+                                             self._stream()), "vqa_dropout_mask")
         return self._keep_att, self._keep_joint

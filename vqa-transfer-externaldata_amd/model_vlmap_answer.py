@@ -240,7 +240,10 @@ class Model(object):
         if getattr(self.config, "dropout_off", False):
             ka = kj = None
         else:   # tf.nn.dropout is applied unconditionally in the reference (also at eval time)
-            ka, kj = eng.make_keep_masks(int(getattr(self.config, "seed", 123)), self._step)
+            # under data parallelism the stream is indexed by the global row (config.shard_row_offset, global_batch)
+            ka, kj = eng.make_keep_masks(int(getattr(self.config, "seed", 123)), self._step,
+                                         row_offset=int(getattr(self.config, "shard_row_offset", 0) or 0),
+                                         global_rows=gb)
         self._step += 1
         self._db, self._keep = db, (ka, kj)
         eng.forward(db, ka, kj, want_dz=self.is_train)

@@ -355,9 +355,28 @@ class PretrainEngine:
         self.optimizer_step(lr)
 
     def state_dict(self):
+        """name -> CPU tensor with the reference's variable names, the Adam slots of every trained variable
+        (`<var>/Adam`, `<var>/Adam_1`) and global_step -- what tf.train.Saver keeps (vlmap_memft/trainer.py);
+        same layout as fusion.FusionEngine.state_dict."""
         out = {k: v.detach().cpu().clone() for k, v in self.params.items()}
+        for k, (o, cnt) in self._tab.items():
+            out[k + "/Adam"] = self.m_flat[o:o + cnt].view(self.shapes[k]).cpu().clone()
+            out[k + "/Adam_1"] = self.v_flat[o:o + cnt].view(self.shapes[k]).cpu().clone()
         out["global_step"] = torch.tensor(self.step_count, dtype=torch.int64)
         return out
+
+    def load_state_dict(self, sd):
+        """Restores parameters, Adam moments and the step count (beta powers), so a resumed run continues the
+        optimiser trajectory of an uninterrupted one."""
+        for k in self.shapes:
+            if k in sd:
+                self.params[k].copy_(torch.as_tensor(sd[k]).to(torch.float32))
+        for k, (o, cnt) in self._tab.items():
+            if k + "/Adam" in sd:
+                self.m_flat[o:o + cnt].copy_(torch.as_tensor(sd[k + "/Adam"]).reshape(-1))
+                self.v_flat[o:o + cnt].copy_(torch.as_tensor(sd[k + "/Adam_1"]).reshape(-1))
+        if "global_step" in sd:
+            self.step_count = int(sd["global_step"])
 
 
 def export_word_weights(state_dict, vocab, answer_dict, save_dir):

@@ -51,10 +51,11 @@ class Trainer(object):
         self.checkpoint_step = config.checkpoint_step
         self._summary_path = os.path.join(self.train_dir, "summaries.jsonl")
         if config.checkpoint is not None:
+            # parameters + Adam slots + step count (tf.train.Saver restores the slots and beta powers too)
             sd = torch.load(config.checkpoint, map_location="cpu")
-            for k, v in self.model.variables().items():
-                v.copy_(sd[k])
+            self.model.engine.load_state_dict(sd)
             self.global_step = int(sd.get("global_step", 0))
+            self.model._step = int(sd.get("dropout_step", self.global_step))
 
     def _lr(self):
         if self.config.lr_weight_decay:
@@ -97,6 +98,7 @@ class Trainer(object):
         path = os.path.join(self.train_dir, "model-{}".format(self.global_step))
         sd = self.model.engine.state_dict()
         sd["global_step"] = torch.tensor(self.global_step, dtype=torch.int64)
+        sd["dropout_step"] = torch.tensor(int(getattr(self.model, "_step", 0)), dtype=torch.int64)
         torch.save(sd, path)
         return path
 

@@ -56,6 +56,8 @@ class Trainer(object):
             dst = os.path.join(self.train_dir, config.vlmap_word_weight_dir.rstrip("/").split("/")[-1])
             if self.rank == 0 and not os.path.exists(dst):
                 shutil.copytree(config.vlmap_word_weight_dir, dst)
+            if self.world > 1:
+                torch.distributed.barrier()      # the other ranks read the copy (Model -> load_word_weight_dir)
             self.vlmap_word_weight_dir = config.vlmap_word_weight_dir = dst
         else:
             self.vlmap_word_weight_dir = config.vlmap_word_weight_dir
@@ -83,7 +85,7 @@ class Trainer(object):
         self._dev_batches, self._dev_batch_bytes = {}, 0
         self._dev_batch_budget = int(getattr(config, "device_batch_cache_gb", 32)) << 30
         self._pending_train_batch, self._pending_global = first[0], None
-        config.global_batch = first[1]
+        self._set_global(first[1])
         self.model = Model(first[0], config, is_train=True, image_features=image_features)
 
         # Optimizer (tf.contrib.layers.optimize_loss: Adam, clip 20.0, train_vars; :87-114)
@@ -108,6 +110,7 @@ class Trainer(object):
             sd = torch.load(self.ckpt_path, map_location="cpu")
             self.model.engine.load_state_dict(sd)
             self.global_step = int(sd.get("global_step", 0))
+            self.model._step = int(sd.get("dropout_step", self.global_step))   # dropout mask stream position
             log.info("Loaded the checkpoint")
         self.pretrained_param_path = config.pretrained_param_path
         if self.pretrained_param_path is not None:
@@ -122,6 +125,13 @@ class Trainer(object):
             return batch, len(batch["image_idx"])
         return dp.shard_batch(batch, self.rank, self.world)
 
+    def _set_global(self, n_global):
+        """global batch size of the batch about to run + the first global row of this rank's shard (it indexes
+        the dropout mask stream, FusionEngine.make_keep_masks)"""
+        self.config.global_batch = n_global
+        self.config.shard_row_offset = (dp.shard_bounds(n_global, self.rank, self.world)[0]
+                                        if self.world > 1 and n_global else 0)
+
     def _lr(self):
         if self.config.lr_weight_decay:     # tf.train.exponential_decay(staircase, 10000, 0.5)  (:89-96)
             return self.learning_rate * (0.5 ** (self.global_step // 10000))
@@ -131,7 +141,8 @@ class Trainer(object):
         if split == "train" and self._pending_train_batch is not None:
             b, self._pending_train_batch = self._pending_train_batch, None
             if self._pending_global is not None:
-                self.config.global_batch, self._pending_global = self._pending_global, None
+                self._set_global(self._pending_global)
+                self._pending_global = None
             return b
         it = self._iters.get(split) or self._iters["train"]
         raw = next(it)
@@ -151,12 +162,13 @@ class Trainer(object):
                 batch = self.model.to_device_batch(batch)
                 self._dev_batches[id(raw)] = (raw, batch, n_global)
                 self._dev_batch_bytes += sum(v.numel() * v.element_size() for v in batch.values() if torch.is_tensor(v))
-        self.config.global_batch = n_global
+        self._set_global(n_global)
         return batch
 
     def _report_values(self):
         torch.cuda.synchronize(self.model.device)
-        rep = self.model.engine.report()
+        # data parallel: statistics are reduced over the ranks, so every rank logs the global-batch report
+        rep = self.model.engine.report(global_rows=self.config.global_batch if self.world > 1 else None)
         return float(rep["answer_train_loss"]), rep
 
     # ------------------------------------------------------------------ steps
@@ -171,7 +183,7 @@ class Trainer(object):
         gb = self.config.global_batch
         nxt = self._next("train")
         self._pending_train_batch, self._pending_global = nxt, self.config.global_batch
-        self.config.global_batch = gb
+        self._set_global(gb)
         loss, report = self._report_values()
         self.global_step += 1
         _end_time = time.time()
@@ -203,6 +215,7 @@ class Trainer(object):
         if self.rank == 0:
             sd = self.model.engine.state_dict()
             sd["global_step"] = torch.tensor(self.global_step, dtype=torch.int64)
+            sd["dropout_step"] = torch.tensor(int(self.model._step), dtype=torch.int64)
             torch.save(sd, path)
         return path
 
