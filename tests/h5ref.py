@@ -1,0 +1,148 @@
+"""TEST INFRASTRUCTURE: a minimal ctypes binding of the real HDF5 C library (libhdf5), used only to pin
+vqa_transfer_externaldata_amd.hdf5_io against the genuine implementation: it writes files through the very C calls
+h5py makes for the reference's scripts (H5Fcreate with default property lists -> superblock v0, H5Dcreate2 ->
+contiguous layout, H5Gcreate2, variable-length strings) and reads files back with H5Dread.  Nothing in the product
+imports this module; tests skip when the image has no libhdf5."""
+import ctypes as C
+import ctypes.util
+import glob
+
+import numpy as np
+
+_CANDIDATES = ["/opt/conda/lib/libhdf5.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so",
+               "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so"]
+
+
+def load():
+    names = []
+    found = ctypes.util.find_library("hdf5")
+    if found:
+        names.append(found)
+    for pat in _CANDIDATES:
+        names += sorted(glob.glob(pat + "*"))
+    for n in names:
+        try:
+            lib = C.CDLL(n)
+            lib.H5open()
+            return lib
+        except OSError:
+            continue
+    return None
+
+
+class H5:
+    def __init__(self):
+        self.lib = lib = load()
+        if lib is None:
+            raise RuntimeError("no libhdf5")
+        hid = C.c_int64
+        for name, res, args in [
+            ("H5Fcreate", hid, [C.c_char_p, C.c_uint, hid, hid]), ("H5Fopen", hid, [C.c_char_p, C.c_uint, hid]),
+            ("H5Fclose", C.c_int, [hid]), ("H5Gcreate2", hid, [hid, C.c_char_p, hid, hid, hid]),
+            ("H5Gclose", C.c_int, [hid]), ("H5Screate_simple", hid, [C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
+            ("H5Screate", hid, [C.c_int]), ("H5Sclose", C.c_int, [hid]),
+            ("H5Dcreate2", hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]),
+            ("H5Dopen2", hid, [hid, C.c_char_p, hid]), ("H5Dclose", C.c_int, [hid]),
+            ("H5Dwrite", C.c_int, [hid, hid, hid, hid, hid, C.c_void_p]),
+            ("H5Dread", C.c_int, [hid, hid, hid, hid, hid, C.c_void_p]), ("H5Dget_space", hid, [hid]),
+            ("H5Dget_type", hid, [hid]), ("H5Tget_size", C.c_size_t, [hid]), ("H5Tget_class", C.c_int, [hid]),
+            ("H5Sget_simple_extent_ndims", C.c_int, [hid]),
+            ("H5Sget_simple_extent_dims", C.c_int, [hid, C.POINTER(C.c_uint64), C.c_void_p]),
+            ("H5Tcopy", hid, [hid]), ("H5Tset_size", C.c_int, [hid, C.c_size_t]), ("H5Tclose", C.c_int, [hid]),
+            ("H5Pcreate", hid, [hid]), ("H5Pset_chunk", C.c_int, [hid, C.c_int, C.POINTER(C.c_uint64)]),
+            ("H5Pset_deflate", C.c_int, [hid, C.c_uint]), ("H5Pset_shuffle", C.c_int, [hid]), ("H5Pclose", C.c_int, [hid]),
+            ("H5Eset_auto2", C.c_int, [hid, C.c_void_p, C.c_void_p]),
+        ]:
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        g = lambda sym: C.c_int64.in_dll(lib, sym).value
+        self.T = {np.dtype("<f4"): (g("H5T_IEEE_F32LE_g"), g("H5T_NATIVE_FLOAT_g")),
+                  np.dtype("<f8"): (g("H5T_IEEE_F64LE_g"), g("H5T_NATIVE_DOUBLE_g")),
+                  np.dtype("<i4"): (g("H5T_STD_I32LE_g"), g("H5T_NATIVE_INT32_g")),
+                  np.dtype("<i8"): (g("H5T_STD_I64LE_g"), g("H5T_NATIVE_INT64_g"))}
+        self.C_S1 = g("H5T_C_S1_g")
+        self.P_DATASET_CREATE = g("H5P_CLS_DATASET_CREATE_ID_g")
+        lib.H5Eset_auto2(0, None, None)            # no error-stack printing; return codes are checked below
+
+    @staticmethod
+    def _ok(v, what):
+        if v < 0:
+            raise RuntimeError("libhdf5 call failed: %s" % what)
+        return v
+
+    # ------------------------------------------------------------------ write like h5py does
+    def write(self, path, tree, chunks=None, deflate=None, shuffle=False):
+        """Nested dict -> file: ndarray -> H5Dcreate2 + H5Dwrite (contiguous unless `chunks` names the dataset),
+        python int -> scalar int64 dataset, str -> scalar VARIABLE-LENGTH string dataset (what h5py stores for
+        `grp['pretrained_param_path'] = 'text'`)."""
+        f = self._ok(self.lib.H5Fcreate(path.encode(), 2, 0, 0), "H5Fcreate")
+        try:
+            self._write_group(f, tree, chunks or {}, deflate, shuffle)
+        finally:
+            self._ok(self.lib.H5Fclose(f), "H5Fclose")
+
+    def _write_group(self, loc, tree, chunks, deflate, shuffle):
+        lib = self.lib
+        for name, v in tree.items():
+            if isinstance(v, dict):
+                g = self._ok(lib.H5Gcreate2(loc, name.encode(), 0, 0, 0), "H5Gcreate2")
+                self._write_group(g, v, chunks, deflate, shuffle)
+                lib.H5Gclose(g)
+                continue
+            if isinstance(v, str):
+                t = lib.H5Tcopy(self.C_S1)
+                lib.H5Tset_size(t, C.c_size_t(-1).value)                 # H5T_VARIABLE
+                sp = lib.H5Screate(0)                                    # H5S_SCALAR
+                d = self._ok(lib.H5Dcreate2(loc, name.encode(), t, sp, 0, 0, 0), "H5Dcreate2")
+                buf = (C.c_char_p * 1)(v.encode())
+                self._ok(lib.H5Dwrite(d, t, 0, 0, 0, C.cast(buf, C.c_void_p)), "H5Dwrite")
+                lib.H5Dclose(d); lib.H5Sclose(sp); lib.H5Tclose(t)
+                continue
+            a = np.ascontiguousarray(np.asarray(v)).reshape(np.asarray(v).shape)
+            ft, mt = self.T[a.dtype.newbyteorder("<") if a.dtype.byteorder == "=" else a.dtype]
+            if a.ndim == 0:
+                sp = lib.H5Screate(0)
+            else:
+                dims = (C.c_uint64 * a.ndim)(*a.shape)
+                sp = lib.H5Screate_simple(a.ndim, dims, None)
+            dcpl = 0
+            if name in chunks:
+                dcpl = self._ok(lib.H5Pcreate(self.P_DATASET_CREATE), "H5Pcreate")
+                cd = (C.c_uint64 * a.ndim)(*chunks[name])
+                lib.H5Pset_chunk(dcpl, a.ndim, cd)
+                if shuffle:
+                    lib.H5Pset_shuffle(dcpl)
+                if deflate is not None:
+                    lib.H5Pset_deflate(dcpl, deflate)
+            d = self._ok(lib.H5Dcreate2(loc, name.encode(), ft, sp, 0, dcpl, 0), "H5Dcreate2")
+            self._ok(lib.H5Dwrite(d, mt, 0, 0, 0, a.ctypes.data_as(C.c_void_p)), "H5Dwrite")
+            lib.H5Dclose(d); lib.H5Sclose(sp)
+            if dcpl:
+                lib.H5Pclose(dcpl)
+
+    # ------------------------------------------------------------------ read what our writer produced
+    def read(self, path, name, dtype):
+        lib = self.lib
+        f = self._ok(lib.H5Fopen(path.encode(), 0, 0), "H5Fopen")
+        try:
+            d = self._ok(lib.H5Dopen2(f, name.encode(), 0), "H5Dopen2 " + name)
+            sp = lib.H5Dget_space(d)
+            nd = lib.H5Sget_simple_extent_ndims(sp)
+            dims = (C.c_uint64 * max(nd, 1))()
+            if nd:
+                lib.H5Sget_simple_extent_dims(sp, dims, None)
+            shape = tuple(int(x) for x in dims[:nd])
+            dt = np.dtype(dtype)
+            if dt.kind == "S":
+                t = lib.H5Dget_type(d)
+                n = lib.H5Tget_size(t)
+                out = np.zeros(shape, "S%d" % n)
+                self._ok(lib.H5Dread(d, t, 0, 0, 0, out.ctypes.data_as(C.c_void_p)), "H5Dread")
+                lib.H5Tclose(t)
+            else:
+                out = np.zeros(shape, dt)
+                self._ok(lib.H5Dread(d, self.T[dt][1], 0, 0, 0, out.ctypes.data_as(C.c_void_p)), "H5Dread")
+            lib.H5Sclose(sp); lib.H5Dclose(d)
+            return out
+        finally:
+            lib.H5Fclose(f)

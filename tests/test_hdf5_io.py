@@ -1,0 +1,178 @@
+"""hdf5_io: the TF-free / h5py-free reader and writer of the reference's HDF5 files.
+
+Pins, strongest first:
+  1. files written through the REAL libhdf5 C library with the calls h5py makes for the reference's scripts
+     (tests/h5ref.py; contiguous datasets, symbol-table groups, scalar int64, variable-length string) are read
+     back value-for-value by hdf5_io.File;
+  2. files written by hdf5_io.write are read back by the real libhdf5 (H5Dread) value-for-value;
+  3. round trip through our own writer + reader, byte-level superblock checks, error behaviour.
+1 and 2 skip when the image has no libhdf5 (this one has /opt/conda/lib/libhdf5.so.103 = HDF5 1.10.6)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests import h5ref
+from vqa_transfer_externaldata_amd import hdf5_io as H
+
+needs_libhdf5 = pytest.mark.skipif(h5ref.load() is None, reason="no libhdf5 in this image")
+
+
+def _feature_tree(rng, N=7, R=36, D=48):
+    """The feature file of data/tools/vqa_v2/process_bottom_up_attention_36.py:47-53,95-100."""
+    nb = rng.random((N, R, 4)).astype(np.float32)
+    return {"image_features": rng.standard_normal((N, R, D)).astype(np.float32), "normal_boxes": nb,
+            "spatial_features": rng.random((N, R, 6)).astype(np.float32),
+            "num_boxes": rng.integers(10, R + 1, N).astype(np.int32),
+            "data_info": {"vfeat_dim": D, "max_box_num": R, "pretrained_param_path": "bottom_up_attention_36"}}
+
+
+def _check_tree(f, tree, prefix=""):
+    assert sorted(f.keys()) == sorted(tree)
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            assert isinstance(f[k], H.Group)
+            _check_tree(f[k], v, prefix + k + "/")
+        elif isinstance(v, str):
+            assert f[k][()] == v and f[k].value == v
+        else:
+            a = np.asarray(v)
+            got = f[k]
+            assert tuple(got.shape) == a.shape, (prefix + k, got.shape, a.shape)
+            np.testing.assert_array_equal(np.asarray(got), a)
+            if a.ndim == 0:
+                assert int(got[()]) == int(a) and int(got.value) == int(a)
+
+
+@needs_libhdf5
+def test_reads_files_written_by_the_real_libhdf5_like_h5py_does(tmp_path):
+    rng = np.random.default_rng(0)
+    h5 = h5ref.H5()
+    # feature file: contiguous f32 / i32 datasets, a sub-group with scalar int64 + variable-length string datasets
+    tree = _feature_tree(rng)
+    p = str(tmp_path / "vfeat_bottomup_36.hdf5")
+    h5.write(p, tree)
+    assert H.is_hdf5(p)
+    with H.File(p) as f:
+        assert f.superblock["version"] == 0 and f.superblock["size_of_offsets"] == 8
+        _check_tree(f, tree)
+        # the access pattern of vqa/model_vlmap_answer.py:59-70
+        feats = np.array(f.get("image_features"))
+        assert feats.dtype == np.float32 and feats.shape == (7, 36, 48)
+        assert int(f["data_info"]["max_box_num"].value) == 36 and int(f["data_info"]["vfeat_dim"].value) == 48
+        assert isinstance(f["image_features"].read(), np.memmap)          # zero-copy for contiguous storage
+        np.testing.assert_array_equal(f["image_features"][3, 5:7], tree["image_features"][3, 5:7])
+    # weights.hdf5 of vlmap_memft/export_word_weights.py:60-73 (f[key] = ndarray)
+    w = {k: rng.standard_normal(s).astype(np.float32) for k, s in
+         [("v_word", (50, 300)), ("l_word", (50, 300)), ("l_answer_word", (40, 300)), ("class_weights", (2048, 40)),
+          ("class_biases", (40,))]}
+    p2 = str(tmp_path / "weights.hdf5")
+    h5.write(p2, w)
+    got = H.load_tree(p2)
+    assert sorted(got) == sorted(w)
+    for k in w:
+        np.testing.assert_array_equal(got[k], w[k])
+    # data_info.hdf5 of generator_tf_record_memft_genome.py:103-107 (np.array(x, dtype=np.int32) scalars + tables)
+    di = {"data_info": {"intseq_ans": rng.integers(0, 99, (30, 4)).astype(np.int32),
+                        "intseq_ans_len": rng.integers(1, 5, 30).astype(np.int32),
+                        "max_ans_len": np.array(4, np.int32), "num_answers": np.array(30, np.int32)}}
+    p3 = str(tmp_path / "data_info.hdf5")
+    h5.write(p3, di)
+    with H.File(p3) as f:
+        assert int(f["data_info"]["num_answers"].value) == 30
+        _check_tree(f, di)
+
+
+@needs_libhdf5
+def test_reads_many_entries_and_chunked_compressed_files_of_libhdf5(tmp_path):
+    """More group entries than one symbol-table node holds (B-tree with several leaves) and, beyond what the
+    reference writes, chunked + shuffled + deflated storage as other tools produce it."""
+    rng = np.random.default_rng(1)
+    h5 = h5ref.H5()
+    tree = {"ds_%03d" % i: rng.standard_normal((3, i + 1)).astype(np.float32) for i in range(41)}
+    tree["grp"] = {"x_%d" % i: np.arange(i + 2, dtype=np.int64) for i in range(11)}
+    p = str(tmp_path / "many.h5")
+    h5.write(p, tree)
+    with H.File(p) as f:
+        _check_tree(f, tree)
+    big = {"table": rng.standard_normal((37, 29)).astype(np.float32), "ids": np.arange(1000, dtype=np.int32)}
+    p2 = str(tmp_path / "chunked.h5")
+    h5.write(p2, big, chunks={"table": (8, 16), "ids": (128,)}, deflate=4, shuffle=True)
+    with H.File(p2) as f:
+        _check_tree(f, big)
+    p3 = str(tmp_path / "chunked_plain.h5")
+    h5.write(p3, big, chunks={"table": (10, 10)})
+    with H.File(p3) as f:
+        _check_tree(f, big)
+
+
+@needs_libhdf5
+def test_files_we_write_are_read_by_the_real_libhdf5(tmp_path):
+    rng = np.random.default_rng(2)
+    h5 = h5ref.H5()
+    tree = _feature_tree(rng)
+    tree["data_info"]["vfeat_dim"] = np.array(48, np.int32)
+    tree["many"] = {"k%02d" % i: rng.standard_normal(5).astype(np.float64) for i in range(20)}   # > one leaf node
+    p = str(tmp_path / "ours.hdf5")
+    H.write(p, tree)
+    for name, dt in [("image_features", "<f4"), ("normal_boxes", "<f4"), ("spatial_features", "<f4"), ("num_boxes", "<i4"),
+                     ("data_info/vfeat_dim", "<i4"), ("data_info/max_box_num", "<i8")]:
+        want = tree
+        for part in name.split("/"):
+            want = want[part]
+        got = h5.read(p, name, dt)
+        np.testing.assert_array_equal(got, np.asarray(want))
+        assert got.shape == np.asarray(want).shape
+    for k, v in tree["many"].items():
+        np.testing.assert_array_equal(h5.read(p, "many/" + k, "<f8"), v)
+    s = h5.read(p, "data_info/pretrained_param_path", "S")
+    assert bytes(s[()]).rstrip(b"\0") == b"bottom_up_attention_36"
+
+
+def test_round_trip_and_superblock_bytes(tmp_path):
+    rng = np.random.default_rng(3)
+    tree = _feature_tree(rng)
+    tree["empty"] = np.zeros((0, 4), np.float32)
+    tree["nested"] = {"deeper": {"x": np.arange(6, dtype=np.int64).reshape(2, 3), "f64": np.float64(2.5)}}
+    p = str(tmp_path / "rt.hdf5")
+    H.write(p, tree)
+    raw = open(p, "rb").read()
+    # format signature and superblock v0 fields (HDF5 File Format Specification, "Disk Format: Level 0A")
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n"
+    assert raw[8] == 0 and raw[9] == 0 and raw[10] == 0 and raw[12] == 0          # the four version numbers
+    assert raw[13] == 8 and raw[14] == 8                                           # size of offsets / lengths
+    leaf_k, internal_k = struct.unpack_from("<HH", raw, 16)
+    assert (leaf_k, internal_k) == (4, 16)
+    base, free, eof, drv = struct.unpack_from("<QQQQ", raw, 24)
+    assert base == 0 and free == H.UNDEF and drv == H.UNDEF and eof == len(raw)
+    name_off, root_hdr, cache_type, _ = struct.unpack_from("<QQII", raw, 56)
+    assert name_off == 0 and cache_type == 1 and root_hdr % 8 == 0
+    btree, heap = struct.unpack_from("<QQ", raw, 80)
+    assert raw[btree:btree + 4] == b"TREE" and raw[heap:heap + 4] == b"HEAP"
+    assert raw[root_hdr] == 1                                                      # version-1 object header
+    with H.File(p) as f:
+        _check_tree(f, tree)
+        assert f["nested/deeper/x"].shape == (2, 3) and float(f["/nested/deeper/f64"][()]) == 2.5
+        assert "image_features" in f and "nope" not in f and f.get("nope") is None
+        with pytest.raises(KeyError):
+            f["data_info/nope"]
+    assert H.load_tree(p)["nested"]["deeper"]["x"].tolist() == [[0, 1, 2], [3, 4, 5]]
+
+
+def test_rejects_what_it_does_not_understand(tmp_path):
+    p = str(tmp_path / "not.hdf5")
+    with open(p, "wb") as f:
+        f.write(b"PK\x03\x04" + b"\0" * 200)
+    assert not H.is_hdf5(p)
+    with pytest.raises(H.Hdf5FormatError, match="not an HDF5 file"):
+        H.File(p)
+    q = str(tmp_path / "v2.hdf5")
+    H.write(q, {"a": np.arange(3)})
+    raw = bytearray(open(q, "rb").read())
+    raw[8] = 2                                                                     # pretend libver='latest'
+    open(q, "wb").write(bytes(raw))
+    with pytest.raises(H.Hdf5FormatError, match="superblock version 2"):
+        H.File(q)
+    with pytest.raises(H.Hdf5FormatError):
+        H.write(str(tmp_path / "bad.hdf5"), {"o": np.array([object()])})
