@@ -115,4 +115,62 @@ def test_evaler_results_schema(tmp_path):
     assert r["pred"].startswith("a") and r["question"].startswith("w")
     rep = saved["avg_eval_report"]
     assert rep["answer_acc_num_point"] == 40 and "testonly_score" in rep and "test_obj_only_score_num_point" in rep
-    assert np.load(ev.save_hdf5)["condition"].shape == (40, 1024)
+    from vqa_transfer_externaldata_amd import hdf5_io
+    assert ev.save_hdf5.endswith("results.hdf5")                     # vqa/evaler.py:75,181-186
+    with hdf5_io.File(ev.save_hdf5) as f:
+        assert f["condition"].shape == (40, 1024)
+
+
+def test_trainer_and_evaler_start_from_reference_format_files_with_cli_defaults(tmp_path):
+    """Nothing in memory: the tf_record directory holds what the reference's preprocessing leaves there --
+    vocab.pkl, answer_dict.pkl (python-2 pickles), data_info.hdf5, <split>/<split>-* TFRecord shards and the
+    default --vfeat_name vfeat_bottomup_36_my.hdf5 (vqa/trainer.py:281,325-329) -- and `Trainer(parse_config(...))`
+    / the Evaler come up on it, train, checkpoint and evaluate."""
+    from vqa_transfer_externaldata_amd import evaler, hdf5_io, input_ops_vqa as io, tfrecord_io as T, trainer
+    Vq, A, N, R, D = 60, 40, 24, 36, 64
+    d = tmp_path / "tf_record_memft"
+    d.mkdir()
+    vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
+    adict = {"vocab": ["a%d" % i for i in range(A)], "dict": {"a%d" % i: i for i in range(A)}, "num_train_answer": 30,
+             "is_object": [i % 2 for i in range(A)], "is_attribute": [1 - i % 2 for i in range(A)]}
+    pickle.dump(vocab, open(d / "vocab.pkl", "wb"), protocol=2)
+    pickle.dump(adict, open(d / "answer_dict.pkl", "wb"), protocol=2)
+    io.write_data_info(str(d), A, max_ans_len=np.array(3, np.int32))
+    for split, n, seed in (("train", 96, 1), ("val", 40, 2), ("testval", 40, 3)):
+        sd = io.synthetic_split(n, N, Vq, A, seed=seed)
+        recs = []
+        for r in range(len(sd)):
+            q = sd.q_flat[sd.q_off[r]:sd.q_off[r + 1]]
+            a0, a1 = sd.ans_off[r], sd.ans_off[r + 1]
+            recs.append(T.make_example({"qid": [int(sd.qid[r])], "image_id": str(sd.image_id[r]),
+                                        "image_idx": [int(sd.image_idx[r])], "q_intseq/list": q, "q_intseq/len": [len(q)],
+                                        "answers/ids": sd.ans_ids[a0:a1], "answers/scores": sd.ans_scores[a0:a1],
+                                        "answers/max_freq_answer": [int(sd.ans_ids[a0])]}))
+        os.makedirs(d / split)
+        half = len(recs) // 2
+        T.write_records(str(d / split / ("%s-00000-of-00002" % split)), recs[:half])
+        T.write_records(str(d / split / ("%s-00001-of-00002" % split)), recs[half:])
+    f = _features(N, R, D)
+    hdf5_io.write(str(d / "vfeat_bottomup_36_my.hdf5"),
+                  {"image_features": f["features"], "spatial_features": f["spatials"], "normal_boxes": f["normal_boxes"],
+                   "num_boxes": f["num_boxes"], "data_info": {"vfeat_dim": D, "max_box_num": R,
+                                                              "pretrained_param_path": "bottom_up_attention_36"}})
+    c = trainer.parse_config(["--tf_record_dir", str(d), "--batch_size", "32", "--max_train_iter", "6",
+                              "--train_average_iter", "2", "--val_average_iter", "1", "--validation_step", "3",
+                              "--checkpoint_step", "3", "--heavy_summary_step", "3", "--model_type", "standard"])
+    assert c.vfeat_path.endswith("vfeat_bottomup_36_my.hdf5")            # the reference's default file name
+    c.train_dir = str(tmp_path / "run")
+    t = trainer.Trainer(c)
+    assert t.model.vfeat_dim == D and t.model.max_box_num == R and t.model.num_answer == A
+    np.testing.assert_array_equal(t.model.engine._table.cpu().numpy(), f["features"])
+    t.train()
+    ckpt = os.path.join(c.train_dir, "model-4")
+    assert os.path.exists(ckpt)
+    ec = evaler.build_parser().parse_args(["--checkpoint", ckpt, "--split", "testval", "--batch_size", "32"])
+    # (parse_checkpoint derives these from the reference's train-dir naming; the test run lives in tmp_path)
+    ec.model_type, ec.tf_record_dir = "standard", str(d)
+    ec.vocab_path, ec.vfeat_path = os.path.join(str(d), ec.vocab_name), os.path.join(str(d), "vfeat_bottomup_36_my.hdf5")
+    ev = evaler.Evaler(ec)
+    ev.eval()
+    saved = pickle.load(open(ev.save_pkl, "rb"))
+    assert len(saved["qid2result"]) == 40 and saved["avg_eval_report"]["answer_acc_num_point"] == 40

@@ -176,3 +176,86 @@ def test_rejects_what_it_does_not_understand(tmp_path):
         H.File(q)
     with pytest.raises(H.Hdf5FormatError):
         H.write(str(tmp_path / "bad.hdf5"), {"o": np.array([object()])})
+
+
+def _writers():
+    """ways to produce a reference-format file: our writer, and the real libhdf5 (as h5py would) when present"""
+    out = [("hdf5_io", H.write)]
+    if h5ref.load() is not None:
+        out.append(("libhdf5", h5ref.H5().write))
+    return out
+
+
+@pytest.mark.parametrize("who,writer", _writers())
+def test_package_entry_points_read_the_reference_files(tmp_path, who, writer):
+    """model_vlmap_answer.load_image_features / load_word_weight_dir and input_ops_vqa.read_num_answers on files in
+    the reference's layout (vqa/model_vlmap_answer.py:59-70, vlmap/modules.py:598-601,
+    vqa/datasets/input_ops_vqa_tf_record_memft.py:13-15)."""
+    import pickle
+    from vqa_transfer_externaldata_amd import input_ops_vqa, model_vlmap_answer as MV
+    rng = np.random.default_rng(4)
+    tree = _feature_tree(rng, N=5, R=36, D=32)
+    p = str(tmp_path / "vfeat_bottomup_36_my.hdf5")
+    writer(p, tree)
+    feats, spat, boxes, nb, max_box, dim = MV.load_image_features(p)
+    assert (max_box, dim) == (36, 32) and feats.shape == (5, 36, 32) and feats.dtype == np.float32
+    np.testing.assert_array_equal(np.asarray(feats), tree["image_features"])
+    np.testing.assert_array_equal(np.asarray(spat), tree["spatial_features"])
+    np.testing.assert_array_equal(np.asarray(boxes), tree["normal_boxes"])
+    np.testing.assert_array_equal(nb, tree["num_boxes"])
+    # the .npz alternative and the error for anything else
+    q = str(tmp_path / "feats.npz")
+    np.savez(q, max_box_num=36, vfeat_dim=32, **{k: v for k, v in tree.items() if k != "data_info"})
+    assert MV.load_image_features(q)[0].shape == (5, 36, 32)
+    bad = tmp_path / "feats.bin"
+    bad.write_bytes(b"\0" * 64)
+    with pytest.raises(ValueError, match="neither an HDF5 file nor"):
+        MV.load_image_features(str(bad))
+    # word weights
+    wd = tmp_path / "word_weights_model-4001"
+    wd.mkdir()
+    cw, cb = rng.standard_normal((64, 9)).astype(np.float32), rng.standard_normal(9).astype(np.float32)
+    writer(str(wd / "weights.hdf5"), {"class_weights": cw, "class_biases": cb, "v_word": np.zeros((3, 4), np.float32)})
+    ad = {"vocab": ["a%d" % i for i in range(9)], "dict": {"a%d" % i: i for i in range(9)}}
+    pickle.dump(ad, open(wd / "answer_dict.pkl", "wb"), protocol=2)
+    ww = MV.load_word_weight_dir(str(wd))
+    np.testing.assert_array_equal(ww["class_weights"], cw)
+    np.testing.assert_array_equal(ww["class_biases"], cb)
+    w, b = MV.word_weight_answer_init({"vocab": ["a7", "unseen"]}, 64, ww)
+    np.testing.assert_array_equal(w[:, 0], cw[:, 7])
+    assert b[0] == cb[7] and b[1] == -100.0
+    # data_info.hdf5
+    writer(str(tmp_path / "data_info.hdf5"), {"data_info": {"num_answers": np.array(3000, np.int32),
+                                                            "max_ans_len": np.array(4, np.int32)}})
+    assert input_ops_vqa.read_num_answers(str(tmp_path)) == 3000
+
+
+def test_extractor_and_export_write_the_reference_layout(tmp_path):
+    import torch
+    from vqa_transfer_externaldata_amd import model_vlmap_answer as MV, pretrain as PT, vfeat as VF
+
+    class FakeModel:                       # stands in for the HIP conv stack: the file layout is what is under test
+        def build(self, batch):
+            return batch["image"].mean(dim=(1, 2))[:, None, :].repeat(1, batch["normal_box"].shape[1], 4)
+
+    rng = np.random.default_rng(5)
+    ids = ["COCO_%d.jpg" % i for i in range(3)]
+    nbx = np.sort(rng.random((3, 4, 4)).astype(np.float32), -1)
+    batches = [{"image": torch.rand(3, 8, 8, 3), "normal_box": torch.from_numpy(nbx), "num_box": [4, 3, 4], "image_id": ids}]
+    path = str(tmp_path / "used_vfeat.hdf5")
+    out = VF.Extractor(FakeModel(), {k: i for i, k in enumerate(ids)}, 4, "data/nets/resnet_v1_50.ckpt").extract(batches, path)
+    feats, spat, boxes, nb, max_box, dim = MV.load_image_features(path)
+    assert (max_box, dim) == (4, 12)
+    np.testing.assert_array_equal(np.asarray(feats), out["image_features"])
+    np.testing.assert_array_equal(np.asarray(spat), out["spatial_features"])
+    assert np.all(np.asarray(feats)[1, 3] == 0)                                  # image 1 has 3 boxes: row 3 stays zero
+    with H.File(path) as f:
+        assert f["data_info"]["pretrained_param_path"][()] == "data-nets-resnet_v1_50.ckpt"
+    sd = {k: np.full(s, i, np.float32) for i, (k, s) in enumerate(PT.variable_shapes(11, 5, 7, 8, 16, 4).items())}
+    d = PT.export_word_weights(sd, {"vocab": ["w"]}, {"vocab": ["a%d" % i for i in range(7)],
+                                                      "dict": {"a%d" % i: i for i in range(7)}},
+                               str(tmp_path / "word_weights_model-1"))
+    got = H.load_tree(os.path.join(d, "weights.hdf5"))
+    assert sorted(got) == ["class_biases", "class_weights", "l_answer_word", "l_word", "v_word"]
+    np.testing.assert_array_equal(got["class_weights"], sd["classifier/fc/weights"])
+    assert MV.load_word_weight_dir(d)["class_biases"].shape == (7,)

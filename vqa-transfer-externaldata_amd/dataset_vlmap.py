@@ -6,7 +6,7 @@ pad by repeating the last, `num` = number of valid ones), captions padded to the
 (batches to the per-batch max), one word set per entry taken round-robin from the answer's shuffled
 word-set list (re-shuffled when exhausted).  The enwiki-context fields are not produced: the cfg-5
 model does not read them.  Files: `<data_dir>/<split>_processed.pkl`, `<split>_image_info.pkl`,
-`answer_dict.pkl`, `wordset_dict5.pkl` as in the reference, features from `<split>_vfeat.npz`.
+`answer_dict.pkl`, `wordset_dict5.pkl` as in the reference, features from `<split>_vfeat.hdf5` (or `.npz`).
 `synthetic_dataset` builds the same structures in memory.
 """
 from __future__ import annotations
@@ -46,9 +46,17 @@ class Dataset(object):
                     "processed": _load_pickle(os.path.join(d, "{}_processed.pkl".format(split))),
                     "answer_dict": _load_pickle(os.path.join(d, "answer_dict.pkl")),
                     "ws_dict": _load_pickle(os.path.join(d, "wordset_dict5.pkl"))}
-            z = np.load(os.path.join(d, "{}_vfeat.npz".format(split)), mmap_mode="r")
+            # '<split>_vfeat.hdf5' of the reference (vlmap_memft/datasets/dataset_vlmap.py:67-72), read without
+            # h5py; '<split>_vfeat.npz' with the same keys as an alternative
+            h5 = os.path.join(d, "{}_vfeat.hdf5".format(split))
+            if os.path.exists(h5):
+                from . import hdf5_io
+                f = hdf5_io.File(h5)
+                z = {k: f[k].read() for k in ("image_features", "spatial_features", "normal_boxes", "num_boxes")}
+            else:
+                z = np.load(os.path.join(d, "{}_vfeat.npz".format(split)))
             data.update(image_features=z["image_features"], spatial_features=z["spatial_features"],
-                        normal_boxes=z["normal_boxes"], num_boxes=z["num_boxes"])
+                        normal_boxes=z["normal_boxes"], num_boxes=np.asarray(z["num_boxes"]))
         self._ids = list(data["ids"])
         self.image_id2idx = data["image_id2idx"]
         self.processed = data["processed"]

@@ -53,7 +53,7 @@ class Evaler(object):
         if not os.path.exists(self.eval_dir):
             os.makedirs(self.eval_dir)
         log.infov("Eval Dir: %s", self.eval_dir)
-        self.save_hdf5 = os.path.join(self.eval_dir, "results.npz")   # heavy outputs (reference: results.hdf5)
+        self.save_hdf5 = os.path.join(self.eval_dir, "results.hdf5")  # heavy outputs (vqa/evaler.py:75,181-186)
         self.save_pkl = os.path.join(self.eval_dir, "results.pkl")
 
     def load_checkpoint(self, config):
@@ -135,7 +135,8 @@ class Evaler(object):
         with open(self.save_pkl, "wb") as f:
             pickle.dump(result_dict, f)
         if self.dump_heavy_output:
-            np.savez(self.save_hdf5, **{k: np.stack(v, axis=0) for k, v in heavy_outputs.items()})
+            from . import hdf5_io
+            hdf5_io.write(self.save_hdf5, {k: np.stack(v, axis=0) for k, v in heavy_outputs.items()})
         log.info("evaluation is done")
         return result_dict
 

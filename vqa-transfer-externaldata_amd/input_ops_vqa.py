@@ -8,9 +8,11 @@ The last batch of a pass may be short.  Behaviour kept from the reference pipeli
     batches repeat every epoch, input_ops...:61-78), repeated 1000 times;
   * otherwise a single ordered pass, then StopIteration (the reference's OutOfRangeError,
     vqa/evaler.py:119-123).
-Storage: `<data_dir>/<split>.npz` (ragged arrays + offsets) and `<data_dir>/data_info.json`
-{"num_answers": A}; the tfrecord/tf.Example reader of the reference needs TensorFlow and is a
-later-round item.  `SyntheticSplit` makes the same dicts from a seed.
+Storage: the reference's own layout -- `<data_dir>/<split>/<split>-*` TFRecord shards (tfrecord_io, no
+TensorFlow) and `<data_dir>/data_info.hdf5` with /data_info/num_answers (hdf5_io, no h5py;
+data/tools/vqa_v2/generator_tf_record_memft_genome.py:81-107) -- or the compact `<data_dir>/<split>.npz`
+(ragged arrays + offsets) this package writes for synthetic splits; `data_info.json` {"num_answers": A} is
+accepted where data_info.hdf5 is absent.
 """
 from __future__ import annotations
 
@@ -18,6 +20,30 @@ import json
 import os
 
 import numpy as np
+
+
+def read_num_answers(data_dir):
+    """num_answers of a tf_record directory: /data_info/num_answers of data_info.hdf5
+    (vqa/datasets/input_ops_vqa_tf_record_memft.py:13-15), else data_info.json."""
+    h5 = os.path.join(data_dir, "data_info.hdf5")
+    if os.path.exists(h5):
+        from . import hdf5_io
+        with hdf5_io.File(h5) as f:
+            return int(f["data_info"]["num_answers"][()])
+    js = os.path.join(data_dir, "data_info.json")
+    if os.path.exists(js):
+        with open(js) as f:
+            return int(json.load(f)["num_answers"])
+    raise FileNotFoundError("neither data_info.hdf5 nor data_info.json under %s" % data_dir)
+
+
+def write_data_info(data_dir, num_answers, **extra):
+    """data_info.hdf5 with the group the reference writes (num_answers as an int32 scalar; optional tables such as
+    intseq_ans / intseq_ans_len / max_ans_len)."""
+    from . import hdf5_io
+    info = {"num_answers": np.array(int(num_answers), np.int32)}
+    info.update(extra)
+    hdf5_io.write(os.path.join(data_dir, "data_info.hdf5"), {"data_info": info})
 
 
 class SplitData:
@@ -35,16 +61,14 @@ class SplitData:
 
     @staticmethod
     def load(data_dir, split):
-        with open(os.path.join(data_dir, "data_info.json")) as f:
-            num_answers = json.load(f)["num_answers"]
+        num_answers = read_num_answers(data_dir)
         z = np.load(os.path.join(data_dir, split + ".npz"), allow_pickle=False)
         return SplitData(z["qid"], z["image_id"], z["image_idx"], z["q_flat"], z["q_off"], z["ans_ids"],
                          z["ans_scores"], z["ans_off"], num_answers)
 
     def save(self, data_dir, split):
         os.makedirs(data_dir, exist_ok=True)
-        with open(os.path.join(data_dir, "data_info.json"), "w") as f:
-            json.dump({"num_answers": self.num_answers}, f)
+        write_data_info(data_dir, self.num_answers)
         np.savez(os.path.join(data_dir, split + ".npz"), qid=self.qid, image_id=self.image_id,
                  image_idx=self.image_idx, q_flat=self.q_flat, q_off=self.q_off, ans_ids=self.ans_ids,
                  ans_scores=self.ans_scores, ans_off=self.ans_off)
@@ -112,9 +136,7 @@ def create(batch_size, data_dir, split, is_train=True, scope="vqa", shuffle=True
         d = SplitData.load(data_dir, split)
     else:                                    # the reference's own tfrecord shards (no TensorFlow needed)
         from . import tfrecord_io
-        with open(os.path.join(data_dir, "data_info.json")) as f:
-            num_answers = json.load(f)["num_answers"]
-        d = tfrecord_io.load_vqa_split(data_dir, split, num_answers)
+        d = tfrecord_io.load_vqa_split(data_dir, split, read_num_answers(data_dir))
     n = len(d)
     order = np.arange(n)
     if is_train and shuffle:

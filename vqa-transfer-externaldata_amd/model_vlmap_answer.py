@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import fusion as F
+from . import hdf5_io
 from .log import log
 
 W_DIM = 300   # Word dimension           (vqa/model_vlmap_answer.py:10-12)
@@ -88,10 +89,39 @@ def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_b
 
 
 def load_word_weight_dir(path):
-    """word_weights_model-N/ written by export_word_weights (weights.npz replaces weights.hdf5)."""
+    """word_weights_model-N/ written by export_word_weights: answer_dict.pkl + weights.hdf5 with class_weights /
+    class_biases (vlmap/modules.py:598-601), read without h5py (hdf5_io); a weights.npz with the same keys is
+    accepted as an alternative."""
     ad = _load_pickle(os.path.join(path, "answer_dict.pkl"))
-    z = np.load(os.path.join(path, "weights.npz"))
+    h5, npz = os.path.join(path, "weights.hdf5"), os.path.join(path, "weights.npz")
+    if os.path.exists(h5):
+        with hdf5_io.File(h5) as f:
+            return {"answer_dict": ad, "class_weights": np.array(f["class_weights"]),
+                    "class_biases": np.array(f["class_biases"])}
+    if not os.path.exists(npz):
+        raise FileNotFoundError("neither weights.hdf5 nor weights.npz under %s" % path)
+    z = np.load(npz)
     return {"answer_dict": ad, "class_weights": z["class_weights"], "class_biases": z["class_biases"]}
+
+
+def load_image_features(path):
+    """(features, spatials, normal_boxes, num_boxes, max_box_num, vfeat_dim) of a region-feature file
+    (vqa/model_vlmap_answer.py:59-70).  The format is taken from the file's magic, not its name: the reference's
+    HDF5 (image_features, spatial_features, normal_boxes, num_boxes, data_info/{max_box_num,vfeat_dim}) is read
+    through hdf5_io -- the big tables come back as np.memmap views, paged in while they are uploaded -- and an
+    .npz with the same names is accepted as an alternative."""
+    if hdf5_io.is_hdf5(path):
+        f = hdf5_io.File(path)              # kept open: the returned arrays are views of the mapped file
+        info = f["data_info"]
+        return (f["image_features"].read(), f["spatial_features"].read(), f["normal_boxes"].read(),
+                np.array(f["num_boxes"]), int(info["max_box_num"][()]), int(info["vfeat_dim"][()]))
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+    if magic[:2] != b"PK":
+        raise ValueError("%s is neither an HDF5 file nor an .npz archive (magic %r)" % (path, magic))
+    z = np.load(path)
+    return (z["image_features"], z["spatial_features"], z["normal_boxes"], z["num_boxes"],
+            int(z["max_box_num"]), int(z["vfeat_dim"]))
 
 
 class Model(object):
@@ -133,9 +163,7 @@ class Model(object):
             feats = get_dummy_data()
         elif image_features is None:
             log.infov("loading image features...")
-            z = np.load(config.vfeat_path, mmap_mode="r")    # .npz/.npy re-pack of the reference hdf5
-            feats = (z["image_features"], z["spatial_features"], z["normal_boxes"], z["num_boxes"],
-                     int(z["max_box_num"]), int(z["vfeat_dim"]))
+            feats = load_image_features(config.vfeat_path)
             log.infov("done")
         else:
             feats = (image_features["features"], image_features["spatials"], image_features["normal_boxes"],

@@ -381,17 +381,19 @@ class PretrainEngine:
 
 def export_word_weights(state_dict, vocab, answer_dict, save_dir):
     """vlmap_memft/export_word_weights.py:35-82: the bridge from pre-training to the VQA model
-    (modules.WordWeightAnswer reads class_weights / class_biases by answer string).  weights.npz replaces
-    weights.hdf5 (no h5py here); vocab.pkl / answer_dict.pkl are written like the reference."""
+    (modules.WordWeightAnswer reads class_weights / class_biases by answer string).  Writes weights.hdf5 with the
+    reference's five datasets (hdf5_io, no h5py) and vocab.pkl / answer_dict.pkl like the reference."""
     import os
     import pickle
+    from . import hdf5_io
     if os.path.exists(save_dir):
         raise ValueError("Do not overwrite: {}".format(save_dir))
     os.makedirs(save_dir)
     g = lambda k: np.asarray(state_dict[k].cpu() if torch.is_tensor(state_dict[k]) else state_dict[k])
-    np.savez(os.path.join(save_dir, "weights.npz"), v_word=g("V_GloVe/embed_map"), l_word=g("L_GloVe/embed_map"),
-             l_answer_word=g("LearnAnswerGloVe/embed_map"), class_weights=g("classifier/fc/weights"),
-             class_biases=g("classifier/fc/biases"))
+    hdf5_io.write(os.path.join(save_dir, "weights.hdf5"),
+                  {"v_word": g("V_GloVe/embed_map"), "l_word": g("L_GloVe/embed_map"),
+                   "l_answer_word": g("LearnAnswerGloVe/embed_map"), "class_weights": g("classifier/fc/weights"),
+                   "class_biases": g("classifier/fc/biases")})
     with open(os.path.join(save_dir, "vocab.pkl"), "wb") as f:
         pickle.dump(vocab, f)
     with open(os.path.join(save_dir, "answer_dict.pkl"), "wb") as f:

@@ -255,11 +255,13 @@ def spatial_features(normal_box):
 
 class Extractor:
     """vqa/vfeat_extractor_tf_record_memft.py:26-147: run the model over batches and fill dense
-    [N, max_roi, D] arrays (image_features, normal_boxes, spatial_features, num_boxes, data_info);
-    written as .npz (h5py is not available)."""
+    [N, max_roi, D] arrays (image_features, normal_boxes, spatial_features, num_boxes, data_info).  save_path
+    ending in .hdf5 / .h5 writes the reference's HDF5 layout (hdf5_io, no h5py: the four datasets + group data_info
+    with max_box_num, vfeat_dim, pretrained_param_path); any other name writes an .npz with the same keys."""
 
-    def __init__(self, model, image_id2idx, max_roi_num):
+    def __init__(self, model, image_id2idx, max_roi_num, pretrained_param_path="random_init"):
         self.model, self.image_id2idx, self.max_roi_num = model, image_id2idx, max_roi_num
+        self.pretrained_param_path = pretrained_param_path
 
     def extract(self, batches, save_path=None):
         N = len(self.image_id2idx)
@@ -282,5 +284,13 @@ class Extractor:
         out = {"image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
                "max_box_num": np.int32(self.max_roi_num), "vfeat_dim": np.int32(feats.shape[2])}
         if save_path is not None:
-            np.savez(save_path, **out)
+            if save_path.endswith((".hdf5", ".h5")):
+                from . import hdf5_io
+                hdf5_io.write(save_path, {
+                    "image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
+                    "data_info": {"pretrained_param_path": self.pretrained_param_path.replace("/", "-"),
+                                  "max_box_num": np.array(self.max_roi_num, np.int32),
+                                  "vfeat_dim": np.array(feats.shape[2], np.int32)}})
+            else:
+                np.savez(save_path, **out)
         return out
