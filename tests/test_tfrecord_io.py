@@ -75,3 +75,41 @@ def test_eval_collection_formats(tmp_path):
     assert res["iter"] == [1, 801] and res["testonly_score"] == [0.1, 0.45]
     lines = (run / "collect_eval_testval_result.txt").read_text().splitlines()
     assert lines[0].split()[0] == "iter" and lines[2] == "00801 0.45000 00000007 0.45000 00000007 0.45000 00000007"
+
+
+def test_eval_collection_rescoring_against_pure_test_annotations(tmp_path):
+    """vqa/eval_collection.py:34-76 with a synthetic pure_test_qid2anno.pkl (python-2 protocol, as the reference's
+    preprocessing dumps it): every score worked out by hand."""
+    import pickle
+    from vqa_transfer_externaldata_amd import eval_collection as EC
+    anno = {10: {"answer_score": {"cat": 1.0, "dog": 0.3}}, 11: {"answer_score": {"red": 0.6}},
+            12: {"answer_score": {"two": 0.9}}, 13: {"answer_score": {"big": 1.0}}}
+    res = {10: {"pred": "cat", "test_obj_max_score": 1.0, "test_attr_max_score": 0.0},      # object-only question
+           11: {"pred": "blue", "test_obj_max_score": 0.0, "test_attr_max_score": 0.6},     # attribute-only, wrong
+           12: {"pred": "two", "test_obj_max_score": 0.9, "test_attr_max_score": 0.9},      # both kinds
+           13: {"pred": "big", "test_obj_max_score": 0.0, "test_attr_max_score": 1.0},      # attribute-only, right
+           99: {"pred": "x", "test_obj_max_score": 0.0, "test_attr_max_score": 0.0}}        # not a pure-test question
+    got = EC.rescore(res, anno)
+    assert got["new_testonly_score"] == pytest.approx((1.0 + 0 + 0.9 + 1.0) / 4)
+    assert got["new_test_obj_only_score"] == pytest.approx(1.0)                            # only qid 10 has no attr answer
+    assert got["new_test_attr_only_score"] == pytest.approx((0 + 1.0) / 2)                 # qids 11, 13
+    with pytest.raises(KeyError):
+        EC.rescore({10: res[10]}, anno)                                                     # reference indexes res[qid]
+    run = tmp_path / "vqa_run"
+    run.mkdir()
+    ed = run / "model-801_eval_test_20180101-000000"
+    ed.mkdir()
+    avg = {}
+    for k in ("testonly_score", "test_obj_only_score", "test_attr_only_score"):
+        avg[k], avg[k + "_num_point"] = 0.5, 4
+    pickle.dump({"qid2result": res, "avg_eval_report": avg}, open(ed / "results.pkl", "wb"))
+    qa = tmp_path / "qa_split"
+    qa.mkdir()
+    pickle.dump(anno, open(qa / "pure_test_qid2anno.pkl", "wb"), protocol=2)
+    out = EC.main(["--train_dirs", str(run), "--split", "test", "--qa_split_dir", str(qa)])[str(run)]
+    assert out["iter"] == [801] and out["new_testonly_score"] == [pytest.approx(0.725)]
+    saved = pickle.load(open(run / "collect_eval_test_result.pkl", "rb"))
+    assert saved["new_test_attr_only_score"] == [pytest.approx(0.5)] and saved["testonly_score_num_point"] == [4]
+    assert (run / "collect_eval_test_result.txt").read_text().splitlines()[1].startswith("00801 0.50000 00000004")
+    with pytest.raises(ValueError, match="Set either"):
+        EC.main(["--split", "test"])
