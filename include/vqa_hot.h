@@ -41,7 +41,8 @@ const char* vqa_hot_error_string(int code);
 /* ---------------------------------------------------------------- a1 / K1
  * V_ft = np.take(features, image_idx); num_V_ft = gather(num_boxes, image_idx)
  * vqa/model_vlmap_answer.py:110-123 (tf.py_func on /cpu:0 + H2D copy).
- * table [N,R,D] f32 resident in HBM, idx i64[B] -> V [B,R,D], nb i32[B]. */
+ * table [N,R,D] f32 resident in HBM, idx i64[B] -> V [B,R,D], nb i32[B].  V == NULL gathers num_boxes only
+ * (the whole-model forward fuses the feature rows into v_linear_v's GEMM, vqa_gemm_f32_gather). */
 int vqa_gather_features(const float* table, const int32_t* nbox_table, const int64_t* idx,
                         float* V, int32_t* nb, int B, int R, int D, int64_t N, void* stream);
 
@@ -85,6 +86,16 @@ int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, in
 int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                     int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
                     float* workspace, int64_t workspace_floats, int max_blocks, void* stream);
+/* The same product with the feature gather fused into the left operand's load ("or fused into K2
+ * A-operand load"): row m of the left operand is row idx[m / R] * R + m % R of `table` [n_samples_in_table * R, K]
+ * (ld = lda), i.e. C = features[image_idx].reshape(B*R, K) * B + bias without a gather pass
+ * (vqa/model_vlmap_answer.py:110-117 + 126-129).  gathered_out (may be NULL; ld = ldg) receives the gathered rows
+ * [M, K] as a by-product for the consumers that re-read V_ft (attention pooling, its backward, dW of v_linear_v).
+ * Out-of-range indices are clamped like vqa_gather_features.  Needs K % 32 == 0, N % 4 == 0 and 16-byte aligned
+ * operands; the table itself may be larger than 4 GiB. */
+int vqa_gemm_f32_gather(int M, int N, int K, const float* table, int lda, const int64_t* idx, int R,
+                        int64_t n_samples_in_table, const float* B, int ldb, float* C, int ldc, const float* bias,
+                        float* gathered_out, int ldg, void* stream);
 int vqa_gemm_set_max_blocks(int n);
 int vqa_gemm_set_order(int order);   /* tuning: 0 n-fastest, 1 m-fastest, -1 automatic */
 int64_t vqa_gemm_workspace_floats(int transA, int transB, int M, int N, int K, int split_k);
@@ -92,6 +103,8 @@ int64_t vqa_gemm_workspace_floats(int transA, int transB, int M, int N, int K, i
  * tile configuration (4, 7..11, 13, 16..18) of the fused GRU-step GEMMs, -1 = defaults */
 int vqa_gemm_set_config(int cfg);
 int vqa_gemm_set_gru_config(int cfg);
+/* tile shape of the tall-activation GEMMs (M >= 2048, N >= 512, K >= 2048): 20 = 128x64 (default), 21 = 64x128 */
+int vqa_gemm_set_tall_config(int cfg);
 
 /* ------------------------------------------- a2,a5,a8,a9 : LN + ReLU (+dropout)
  * y = relu(layer_norm(pre)) [* keepmask / keep]  with statistics over groups of
@@ -202,6 +215,8 @@ int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, con
  * same regions, vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:323-364, without materialising the
  * x5 tile): v [B,R,H], V [B,R,D], nb [B] per memory; qv [B*rep,H], keepmask [B*rep,R,H], att
  * [B*rep,R], pooled [B*rep,D] per query; dv [B,R,H] is summed over the queries of a memory. */
+/* tuning / A-B switch: 1 (default) = the loads-in-flight forward kernel for the models' shapes, 0 = generic kernel */
+int vqa_attn_set_fast(int on);
 int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
                           const float* bias, const uint8_t* keepmask, float keep_prob, float* att, float* pooled,
                           int B, int rep, int R, int H, int D, void* stream);
@@ -264,6 +279,7 @@ typedef struct {
     int32_t flags;           /* VQA_FLAG_* bit mask, per call (no process-wide state) */
 } vqa_dims_t;
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
+#define VQA_FLAG_SEPARATE_GATHER 2  /* run the feature gather as its own pass instead of inside v_linear_v's GEMM */
 
 /* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
 typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;

@@ -157,5 +157,7 @@ def test_checkpoint_resume_continues_the_adam_trajectory():
         eng3.train_step(db, dm, 2e-3)
     torch.cuda.synchronize()
     for k, v in eng3.params.items():
+        if k.endswith("score/fc/biases"):
+            continue       # analytically zero gradient (softmax shift invariance): Adam amplifies run-to-run rounding noise
         # bitwise up to the atomically scatter-added embedding gradients (order of the adds varies run to run)
         np.testing.assert_allclose(v.cpu().numpy(), want[k], rtol=0, atol=2e-6, err_msg=k)

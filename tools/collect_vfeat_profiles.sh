@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): extractor profile of the tree as shipped -- kernel trace + stats of
+# tools/vfeat_bench.py 128 (the bench's batch), then separate PMC passes (MFMA busy; FETCH_SIZE; WRITE_SIZE).
+# Outputs under gpurun_out/prof_vfeat/; copy the summaries into profiles/.
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_vfeat
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/tools/vfeat_bench.py 128 5"
+python3 $R/tools/vfeat_bench.py 128 10 > $O/vfeat_bench.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- $B > $O/trace.log 2>&1
+python3 $R/tools/trace_summary.py $O/trace/t_kernel_trace.csv 6 > $O/trace_summary.txt 2>&1 || true
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -d $O/mfma -o m --output-format csv -- $B > $O/mfma.log 2>&1
+python3 $R/tools/pmc_simple.py $O/mfma/m_counter_collection.csv gemm_f32 > $O/pmc_mfma.txt 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f --output-format csv -- $B > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o w --output-format csv -- $B > $O/write.log 2>&1
+python3 $R/tools/pmc_summary.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || true
+rm -rf $O/trace/*.db $O/mfma/*_kernel_trace.csv $O/fetch/*_kernel_trace.csv $O/write/*_kernel_trace.csv 2>/dev/null || true
+echo "vfeat profiles collected"; cat $O/vfeat_bench.txt | tail -2; head -20 $O/trace_summary.txt

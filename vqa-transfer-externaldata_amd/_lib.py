@@ -61,6 +61,8 @@ SIGNATURES = {
     "vqa_gemm_f32": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _P]),
     "vqa_gemm_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I]),
     "vqa_gemm_f32_ex": (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _L, _I, _P]),
+    "vqa_gemm_f32_gather": (_I, [_I, _I, _I, _P, _I, _P, _I, _L, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "vqa_gemm_set_tall_config": (_I, [_I]),
     "vqa_gemm_set_max_blocks": (_I, [_I]),
     "vqa_gemm_set_order": (_I, [_I]),
     "vqa_gemm_set_config": (_I, [_I]),
@@ -90,6 +92,7 @@ SIGNATURES = {
     "vqa_gru_cand_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "vqa_gru_bwd_a": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
     "vqa_gru_bwd_b": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "vqa_attn_set_fast": (_I, [_I]),
     "vqa_attn_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_attn_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_attn_pool_fwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -302,12 +302,27 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     Side& sd = side_stream();
     const bool forked = fork_side(c, sd);
     Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
-    // a1: V_ft = features[image_idx]
-    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, cv.f("V_ft"), cv.i32("num_V_ft"), (int)B,
-                            (int)R, (int)D, dims->N_img, cv.st));
-    // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
-    TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v",
-                       "rstd_v", nullptr, 1.f));
+    // a1 + a2: V_ft = features[image_idx] is not a pass of its own -- v_linear_v's GEMM reads the table rows through
+    // image_idx in its operand loader and leaves the gathered [B*R, D] block in the workspace as a by-product (attention
+    // pooling, its backward and dW of v_linear_v re-read it).  LN statistics over the whole [R,H] block of a sample.
+    const bool fuse_gather = (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table) && !(dims->flags & VQA_FLAG_SEPARATE_GATHER);
+    if (fuse_gather) {
+        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, nullptr, cv.i32("num_V_ft"), (int)B, (int)R,
+                                (int)D, dims->N_img, cv.st));
+        {
+            ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
+            TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
+                                    P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
+                                    cv.st));
+        }
+        TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
+                            cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
+    } else {
+        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, cv.f("V_ft"), cv.i32("num_V_ft"), (int)B,
+                                (int)R, (int)D, dims->N_img, cv.st));
+        TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v",
+                           "rstd_v", nullptr, 1.f));
+    }
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));

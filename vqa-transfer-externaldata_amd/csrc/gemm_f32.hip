@@ -47,6 +47,10 @@ struct GemmArgs {
     int Hi, Wi, Ci, Ho, Wo, cstride, pad_t, pad_l, kw;
     int conv_taps;                  // kh * kw
     int vec_epi;                    // plain epilogue may use 16-byte accesses
+    // row-gathered A (GATHER kernels): logical row m of the left operand is row g_idx[m / g_R] * g_R + m % g_R of the
+    // table at A (the feature gather V_ft = features[image_idx] fused into v_linear_v's operand load); g_out, when
+    // set, receives the gathered rows densely [M, K] as a by-product (written by the workgroups of column panel 0)
+    const int64_t* g_idx; int g_R; int64_t g_N; float* g_out; int g_ldo;
 };
 
 // XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
@@ -172,6 +176,17 @@ struct Stager {
             }
         }
     }
+    // row-gathered operand: every lane carries the 64-bit address of its row piece (rows of one tile come from
+    // anywhere in a table that may exceed a buffer descriptor's 4 GiB), the k advance is a uniform element offset
+    __device__ __forceinline__ void load_ptr(const float* const (&src)[NV], int koff) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const float4*>(src[i] + koff);
+    }
+    __device__ __forceinline__ void store_ptr(float* const (&dst)[NV], int koff) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (dst[i] != nullptr) *reinterpret_cast<float4*>(dst[i] + koff) = reg[i];
+    }
     __device__ __forceinline__ void load_full(__amdgpu_buffer_rsrc_t rs, unsigned soff) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -253,8 +268,9 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
 }
 
 template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
-          bool EDGE = false, int NT = 256>
+          bool EDGE = false, int NT = 256, bool GATHER = false>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
+    static_assert(!GATHER || (A_KC && DEEP == 0 && !CONV && !EDGE && EPI == EPI_PLAIN), "row-gathered A: plain NN/NT tiles");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
     static_assert(WAVES_M * WAVES_N * WGK * 64 == NT, "one 32x32-tiled wave per (m, n, k-group) slot");
@@ -396,8 +412,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 }
             }
         }
+        const float* gsrc[NVA];     // dead (and optimised away) unless GATHER
+        float* gdst[NVA];
+        if (GATHER) {      // host guarantees K % BK == 0 and no split-k: every tile is full
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+                const int m = m0 + row, mc = min(m, p.M - 1);
+                const int smp = mc / p.g_R, reg_row = mc - smp * p.g_R;
+                int64_t src = p.g_idx[smp];
+                src = src < 0 ? 0 : (src >= p.g_N ? p.g_N - 1 : src);        // np.take would raise; clamp like vqa_gather_features
+                gsrc[i] = p.A + (src * p.g_R + reg_row) * (int64_t)p.lda + kq;
+                gdst[i] = (p.g_out != nullptr && n0 == 0 && m < p.M) ? p.g_out + (int64_t)m * p.g_ldo + kq : nullptr;
+            }
+        }
         auto load_a = [&](int k0) {
-            if (CONV) sa.load_conv(rsA, iy0, ix0, pix, k0, p.Hi, p.Wi, p.Ci, p.kw);
+            if (GATHER) sa.load_ptr(gsrc, k0 - kbeg);
+            else if (CONV) sa.load_conv(rsA, iy0, ix0, pix, k0, p.Hi, p.Wi, p.Ci, p.kw);
             else if (EDGE) sa.load(p.A, p.lda, m0, k0, p.M, kend, va);
             else sa.load_fast(rsA, p.lda, m0, k0, p.M, kend);
         };
@@ -410,6 +442,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             load_b(kbeg);
             sa.store(L0);
             sb.store(L0 + A_FL);
+            if (GATHER) sa.store_ptr(gdst, 0);
         }
         __syncthreads();
         int t = 0;
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             const int nfull = (kend - kbeg) / BK;
             unsigned oa = stepA, ob = stepB;   // scalar byte offsets of tile t + 1
             for (; t + 2 < nfull; t += 2) {
-                sa.load_full(rsA, oa);
+                if (GATHER) sa.load_ptr(gsrc, (t + 1) * BK); else sa.load_full(rsA, oa);
                 sb.load_full(rsB, ob);
                 oa += stepA; ob += stepB;
                 __builtin_amdgcn_sched_barrier(0);
@@ -479,8 +512,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 __builtin_amdgcn_sched_barrier(0);
                 sa.store(L1);
                 sb.store(L1 + A_FL);
+                if (GATHER) sa.store_ptr(gdst, (t + 1) * BK);
                 __syncthreads();
-                sa.load_full(rsA, oa);
+                if (GATHER) sa.load_ptr(gsrc, (t + 2) * BK); else sa.load_full(rsA, oa);
                 sb.load_full(rsB, ob);
                 oa += stepA; ob += stepB;
                 __builtin_amdgcn_sched_barrier(0);
@@ -488,6 +522,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 __builtin_amdgcn_sched_barrier(0);
                 sa.store(L0);
                 sb.store(L0 + A_FL);
+                if (GATHER) sa.store_ptr(gdst, (t + 2) * BK);
                 __syncthreads();
             }
         }
@@ -503,6 +538,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             __builtin_amdgcn_sched_barrier(0);
             sa.store(nxt);
             sb.store(nxt + A_FL);
+            if (GATHER) sa.store_ptr(gdst, (t + 1) * BK);
             __syncthreads();
         }
         if (nt > 0) {
@@ -807,14 +843,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
-          bool EDGE = false, int NT = 256>
+          bool EDGE = false, int NT = 256, bool GATHER = false>
 int launch_one(GemmArgs a, const EpiArgs& ep, int split, hipStream_t st, int max_blocks = 0) {
     constexpr size_t tiles = 2 * (tile_floats<BM, BK, A_KC>() + tile_floats<BN, BK, B_KC>()) * sizeof(float);
     constexpr size_t red = (EPI == EPI_PLAIN) ? (size_t)(WGK - 1) * (BM / WM) * (BN / WN) * (WM / 32) * (WN / 32) * 16 * 64 * sizeof(float) : 0;
     // epilogue transpose patches: one per (m, n) wave slot, and per k group as well for the fused epilogues
     constexpr size_t stage = (size_t)(EPI == EPI_PLAIN ? 1 : WGK) * (BM / WM) * (BN / WN) * 32 * 36 * sizeof(float);
     constexpr size_t lds = tiles > red + stage ? tiles : red + stage;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE, NT>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, WGK, BK, DEEP, A_KC, B_KC, EPI, CONV, EDGE, NT, GATHER>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {   // MI355X has 160 KiB of LDS per CU; > 64 KiB needs the opt-in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -946,6 +982,10 @@ int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st)
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
+// Tall activations x wide weights (v_linear_v forward, M 18432, N 1024, K 2048): 128x64 tiles (cfg 20) run as fast
+// as 64x128 (cfg 21: 551 vs 553 us) and halve the B panel every tile streams (512 KB instead of 1 MB), i.e. the
+// L2<->fabric traffic of the weight matrix, which no XCD's 4 MiB L2 can hold (8 MB).
+int g_tall_cfg = 20;
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
 // Tile config of the fused GRU-step GEMMs: many waves with small per-wave tiles (32x32), in-block split-k and two
 // tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU, and
@@ -970,7 +1010,7 @@ inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
     if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
-    else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? 21 : 22) : 13; target = 256; }
+    else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? g_tall_cfg : 22) : 13; target = 256; }
     else { cfg = (!tB && N > 2048) ? 13 : 23; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
@@ -995,6 +1035,7 @@ GemmArgs make_args(int M, int N, int K, const float* A, int lda, const float* B,
     a.scale = nullptr; a.relu = 0;
     a.a_bytes = a.b_bytes = 0;   // filled by set_extents() once the layout is known
     a.Hi = a.Wi = a.Ci = a.Ho = a.Wo = a.cstride = a.pad_t = a.pad_l = a.kw = a.conv_taps = 0;
+    a.g_idx = nullptr; a.g_R = 1; a.g_N = 0; a.g_out = nullptr; a.g_ldo = 0;
     return a;
 }
 
@@ -1070,6 +1111,38 @@ extern "C" int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, cons
     }
     a.k_per_split = (int)cdiv(std::max(K, 1), 64) * 64;
     return launch_by_id(cfg, transA, transB, a, 1, st, max_blocks);
+}
+
+// C[M,N] = gather(table)[M,K] * B[K,N] (+ bias): row m of the left operand is row idx[m / R] * R + m % R of the table.
+extern "C" int vqa_gemm_f32_gather(int M, int N, int K, const float* table, int lda, const int64_t* idx, int R,
+                                   int64_t n_samples_in_table, const float* B, int ldb, float* C, int ldc,
+                                   const float* bias, float* gathered_out, int ldg, void* stream) {
+    VQA_REQUIRE(M >= 0 && N >= 0 && K > 0 && R > 0 && n_samples_in_table > 0, VQA_ERR_ARG);
+    if (M == 0 || N == 0) return VQA_OK;
+    VQA_REQUIRE(table && idx && B && C, VQA_ERR_ARG);
+    VQA_REQUIRE(lda >= K && ldb >= N && ldc >= N && (gathered_out == nullptr || ldg >= K), VQA_ERR_ARG);
+    VQA_REQUIRE(K % 32 == 0 && N % 4 == 0, VQA_ERR_UNSUPPORTED);          // every k tile full, 16-byte rows
+    VQA_REQUIRE(lda % 4 == 0 && vqa_aligned16(table) && ldb % 4 == 0 && vqa_aligned16(B) &&
+                    (gathered_out == nullptr || (ldg % 4 == 0 && vqa_aligned16(gathered_out))),
+                VQA_ERR_ALIGN);
+    GemmArgs a = make_args(M, N, K, table, lda, B, ldb, C, ldc, bias, nullptr, 0);
+    const int64_t bb = ((int64_t)(K - 1) * ldb + N) * 4;
+    VQA_REQUIRE(bb < 0xFFFFFF00ll, VQA_ERR_UNSUPPORTED);
+    a.a_bytes = 0;                     // A is addressed through per-lane 64-bit pointers (the table may exceed 4 GiB)
+    a.b_bytes = (unsigned)bb;
+    a.g_idx = idx; a.g_R = R; a.g_N = n_samples_in_table; a.g_out = gathered_out; a.g_ldo = ldg;
+    a.k_per_split = (int)cdiv(K, 64) * 64;
+    const EpiArgs ep{};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_tall_cfg == 21)
+        return launch_one<64, 128, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, false, false, 512, true>(a, ep, 1, st, 0);
+    return launch_one<128, 64, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, false, false, 512, true>(a, ep, 1, st, 0);
+}
+
+extern "C" int vqa_gemm_set_tall_config(int cfg) {
+    VQA_REQUIRE(cfg == 20 || cfg == 21, VQA_ERR_ARG);
+    g_tall_cfg = cfg;
+    return VQA_OK;
 }
 
 // ---------------------------------------------------------------------------- fused GRU recurrence

@@ -327,11 +327,11 @@ __global__ __launch_bounds__(256) void dropout_mask_bytes_kernel(uint8_t* __rest
 
 extern "C" int vqa_gather_features(const float* table, const int32_t* nbox_table, const int64_t* idx, float* V,
                                    int32_t* nb, int B, int R, int D, int64_t N, void* stream) {
-    VQA_REQUIRE(table && idx && V && B >= 0 && R > 0 && D > 0 && N > 0, VQA_ERR_ARG);
+    VQA_REQUIRE(table && idx && (V || nb) && B >= 0 && R > 0 && D > 0 && N > 0, VQA_ERR_ARG);
     VQA_REQUIRE(nb == nullptr || nbox_table != nullptr, VQA_ERR_ARG);
     VQA_REQUIRE(vqa_aligned16(table) && vqa_aligned16(V) && ((int64_t)R * D) % 4 == 0, VQA_ERR_ALIGN);
     if (B == 0) return VQA_OK;
-    const int64_t row = (int64_t)R * D;
+    const int64_t row = V != nullptr ? (int64_t)R * D : 0;      // V == NULL: num_boxes only
     const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(row / 4, 256 * 4), 16));
     hipLaunchKernelGGL(gather_features_kernel, dim3(B, chunks), dim3(256), 0, (hipStream_t)stream, table, nbox_table,
                        idx, V, nb, B, row, N);
