@@ -158,9 +158,14 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=4):
                       "oracle/torch_ref.py; the reference TF1 path cannot run here)" % (steps, cfg["B"])}
 
 
-# v_linear_v forward GEMM: 64x128 tiles, 8 waves of 32x32 (cfg 21), NN layout, plain epilogue -> 288 x 8 = 2304 workgroups
-ROOFLINE_KERNEL = "gemm_f32_kernel<64,128,32,32,1,32,0,true,false,0,false,false,512>"
+# v_linear_v forward GEMM: 128x64 tiles, 8 waves of 32x32 (cfg 20), NN layout, rows of the left operand gathered from the
+# feature table through image_idx (GATHER = true), plain epilogue -> 144 x 16 = 2304 workgroups
+ROOFLINE_KERNEL = "gemm_f32_kernel<128,64,32,32,1,32,0,true,false,0,false,false,512,true>"
 PMC_TRAFFIC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
+
+
+def name_of(path):
+    return os.path.basename(path)
 
 
 def pmc_traffic():
@@ -177,12 +182,12 @@ def pmc_traffic():
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if k.startswith("_"):
+            if k.startswith("_") or "grid=" not in k:
                 continue
-            kk = k.replace(" ", "")
-            if kk.startswith(want[:-1]) and kk.endswith("grid=2304"):
+            name, grid = k.replace(" ", "").split("grid=")      # tools/pmc_summary.py truncates long kernel names
+            if grid == "2304" and len(name) > 40 and want.startswith(name.rstrip(">")):
                 try:
-                    return float(v["hbm_bytes_per_launch"]), "profiles/" + name
+                    return float(v["hbm_bytes_per_launch"]), "profiles/" + name_of(path)
                 except (KeyError, TypeError, ValueError):
                     pass
     return None, None
@@ -380,7 +385,7 @@ def main():
                                    "v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (L2<->fabric, PMC; algorithmic minimum 235e6)",
+                         "traffic_unit": "bytes/launch (L2<->fabric, PMC; algorithmic minimum 235e6 + 151e6 gathered V_ft by-product)",
                          "traffic_source": ("%s (committed rocprofv3 --pmc passes of this bench, not measured in "
                                             "this run)" % traffic_src) if traffic_src else None,
                          "kernel_ms": kern_ms, "samples": n.value},

@@ -329,6 +329,67 @@ int vqa_fusion_backward(const vqa_dims_t* dims, const vqa_params_t* params, cons
                         float* embed_slice_sq, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Whole cfg-5 pre-training model (vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:54-94,
+ * 323-609, 675-706) and its backward, one host call each -- the same shape as vqa_fusion_forward / _backward.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t B, n, R, D, H, W, A, Vq, n_ws;  /* images, entries per category (5), regions, feature / hidden / word dims,
+                                             * answers, caption vocabulary, word-set vocabulary */
+    int32_t L;                               /* padded caption length of THIS batch (blanks [B,n,L]) */
+    int32_t flags;                           /* VQA_FLAG_* */
+    float keep_att, keep_joint;              /* 0.8 / 0.5 */
+} vqa_pretrain_dims_t;
+
+/* fc_layer scope shared by several call sites: one weight / bias, one LayerNorm (beta, gamma) PER CALL SITE in TF
+ * graph order (layers.layer_norm is un-scoped: `LayerNorm`, `LayerNorm_1`, ...); unused slots NULL. */
+typedef struct { float *w, *b, *beta[4], *gamma[4]; } vqa_pt_fc_t;
+
+typedef struct {
+    float* wordset_map;                     /* wordset_map/learn [n_ws,W] */
+    float* l_glove;                         /* L_GloVe/embed_map [Vq,W] */
+    vqa_pt_fc_t spat_v_linear_v;            /* [6,H]   LN x2 (object, attribute) */
+    vqa_pt_fc_t spat_q_linear_v;            /* [6,H]   LN x2 */
+    vqa_pt_fc_t spat_att_score;             /* spat_att/compute/score [H,1] */
+    float *gru_wg, *gru_bg, *gru_wc, *gru_bc; /* encode_L_blank/rnn/gru_cell/{gates,candidate}/{kernel,bias} */
+    vqa_pt_fc_t pooled_linear_l;            /* [D,H]   LN x4 (obj bf, attr bf, obj ws, attr ws) */
+    vqa_pt_fc_t q_linear_l;                 /* [H,H]   LN x4 */
+    vqa_pt_fc_t joint_fc;                   /* [H,2H]  LN x4 */
+    vqa_pt_fc_t wordset_ft;                 /* [W,H]   LN x2 */
+    vqa_pt_fc_t classifier;                 /* [2H,A] */
+} vqa_pretrain_params_t;
+
+typedef struct {                            /* one blank-fill category (vlmap_memft/datasets/dataset_vlmap.py:128-236) */
+    const float* normal_boxes;              /* [B,n,4] */
+    const int32_t *fills, *blanks, *blanks_len, *wordsets;   /* [B,n], [B,n,L] zero padded, [B,n], [B,n] */
+    const int32_t* num;                     /* [B] valid entries per image */
+    const uint8_t *keep_att, *keep_bf_joint, *keep_ws_joint;  /* [B*n,R,H], [B*n,2H], [B*n,2H] 0/1 or NULL */
+    /* captions ordered by length, longest first (all three NULL = as given): perm / inv device int32 [B*n],
+     * live_rows HOST int[L] = #captions longer than t -- the recurrence then runs on the live prefix only */
+    const int32_t *perm, *inv, *live_rows;
+} vqa_pretrain_kind_t;
+
+typedef struct {
+    const float* image_ft;                  /* [B,R,D] */
+    const float* spatial_ft;                /* [B,R,6] */
+    const int32_t* num_boxes;               /* [B] */
+    vqa_pretrain_kind_t kind[2];            /* 0 = object, 1 = attribute */
+} vqa_pretrain_batch_t;
+
+int64_t vqa_pretrain_workspace_bytes(const vqa_pretrain_dims_t* dims);
+/* Named intermediates inside the workspace: "<obj|attr>/{att,pooled,valid,bf_state,...}",
+ * "<obj|attr>/<bf|ws>/{z,dz,stats,j,...}", "report" (13 floats in the order of vqa_pretrain_report_key). */
+int vqa_pretrain_tensor(const vqa_pretrain_dims_t* dims, const char* name, int64_t* offset_bytes, int64_t* n_elems);
+const char* vqa_pretrain_report_key(int i);
+int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* params,
+                         const vqa_pretrain_batch_t* batch, void* workspace, int64_t workspace_bytes, int want_dz,
+                         void* stream);
+/* grads: same layout as params, every member non-NULL.  Gradient buffers are OVERWRITTEN (the two embedding tables
+ * are cleared and scatter-added).  slice_sq receives the sum of squares of the un-aggregated embedding slices. */
+int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* params,
+                          const vqa_pretrain_params_t* grads, const vqa_pretrain_batch_t* batch, void* workspace,
+                          int64_t workspace_bytes, float* slice_sq, void* stream);
+
+/* ------------------------------------------------------------------------
  * Region-feature extractor, NHWC fp32.
  * ------------------------------------------------------------------------ */
 /* conv + folded inference BatchNorm (+ residual) (+ ReLU):

@@ -3,7 +3,7 @@
 # roofline object quotes.  Outputs under gpurun_out/prof_final/; copy the summaries into profiles/.
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/${PROF_TAG:-prof_final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-vfeat"

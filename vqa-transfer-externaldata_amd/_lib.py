@@ -46,6 +46,31 @@ class Batch(C.Structure):
                 ("live_rows", C.c_void_p)]
 
 
+class PtDims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("B", "n", "R", "D", "H", "W", "A", "Vq", "n_ws", "L", "flags")] + \
+               [("keep_att", C.c_float), ("keep_joint", C.c_float)]
+
+
+class PtFc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("beta", C.c_void_p * 4), ("gamma", C.c_void_p * 4)]
+
+
+class PtParams(C.Structure):
+    _fields_ = [("wordset_map", C.c_void_p), ("l_glove", C.c_void_p), ("spat_v_linear_v", PtFc),
+                ("spat_q_linear_v", PtFc), ("spat_att_score", PtFc), ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p),
+                ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p), ("pooled_linear_l", PtFc), ("q_linear_l", PtFc),
+                ("joint_fc", PtFc), ("wordset_ft", PtFc), ("classifier", PtFc)]
+
+
+class PtKind(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("normal_boxes", "fills", "blanks", "blanks_len", "wordsets", "num", "keep_att",
+                                          "keep_bf_joint", "keep_ws_joint", "perm", "inv", "live_rows")]
+
+
+class PtBatch(C.Structure):
+    _fields_ = [("image_ft", C.c_void_p), ("spatial_ft", C.c_void_p), ("num_boxes", C.c_void_p), ("kind", PtKind * 2)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol declared in include/vqa_hot.h
@@ -118,6 +143,12 @@ SIGNATURES = {
     "vqa_fusion_forward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Batch), _P, _L, _I, _P]),
     "vqa_fusion_backward_phases": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
                                         _P, _I, _P]),
+    "vqa_pretrain_workspace_bytes": (_L, [C.POINTER(PtDims)]),
+    "vqa_pretrain_tensor": (_I, [C.POINTER(PtDims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vqa_pretrain_report_key": (C.c_char_p, [_I]),
+    "vqa_pretrain_forward": (_I, [C.POINTER(PtDims), C.POINTER(PtParams), C.POINTER(PtBatch), _P, _L, _I, _P]),
+    "vqa_pretrain_backward": (_I, [C.POINTER(PtDims), C.POINTER(PtParams), C.POINTER(PtParams), C.POINTER(PtBatch), _P, _L,
+                                   _P, _P]),
     "vqa_fusion_backward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
                                  _P, _P]),
 }

@@ -178,14 +178,26 @@ struct Stager {
     }
     // row-gathered operand: every lane carries the 64-bit address of its row piece (rows of one tile come from
     // anywhere in a table that may exceed a buffer descriptor's 4 GiB), the k advance is a uniform element offset
+    // (The load goes through a native vector type: assigning HIP's float4 struct from a dereferenced pointer keeps
+    // the whole stager object in scratch memory -- hipcc does not scalarise that copy.)
     __device__ __forceinline__ void load_ptr(const float* const (&src)[NV], int koff) {
+        typedef float f32x4n __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const float4*>(src[i] + koff);
+        for (int i = 0; i < NV; ++i) {
+            const f32x4n v = *reinterpret_cast<const f32x4n*>(src[i] + koff);
+            reg[i] = make_float4(v.x, v.y, v.z, v.w);
+        }
     }
-    __device__ __forceinline__ void store_ptr(float* const (&dst)[NV], int koff) const {
+    // by-product copy of the staged tile: buffer stores, so lanes that must not write (rows past M) carry an
+    // out-of-range offset and the hardware drops them -- a per-lane `if` around a store costs branches and waits
+    __device__ __forceinline__ void store_buf(__amdgpu_buffer_rsrc_t rs, const unsigned (&off)[NV], unsigned soff) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (dst[i] != nullptr) *reinterpret_cast<float4*>(dst[i] + koff) = reg[i];
+        for (int i = 0; i < NV; ++i) {
+            u32x4 v;
+            v.x = __float_as_uint(reg[i].x); v.y = __float_as_uint(reg[i].y);
+            v.z = __float_as_uint(reg[i].z); v.w = __float_as_uint(reg[i].w);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, off[i], soff, 0);
+        }
     }
     __device__ __forceinline__ void load_full(__amdgpu_buffer_rsrc_t rs, unsigned soff) {
 #pragma unroll
@@ -413,7 +425,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             }
         }
         const float* gsrc[NVA];     // dead (and optimised away) unless GATHER
-        float* gdst[NVA];
+        unsigned gdst[NVA];
+        const bool g_store = GATHER && p.g_out != nullptr && n0 == 0;      // workgroup-uniform
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+            p.g_out, 0, GATHER && p.g_out != nullptr ? (int)(((int64_t)(p.M - 1) * p.g_ldo + p.K) * 4) : 0, 0x00020000);
         if (GATHER) {      // host guarantees K % BK == 0 and no split-k: every tile is full
 #pragma unroll
             for (int i = 0; i < NVA; ++i) {
@@ -424,7 +439,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 int64_t src = p.g_idx[smp];
                 src = src < 0 ? 0 : (src >= p.g_N ? p.g_N - 1 : src);        // np.take would raise; clamp like vqa_gather_features
                 gsrc[i] = p.A + (src * p.g_R + reg_row) * (int64_t)p.lda + kq;
-                gdst[i] = (p.g_out != nullptr && n0 == 0 && m < p.M) ? p.g_out + (int64_t)m * p.g_ldo + kq : nullptr;
+                gdst[i] = (m < p.M) ? (unsigned)(((int64_t)m * p.g_ldo + kq) * 4) : Stager<BM, BK, A_KC, NT>::OOB;
             }
         }
         auto load_a = [&](int k0) {
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             load_b(kbeg);
             sa.store(L0);
             sb.store(L0 + A_FL);
-            if (GATHER) sa.store_ptr(gdst, 0);
+            if (g_store) sa.store_buf(rsG, gdst, 0u);
         }
         __syncthreads();
         int t = 0;
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 __builtin_amdgcn_sched_barrier(0);
                 sa.store(L1);
                 sb.store(L1 + A_FL);
-                if (GATHER) sa.store_ptr(gdst, (t + 1) * BK);
+                if (g_store) sa.store_buf(rsG, gdst, (unsigned)((t + 1) * BK) * 4u);
                 __syncthreads();
                 if (GATHER) sa.load_ptr(gsrc, (t + 2) * BK); else sa.load_full(rsA, oa);
                 sb.load_full(rsB, ob);
@@ -522,7 +537,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
                 __builtin_amdgcn_sched_barrier(0);
                 sa.store(L0);
                 sb.store(L0 + A_FL);
-                if (GATHER) sa.store_ptr(gdst, (t + 2) * BK);
+                if (g_store) sa.store_buf(rsG, gdst, (unsigned)((t + 2) * BK) * 4u);
                 __syncthreads();
             }
         }
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
             __builtin_amdgcn_sched_barrier(0);
             sa.store(nxt);
             sb.store(nxt + A_FL);
-            if (GATHER) sa.store_ptr(gdst, (t + 1) * BK);
+            if (g_store) sa.store_buf(rsG, gdst, (unsigned)((t + 1) * BK) * 4u);
             __syncthreads();
         }
         if (nt > 0) {
@@ -1130,6 +1145,7 @@ extern "C" int vqa_gemm_f32_gather(int M, int N, int K, const float* table, int 
     VQA_REQUIRE(bb < 0xFFFFFF00ll, VQA_ERR_UNSUPPORTED);
     a.a_bytes = 0;                     // A is addressed through per-lane 64-bit pointers (the table may exceed 4 GiB)
     a.b_bytes = (unsigned)bb;
+    VQA_REQUIRE(gathered_out == nullptr || ((int64_t)(M - 1) * ldg + K) * 4 < 0xFFFFFF00ll, VQA_ERR_UNSUPPORTED);
     a.g_idx = idx; a.g_R = R; a.g_N = n_samples_in_table; a.g_out = gathered_out; a.g_ldo = ldg;
     a.k_per_split = (int)cdiv(K, 64) * 64;
     const EpiArgs ep{};

@@ -1,0 +1,457 @@
+// Host-side composition of the cfg-5 pre-training model: one call enqueues the whole forward
+// (or backward) pass of vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py on the caller's stream -- the
+// counterpart of vqa_fusion_forward / vqa_fusion_backward for the fusion model.
+//
+// Per category k in {object, attribute} (reference lines relative to that file):
+//   build_*_V_ft      :323-364, :414-455   6-d box -> FC 1024 + LN + ReLU for the 36 regions (once per image) and the
+//                                          n = 5 key boxes, Hadamard attention + pooling over the raw features with the
+//                                          x5 tile of V_ft never materialised (attn_pool_*_rep)
+//   build_*_blank_fill:505-609             L_GloVe embedding -> GRU over the caption with a blank (length-sorted live
+//                                          prefix) -> fusion MLP -> classifier -> masked softmax-CE, top-1 / top-5
+//   build_*_wordset   :366-412, :457-503   tanh(word-set embedding) -> FC + LN + tanh -> the same fusion MLP
+//   n_way_classification_loss :675-706
+// LayerNorm instance indices follow the TF graph build order (oracle/pretrain_oracle.py): scope[ki] for the V_ft /
+// blank-fill / wordset_ft call sites, scope[2 + ki] for the word-set call sites of the shared fusion MLP.
+//
+// The workspace layout is a function of the dims alone, so the host views named intermediates without copies.
+#include <string.h>
+
+#include <set>
+#include <string>
+#include <vector>
+
+#include "vqa_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- small kernels of this model
+// key6 = (y1, x1, y2, x2, y2 - y1, x2 - x1)   (:330-333)
+__global__ __launch_bounds__(256) void box6_kernel(const float* __restrict__ key, float* __restrict__ key6, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = reinterpret_cast<const float4*>(key)[i];
+    float* o = key6 + (int64_t)i * 6;
+    o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = b.z - b.x; o[5] = b.w - b.y;
+}
+
+// valid[b, j] = j < num[b] ; inv_valid = 1 / sum(valid)     (tf.sequence_mask + reduce_sum, :675-706)
+__global__ __launch_bounds__(256) void valid_kernel(const int32_t* __restrict__ num, float* __restrict__ valid,
+                                                    float* __restrict__ inv_valid, int B, int n) {
+    __shared__ float red[16];
+    float tot = 0.f;
+    for (int i = threadIdx.x; i < B * n; i += 256) {
+        const float v = (i % n) < num[i / n] ? 1.f : 0.f;
+        valid[i] = v;
+        tot += v;
+    }
+    tot = block_sum(tot, red);
+    if (threadIdx.x == 0) inv_valid[0] = 1.f / tot;
+}
+
+// out[i, :] = in[index[i], :]   (rows of `cols` 4-byte words; index == NULL copies)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __restrict__ in, const int32_t* __restrict__ index,
+                                                          uint32_t* __restrict__ out, int rows, int cols) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        out[i] = in[(int64_t)(index ? index[r] : r) * cols + c];
+    }
+}
+
+// report[3 h + j] = sum_rows stats_h[:, j] * inv_valid_h (j = loss, top-1, top-k), report[12] = sum of the 4 losses
+struct ReportArgs { const float* stats[4]; const float* inv[4]; int rows; };
+__global__ __launch_bounds__(256) void pretrain_report_kernel(ReportArgs a, float* __restrict__ report) {
+    __shared__ float red[16];
+    __shared__ float loss[4];
+    for (int h = 0; h < 4; ++h) {
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int i = threadIdx.x; i < a.rows; i += 256) s += a.stats[h][(int64_t)i * 4 + j];
+            s = block_sum(s, red);
+            if (threadIdx.x == 0) {
+                const float v = s * a.inv[h][0];
+                report[3 * h + j] = v;
+                if (j == 0) loss[h] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) report[12] = ((loss[0] + loss[1]) + loss[2]) + loss[3];
+}
+
+// ---------------------------------------------------------------- workspace layout
+struct Entry { std::string name; int64_t off, n; };
+struct Layout {
+    std::vector<Entry> e;
+    int64_t total = 0;
+    void add(const std::string& name, int64_t n) {
+        e.push_back({name, total, n});
+        total += ((n * 4 + 255) / 256) * 256;
+    }
+    const Entry* find(const std::string& name) const {
+        for (const auto& x : e)
+            if (x.name == name) return &x;
+        return nullptr;
+    }
+};
+
+const char* const KIND[2] = {"obj", "attr"};
+const char* const HEAD[2] = {"bf", "ws"};      // blank fill, word set
+
+int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+Layout make_layout(const vqa_pretrain_dims_t& d) {
+    Layout L;
+    const int64_t B = d.B, n = d.n, R = d.R, D = d.D, H = d.H, W = d.W, A = d.A, T = d.L, Bn = B * n;
+    for (int k = 0; k < 2; ++k) {
+        const std::string p = std::string(KIND[k]) + "/";
+        L.add(p + "key6", Bn * 6);
+        L.add(p + "v_pre", B * R * H); L.add(p + "v", B * R * H); L.add(p + "v_mean", B); L.add(p + "v_rstd", B);
+        L.add(p + "qv_pre", Bn * H); L.add(p + "qv", Bn * H); L.add(p + "qv_mean", B); L.add(p + "qv_rstd", B);
+        L.add(p + "att", Bn * R); L.add(p + "pooled", Bn * D);
+        L.add(p + "valid", Bn); L.add(p + "inv_valid", 4);
+        L.add(p + "blanks_s", Bn * T); L.add(p + "lens_s", Bn);
+        L.add(p + "x_tm", T * Bn * W); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
+        L.add(p + "gru_r", T * Bn * H); L.add(p + "gru_u", T * Bn * H); L.add(p + "gru_c", T * Bn * H);
+        L.add(p + "gru_rh", T * Bn * H);
+        L.add(p + "bf_state", Bn * H);
+        L.add(p + "wse", Bn * W); L.add(p + "ws", Bn * W);
+        L.add(p + "wf_pre", Bn * H); L.add(p + "wf", Bn * H); L.add(p + "wf_mean", B); L.add(p + "wf_rstd", B);
+        for (int t = 0; t < 2; ++t) {
+            const std::string q = p + HEAD[t] + "/";
+            L.add(q + "vl_pre", Bn * H); L.add(q + "vl", Bn * H); L.add(q + "vl_mean", B); L.add(q + "vl_rstd", B);
+            L.add(q + "ll_pre", Bn * H); L.add(q + "ll", Bn * H); L.add(q + "ll_mean", B); L.add(q + "ll_rstd", B);
+            L.add(q + "jin", Bn * H);
+            L.add(q + "j_pre", Bn * 2 * H); L.add(q + "j", Bn * 2 * H); L.add(q + "j_mean", B); L.add(q + "j_rstd", B);
+            L.add(q + "z", Bn * A); L.add(q + "dz", Bn * A); L.add(q + "stats", Bn * 4);
+        }
+    }
+    L.add("report", 16);
+    // backward scratch, shared by the two categories
+    L.add("d_j", Bn * 2 * H); L.add("d_jpre", Bn * 2 * H); L.add("d_jin", Bn * H);
+    L.add("d_vl", Bn * H); L.add("d_ll", Bn * H); L.add("d_vlpre", Bn * H); L.add("d_llpre", Bn * H);
+    L.add("d_pl", Bn * D); L.add("d_pooled", Bn * D);
+    L.add("d_state", Bn * H); L.add("d_state_s", Bn * H); L.add("d_hscratch", Bn * H);
+    L.add("dxp", T * Bn * 3 * H); L.add("dx", T * Bn * W);
+    L.add("d_wf", Bn * H); L.add("d_wfpre", Bn * H); L.add("d_ws", Bn * W); L.add("d_wse", Bn * W);
+    L.add("d_v", B * R * H); L.add("d_vpre", B * R * H); L.add("d_qv", Bn * H); L.add("d_qvpre", Bn * H);
+    L.add("part_a", B * 2 * H); L.add("part_b", B * 2 * H); L.add("part_c", B * 2 * H);
+    L.add("part_dw", Bn * H); L.add("part_db", Bn);
+    L.add("vec_a", max64(max64(A, 3 * H), 16)); L.add("vec_b", max64(max64(A, 3 * H), 16));
+    L.add("vec_c", max64(max64(A, 3 * H), 16));
+    L.add("sq", 16);
+    int64_t gw = 4;
+    auto g = [&](int tA, int tB, int64_t M, int64_t N, int64_t K) {
+        gw = max64(gw, vqa_gemm_workspace_floats(tA, tB, (int)M, (int)N, (int)K, 0));
+    };
+    g(0, 0, B * R, H, 6); g(0, 0, Bn, H, 6); g(0, 0, Bn, H, D); g(0, 0, Bn, H, H); g(0, 0, Bn, 2 * H, H);
+    g(0, 0, Bn, A, 2 * H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
+    g(1, 0, 2 * H, A, Bn); g(0, 1, Bn, 2 * H, A); g(1, 0, H, 2 * H, Bn); g(0, 1, Bn, H, 2 * H); g(1, 0, D, H, Bn);
+    g(0, 1, Bn, D, H); g(1, 0, H, H, Bn); g(0, 1, Bn, H, H); g(1, 0, W, H, Bn); g(0, 1, Bn, W, H);
+    g(1, 0, W, 2 * H, T * Bn); g(1, 0, H, 2 * H, T * Bn); g(1, 0, W, H, T * Bn); g(1, 0, H, H, T * Bn);
+    g(0, 1, T * Bn, W, 2 * H); g(0, 1, T * Bn, W, H); g(1, 0, 6, H, B * R); g(1, 0, 6, H, Bn);
+    L.add("gemm_ws", gw);
+    int64_t cw = 4;
+    cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)Bn, (int)A));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)(T * Bn), (int)(3 * H)));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)Bn, (int)H));
+    L.add("colsum_ws", 3 * cw);
+    L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * Bn * W), 4));
+    return L;
+}
+
+bool dims_ok(const vqa_pretrain_dims_t* d) {
+    return d && d->B > 0 && d->n > 0 && d->n <= 8 && d->R > 0 && d->D > 0 && d->H > 0 && d->W > 0 && d->A > 0 &&
+           d->Vq > 0 && d->n_ws > 0 && d->L > 0 && d->H % 4 == 0 && d->D % 4 == 0;
+}
+
+#define TRY(x)                           \
+    do {                                 \
+        int rc__ = (x);                  \
+        if (rc__ != VQA_OK) return rc__; \
+    } while (0)
+
+struct Ctx {
+    const vqa_pretrain_dims_t& d;
+    const Layout& L;
+    char* ws;
+    hipStream_t st;
+    float* f(const std::string& name) const { return reinterpret_cast<float*>(ws + L.find(name)->off); }
+    int32_t* i32(const std::string& name) const { return reinterpret_cast<int32_t*>(ws + L.find(name)->off); }
+    int64_t count(const std::string& name) const { return L.find(name)->n; }
+    int gemm(int tA, int tB, int64_t M, int64_t N, int64_t K, const float* A, int lda, const float* B, int ldb, float* C,
+             int ldc, const float* bias = nullptr, const float* D = nullptr, int ldd = 0) const {
+        return vqa_gemm_f32(tA, tB, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, bias, D, ldd, 0, f("gemm_ws"),
+                            count("gemm_ws"), st);
+    }
+};
+
+// modules.fc_layer forward: FC on the last axis, layer_norm over groups of `rows` rows, activation (0 relu, 1 tanh)
+int fc_ln_fwd(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N, const vqa_pt_fc_t& p, int ln, int rows,
+              int act, const std::string& pre, const std::string& y, const std::string& mean, const std::string& rstd,
+              const uint8_t* keep, float keep_prob) {
+    TRY(c.gemm(0, 0, M, N, K, x, (int)K, p.w, (int)N, c.f(pre), (int)N, p.b));
+    return vqa_ln_act_fwd(c.f(pre), p.gamma[ln], p.beta[ln], keep, keep_prob, c.f(y), c.f(mean), c.f(rstd),
+                          (int)(M / rows), rows, (int)N, act, c.st);
+}
+
+// Gradient accumulation over the call sites that share a variable: the first contribution overwrites (gradient
+// buffers are not cleared between steps), later ones add.
+struct Acc {
+    const Ctx& c;
+    std::set<const float*> touched;
+    int vec(float* grad, const float* value, int64_t n) {      // value already computed somewhere else
+        if (touched.insert(grad).second)
+            return hipMemcpyAsync(grad, value, (size_t)n * 4, hipMemcpyDeviceToDevice, c.st) == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
+        return vqa_add_inplace(grad, value, n, c.st);
+    }
+    // dW (+)= x^T * dpre
+    int weight(float* gw, const float* x, int ldx, const float* dpre, int ldp, int64_t K, int64_t N, int64_t M) {
+        const bool first = touched.insert(gw).second;
+        return c.gemm(1, 0, K, N, M, x, ldx, dpre, ldp, gw, (int)N, nullptr, first ? nullptr : gw, (int)N);
+    }
+    // three column sums (d_gamma, d_beta, d_bias partials [G, N]) into their gradients
+    int colsum3(const float* p0, const float* p1, const float* p2, int64_t G, int64_t N, float* g0, float* g1, float* g2) {
+        const bool f0 = touched.count(g0) == 0, f1 = touched.count(g1) == 0, f2 = touched.count(g2) == 0;
+        float* o0 = f0 ? g0 : c.f("vec_a");
+        float* o1 = f1 ? g1 : c.f("vec_b");
+        float* o2 = f2 ? g2 : c.f("vec_c");
+        TRY(vqa_colsum3(p0, p1, p2, (int)G, (int)N, (int)N, o0, o1, o2, c.f("colsum_ws"), c.count("colsum_ws"), c.st));
+        if (!f0) TRY(vqa_add_inplace(g0, o0, N, c.st));
+        if (!f1) TRY(vqa_add_inplace(g1, o1, N, c.st));
+        if (!f2) TRY(vqa_add_inplace(g2, o2, N, c.st));
+        touched.insert(g0); touched.insert(g1); touched.insert(g2);
+        return VQA_OK;
+    }
+    int colsum(const float* X, int64_t M, int64_t N, int ldx, float* grad) {
+        const bool first = touched.insert(grad).second;
+        float* o = first ? grad : c.f("vec_a");
+        TRY(vqa_colsum(X, (int)M, (int)N, ldx, o, c.f("colsum_ws"), c.count("colsum_ws"), c.st));
+        if (!first) TRY(vqa_add_inplace(grad, o, N, c.st));
+        return VQA_OK;
+    }
+};
+
+// backward of fc_ln_fwd: dy -> d_pre (named), parameter gradients accumulated, optional dx = d_pre * W^T
+int fc_ln_bwd(const Ctx& c, Acc& acc, const float* dy, const float* x, int64_t M, int64_t K, int64_t N, const vqa_pt_fc_t& p,
+              const vqa_pt_fc_t& g, int ln, int rows, int act, const std::string& pre, const std::string& mean,
+              const std::string& rstd, const uint8_t* keep, float keep_prob, const std::string& d_pre, float* dx) {
+    const int64_t G = M / rows;
+    TRY(vqa_ln_act_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma[ln], p.beta[ln], keep, keep_prob, c.f(d_pre),
+                       c.f("part_a"), c.f("part_b"), c.f("part_c"), (int)G, rows, (int)N, act, c.st));
+    TRY(acc.colsum3(c.f("part_a"), c.f("part_b"), c.f("part_c"), G, N, g.gamma[ln], g.beta[ln], g.b));
+    TRY(acc.weight(g.w, x, (int)K, c.f(d_pre), (int)N, K, N, M));
+    if (dx != nullptr) TRY(c.gemm(0, 1, M, K, N, c.f(d_pre), (int)N, p.w, (int)N, dx, (int)K));
+    return VQA_OK;
+}
+
+int gather_rows(const void* in, const int32_t* index, void* out, int64_t rows, int64_t cols, hipStream_t st) {
+    if (rows * cols == 0) return VQA_OK;
+    const int grid = (int)std::min<int64_t>((rows * cols + 255) / 256, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, st, static_cast<const uint32_t*>(in), index,
+                       static_cast<uint32_t*>(out), (int)rows, (int)cols);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+const char* const REPORT_KEYS[13] = {
+    "obj_blank_fill_loss", "obj_blank_fill_acc", "obj_blank_fill_top_5_acc", "obj_wordset_loss", "obj_wordset_acc",
+    "obj_wordset_top_5_acc", "attr_blank_fill_loss", "attr_blank_fill_acc", "attr_blank_fill_top_5_acc",
+    "attr_wordset_loss", "attr_wordset_acc", "attr_wordset_top_5_acc", "total_loss"};
+
+}  // namespace
+
+extern "C" const char* vqa_pretrain_report_key(int i) { return (i >= 0 && i < 13) ? REPORT_KEYS[i] : nullptr; }
+
+extern "C" int64_t vqa_pretrain_workspace_bytes(const vqa_pretrain_dims_t* dims) {
+    if (!dims_ok(dims)) return VQA_ERR_ARG;
+    return make_layout(*dims).total;
+}
+
+extern "C" int vqa_pretrain_tensor(const vqa_pretrain_dims_t* dims, const char* name, int64_t* offset_bytes,
+                                   int64_t* n_elems) {
+    if (!dims_ok(dims) || name == nullptr) return VQA_ERR_ARG;
+    const Layout L = make_layout(*dims);
+    const Entry* e = L.find(name);
+    if (e == nullptr) return VQA_ERR_ARG;
+    if (offset_bytes) *offset_bytes = e->off;
+    if (n_elems) *n_elems = e->n;
+    return VQA_OK;
+}
+
+extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* P,
+                                    const vqa_pretrain_batch_t* bt, void* workspace, int64_t workspace_bytes,
+                                    int want_dz, void* stream) {
+    VQA_REQUIRE(dims_ok(dims) && P && bt && workspace, VQA_ERR_ARG);
+    const Layout L = make_layout(*dims);
+    VQA_REQUIRE(workspace_bytes >= L.total, VQA_ERR_WORKSPACE);
+    VQA_REQUIRE(vqa_aligned16(workspace), VQA_ERR_ALIGN);
+    const Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    const int64_t B = dims->B, n = dims->n, R = dims->R, D = dims->D, H = dims->H, W = dims->W, A = dims->A, T = dims->L;
+    const int64_t Bn = B * n;
+    VQA_REQUIRE(bt->image_ft && bt->spatial_ft && bt->num_boxes, VQA_ERR_ARG);
+    ReportArgs ra{};
+    ra.rows = (int)Bn;
+    for (int k = 0; k < 2; ++k) {
+        const vqa_pretrain_kind_t& kb = bt->kind[k];
+        VQA_REQUIRE(kb.normal_boxes && kb.fills && kb.blanks && kb.blanks_len && kb.wordsets && kb.num, VQA_ERR_ARG);
+        VQA_REQUIRE((kb.perm == nullptr) == (kb.inv == nullptr) && (kb.perm == nullptr) == (kb.live_rows == nullptr),
+                    VQA_ERR_ARG);
+        const std::string p = std::string(KIND[k]) + "/";
+        // ---- build_*_V_ft: spatial attention over the regions
+        hipLaunchKernelGGL(box6_kernel, dim3((unsigned)((Bn + 255) / 256)), dim3(256), 0, c.st, kb.normal_boxes,
+                           c.f(p + "key6"), (int)Bn);
+        VQA_CHECK_LAUNCH();
+        TRY(fc_ln_fwd(c, bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, k, (int)R, 0, p + "v_pre", p + "v", p + "v_mean",
+                      p + "v_rstd", nullptr, 1.f));
+        TRY(fc_ln_fwd(c, c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, k, (int)n, 0, p + "qv_pre", p + "qv", p + "qv_mean",
+                      p + "qv_rstd", nullptr, 1.f));
+        TRY(vqa_attn_pool_fwd_rep(c.f(p + "v"), c.f(p + "qv"), bt->image_ft, bt->num_boxes, P->spat_att_score.w,
+                                  P->spat_att_score.b, kb.keep_att, dims->keep_att, c.f(p + "att"), c.f(p + "pooled"),
+                                  (int)B, (int)n, (int)R, (int)H, (int)D, c.st));
+        hipLaunchKernelGGL(valid_kernel, dim3(1), dim3(256), 0, c.st, kb.num, c.f(p + "valid"), c.f(p + "inv_valid"),
+                           (int)B, (int)n);
+        VQA_CHECK_LAUNCH();
+
+        auto head = [&](int t, const float* l_ft, const uint8_t* jmask) -> int {
+            const std::string q = p + HEAD[t] + "/";
+            const int ln = (t == 0) ? k : 2 + k;
+            TRY(fc_ln_fwd(c, c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, ln, (int)n, 0, q + "vl_pre", q + "vl",
+                          q + "vl_mean", q + "vl_rstd", nullptr, 1.f));
+            TRY(fc_ln_fwd(c, l_ft, Bn, H, H, P->q_linear_l, ln, (int)n, 0, q + "ll_pre", q + "ll", q + "ll_mean",
+                          q + "ll_rstd", nullptr, 1.f));
+            TRY(vqa_mul(c.f(q + "vl"), c.f(q + "ll"), c.f(q + "jin"), Bn * H, c.st));
+            TRY(fc_ln_fwd(c, c.f(q + "jin"), Bn, H, 2 * H, P->joint_fc, ln, (int)n, 0, q + "j_pre", q + "j", q + "j_mean",
+                          q + "j_rstd", jmask, dims->keep_joint));
+            TRY(c.gemm(0, 0, Bn, A, 2 * H, c.f(q + "j"), (int)(2 * H), P->classifier.w, (int)A, c.f(q + "z"), (int)A,
+                       P->classifier.b));
+            TRY(vqa_softmax_ce_fwd(c.f(q + "z"), kb.fills, c.f(p + "valid"), 5, c.f(p + "inv_valid"), c.f(q + "stats"),
+                                   want_dz ? c.f(q + "dz") : nullptr, (int)Bn, (int)A, c.st));
+            ra.stats[2 * k + t] = c.f(q + "stats");
+            ra.inv[2 * k + t] = c.f(p + "inv_valid");
+            return VQA_OK;
+        };
+
+        // ---- build_*_blank_fill: captions in length order when the host sorted them (live prefix recurrence)
+        TRY(gather_rows(kb.blanks, kb.perm, c.i32(p + "blanks_s"), Bn, T, c.st));
+        TRY(gather_rows(kb.blanks_len, kb.perm, c.i32(p + "lens_s"), Bn, 1, c.st));
+        TRY(vqa_embed_fwd(P->l_glove, c.i32(p + "blanks_s"), c.f(p + "x_tm"), (int)Bn, (int)T, (int)W, dims->Vq, c.st));
+        float* xp = c.f(p + "xp");
+        TRY(c.gemm(0, 0, T * Bn, 2 * H, W, c.f(p + "x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
+        TRY(c.gemm(0, 0, T * Bn, H, W, c.f(p + "x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+        float* hs = c.f(p + "hs");
+        if (hipMemsetAsync(hs, 0, (size_t)Bn * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+        const float* Wg_h = P->gru_wg + W * 2 * H;
+        const float* Wc_h = P->gru_wc + W * H;
+        if (kb.live_rows != nullptr)
+            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, c.i32(p + "lens_s"), kb.live_rows, hs, c.f(p + "gru_r"),
+                                     c.f(p + "gru_u"), c.f(p + "gru_c"), c.f(p + "gru_rh"), (int)T, (int)Bn, (int)H, c.st));
+        else
+            TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
+                                c.f(p + "gru_c"), c.f(p + "gru_rh"), (int)T, (int)Bn, (int)H, c.st));
+        TRY(gather_rows(hs + T * Bn * H, kb.inv, c.f(p + "bf_state"), Bn, H, c.st));      // back to caption order
+        TRY(head(0, c.f(p + "bf_state"), kb.keep_bf_joint));
+        // ---- build_*_wordset
+        TRY(vqa_embed_fwd(P->wordset_map, kb.wordsets, c.f(p + "wse"), (int)Bn, 1, (int)W, dims->n_ws, c.st));
+        TRY(vqa_tanh_fwd(c.f(p + "wse"), c.f(p + "ws"), Bn * W, c.st));
+        TRY(fc_ln_fwd(c, c.f(p + "ws"), Bn, W, H, P->wordset_ft, k, (int)n, 1, p + "wf_pre", p + "wf", p + "wf_mean",
+                      p + "wf_rstd", nullptr, 1.f));
+        TRY(head(1, c.f(p + "wf"), kb.keep_ws_joint));
+    }
+    hipLaunchKernelGGL(pretrain_report_kernel, dim3(1), dim3(256), 0, c.st, ra, c.f("report"));
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* P,
+                                     const vqa_pretrain_params_t* G, const vqa_pretrain_batch_t* bt, void* workspace,
+                                     int64_t workspace_bytes, float* slice_sq, void* stream) {
+    VQA_REQUIRE(dims_ok(dims) && P && G && bt && workspace, VQA_ERR_ARG);
+    const Layout L = make_layout(*dims);
+    VQA_REQUIRE(workspace_bytes >= L.total, VQA_ERR_WORKSPACE);
+    const Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
+    const int64_t B = dims->B, n = dims->n, R = dims->R, D = dims->D, H = dims->H, W = dims->W, A = dims->A, T = dims->L;
+    const int64_t Bn = B * n;
+    Acc acc{c, {}};
+    // the two embedding tables are scatter-added: cleared here; every other gradient is overwritten on first touch
+    if (hipMemsetAsync(G->l_glove, 0, (size_t)dims->Vq * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+    if (hipMemsetAsync(G->wordset_map, 0, (size_t)dims->n_ws * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+    const float* sq_prev = nullptr;
+    auto add_slice_sq = [&](const float* g, int64_t cnt) -> int {     // running sum of the un-aggregated slice norms
+        TRY(vqa_sumsq(g, cnt, sq_prev, c.f("sq"), c.f("sumsq_ws"), c.count("sumsq_ws"), c.st));
+        sq_prev = c.f("sq");
+        return VQA_OK;
+    };
+    for (int k = 0; k < 2; ++k) {
+        const vqa_pretrain_kind_t& kb = bt->kind[k];
+        const std::string p = std::string(KIND[k]) + "/";
+        bool have_dpooled = false;
+        auto head_bwd = [&](int t, const float* l_ft, const uint8_t* jmask, float* d_lft) -> int {
+            const std::string q = p + HEAD[t] + "/";
+            const int ln = (t == 0) ? k : 2 + k;
+            TRY(acc.weight(G->classifier.w, c.f(q + "j"), (int)(2 * H), c.f(q + "dz"), (int)A, 2 * H, A, Bn));
+            TRY(acc.colsum(c.f(q + "dz"), Bn, A, (int)A, G->classifier.b));
+            TRY(c.gemm(0, 1, Bn, 2 * H, A, c.f(q + "dz"), (int)A, P->classifier.w, (int)A, c.f("d_j"), (int)(2 * H)));
+            TRY(fc_ln_bwd(c, acc, c.f("d_j"), c.f(q + "jin"), Bn, H, 2 * H, P->joint_fc, G->joint_fc, ln, (int)n, 0,
+                          q + "j_pre", q + "j_mean", q + "j_rstd", jmask, dims->keep_joint, "d_jpre", c.f("d_jin")));
+            TRY(vqa_mul_bwd(c.f("d_jin"), c.f(q + "vl"), c.f(q + "ll"), c.f("d_vl"), c.f("d_ll"), Bn * H, c.st));
+            float* dpl = have_dpooled ? c.f("d_pl") : c.f("d_pooled");
+            TRY(fc_ln_bwd(c, acc, c.f("d_vl"), c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, G->pooled_linear_l, ln,
+                          (int)n, 0, q + "vl_pre", q + "vl_mean", q + "vl_rstd", nullptr, 1.f, "d_vlpre", dpl));
+            if (have_dpooled) TRY(vqa_add_inplace(c.f("d_pooled"), dpl, Bn * D, c.st));
+            have_dpooled = true;
+            return fc_ln_bwd(c, acc, c.f("d_ll"), l_ft, Bn, H, H, P->q_linear_l, G->q_linear_l, ln, (int)n, 0, q + "ll_pre",
+                             q + "ll_mean", q + "ll_rstd", nullptr, 1.f, "d_llpre", d_lft);
+        };
+        // ---- blank fill -> GRU -> L_GloVe
+        TRY(head_bwd(0, c.f(p + "bf_state"), kb.keep_bf_joint, c.f("d_state")));
+        TRY(gather_rows(c.f("d_state"), kb.perm, c.f("d_state_s"), Bn, H, c.st));          // into the sorted order
+        const float* Wg_h = P->gru_wg + W * 2 * H;
+        const float* Wc_h = P->gru_wc + W * H;
+        float* dxp = c.f("dxp");
+        const float* hs = c.f(p + "hs");
+        if (kb.live_rows != nullptr)
+            TRY(vqa_gru_seq_bwd_live(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), kb.live_rows, hs, c.f(p + "gru_r"),
+                                     c.f(p + "gru_u"), c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H,
+                                     c.st));
+        else
+            TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
+                                c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H, c.st));
+        const int ld3 = (int)(3 * H);
+        TRY(acc.weight(G->gru_wg, c.f(p + "x_tm"), (int)W, dxp, ld3, W, 2 * H, T * Bn));
+        TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * Bn));
+        TRY(acc.weight(G->gru_wc, c.f(p + "x_tm"), (int)W, dxp + 2 * H, ld3, W, H, T * Bn));
+        TRY(acc.weight(G->gru_wc + W * H, c.f(p + "gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * Bn));
+        TRY(acc.colsum(dxp, T * Bn, 2 * H, ld3, G->gru_bg));
+        TRY(acc.colsum(dxp + 2 * H, T * Bn, H, ld3, G->gru_bc));
+        float* dx = c.f("dx");
+        TRY(c.gemm(0, 1, T * Bn, W, 2 * H, dxp, ld3, P->gru_wg, (int)(2 * H), dx, (int)W));
+        TRY(c.gemm(0, 1, T * Bn, W, H, dxp + 2 * H, ld3, P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+        TRY(vqa_embed_bwd_len_det(dx, c.i32(p + "blanks_s"), c.i32(p + "lens_s"), G->l_glove, (int)Bn, (int)T, (int)W,
+                                  dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
+        TRY(add_slice_sq(dx, T * Bn * W));
+        // ---- word set -> wordset_ft -> tanh -> wordset_map
+        TRY(head_bwd(1, c.f(p + "wf"), kb.keep_ws_joint, c.f("d_wf")));
+        TRY(fc_ln_bwd(c, acc, c.f("d_wf"), c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, k, (int)n, 1, p + "wf_pre",
+                      p + "wf_mean", p + "wf_rstd", nullptr, 1.f, "d_wfpre", c.f("d_ws")));
+        TRY(vqa_tanh_bwd(c.f("d_ws"), c.f(p + "ws"), c.f("d_wse"), Bn * W, c.st));
+        TRY(vqa_embed_bwd_len_det(c.f("d_wse"), kb.wordsets, nullptr, G->wordset_map, (int)Bn, 1, (int)W, dims->n_ws,
+                                  (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
+        TRY(add_slice_sq(c.f("d_wse"), Bn * W));
+        // ---- spatial attention
+        TRY(vqa_attn_pool_bwd_rep(c.f("d_pooled"), c.f(p + "v"), c.f(p + "qv"), bt->image_ft, c.f(p + "att"),
+                                  P->spat_att_score.w, kb.keep_att, dims->keep_att, c.f("d_v"), c.f("d_qv"),
+                                  c.f("part_dw"), c.f("part_db"), (int)B, (int)n, (int)R, (int)H, (int)D, c.st));
+        TRY(acc.colsum(c.f("part_dw"), Bn, H, (int)H, G->spat_att_score.w));
+        TRY(acc.colsum(c.f("part_db"), Bn, 1, 1, G->spat_att_score.b));
+        TRY(fc_ln_bwd(c, acc, c.f("d_v"), bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, G->spat_v_linear_v, k, (int)R, 0,
+                      p + "v_pre", p + "v_mean", p + "v_rstd", nullptr, 1.f, "d_vpre", nullptr));
+        TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, k, (int)n, 0,
+                      p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
+    }
+    if (slice_sq != nullptr && sq_prev != nullptr)
+        if (hipMemcpyAsync(slice_sq, sq_prev, sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
+            return VQA_ERR_LAUNCH;
+    return VQA_OK;
+}

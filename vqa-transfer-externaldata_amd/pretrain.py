@@ -6,9 +6,11 @@ caption with a blank) and word-set conditioned heads for objects and attributes,
 sharing pooled_linear_l / q_linear_l / joint_fc / classifier with ONE LayerNorm variable set per call
 site (TF's un-scoped layer_norm: LayerNorm, LayerNorm_1, ... in graph build order), softmax-CE over
 the obj3000+attr1000 answers with top-1 / top-5 accuracy.  Forward and the hand-derived backward are
-composed here from the C-ABI ops (libvqahot.so); the effective batch is B*n rows and the x n tile of
-V_ft / spatial_ft that the reference materialises (:324-333) never exists: the attention kernels take
-`rep = n` queries per memory and v_linear_v of the (identical) tiles is computed once per image.
+ONE C call each (vqa_pretrain_forward / vqa_pretrain_backward, csrc/pretrain_model.hip: every kernel of the
+pass is enqueued from C++, the workspace is carved from the dims, no torch op runs inside the step); the
+effective batch is B*n rows and the x n tile of V_ft / spatial_ft that the reference materialises (:324-333)
+never exists: the attention kernels take `rep = n` queries per memory and v_linear_v of the (identical) tiles
+is computed once per image.
 """
 from __future__ import annotations
 
@@ -99,7 +101,7 @@ def _pad4(n):
 
 
 class PretrainEngine:
-    def __init__(self, *, n, R, D, H, W, A, Vq, n_ws, params, device="cuda:0"):
+    def __init__(self, *, n, R, D, H, W, A, Vq, n_ws, params, device="cuda:0", deterministic=False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("PretrainEngine needs a GPU (no CPU fallback)")
@@ -131,42 +133,12 @@ class PretrainEngine:
             self.params[k].copy_(torch.as_tensor(np.asarray(params[k])).to(torch.float32))
         self.step_count = 0
         self.report = {}
+        self.Vq, self.n_ws, self.deterministic = Vq, n_ws, bool(deterministic)
+        self.workspace, self.dims = None, None
+        self._p_struct = self._param_struct(self.params)
+        self._g_struct = self._param_struct(self.grads)
 
-    # ------------------------------------------------------------------ layer helpers
-    def _fc_ln(self, x2d, scope, ln_idx, rows, act, keep=None, keep_prob=1.0):
-        p = self.params
-        pre = ops.gemm(x2d, p[scope + "/fc/weights"], bias=p[scope + "/fc/biases"])
-        y, mean, rstd = ops.ln_act_fwd(pre, p[ln_name(scope, ln_idx) + "/gamma"], p[ln_name(scope, ln_idx) + "/beta"],
-                                       rows, act, keep, keep_prob)
-        return y, (x2d, pre, mean, rstd, scope, ln_idx, rows, act, keep, keep_prob)
-
-    def _acc(self, name, value):
-        """first contribution overwrites (grad buffers are not cleared), later ones add"""
-        g = self.grads[name]
-        if name in self._touched:
-            ops.add_inplace(g.view(-1), value.reshape(-1).contiguous())
-        else:
-            g.copy_(value.view(g.shape))
-            self._touched.add(name)
-
-    def _fc_ln_bwd(self, dy, tape, need_dx=True):
-        x2d, pre, mean, rstd, scope, ln_idx, rows, act, keep, keep_prob = tape
-        p = self.params
-        ln = ln_name(scope, ln_idx)
-        dpre, dgamma, dbeta, dbias = ops.ln_act_bwd(dy, pre, mean, rstd, p[ln + "/gamma"], p[ln + "/beta"], rows, act,
-                                                    keep, keep_prob)
-        self._acc(ln + "/gamma", dgamma)
-        self._acc(ln + "/beta", dbeta)
-        self._acc(scope + "/fc/biases", dbias)
-        wname = scope + "/fc/weights"
-        gw = self.grads[wname]
-        if wname in self._touched:          # shared weights: dW += x^T dpre (GEMM with C as its own addend)
-            ops.gemm(x2d, dpre, transA=True, addend=gw, out=gw)
-        else:
-            ops.gemm(x2d, dpre, transA=True, out=gw)
-            self._touched.add(wname)
-        return ops.gemm(dpre, p[wname], transB=True) if need_dx else None
-
+    # ------------------------------------------------------------------ C-ABI plumbing
     def make_keep_masks(self, B, seed, step):
         """reproducible dropout keep-masks for (seed, step): {kind/att, kind/bf_joint, kind/ws_joint}"""
         n, R, H = self.n, self.R, self.H
@@ -178,160 +150,112 @@ class PretrainEngine:
                 off += cnt
         return out
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, batch, masks):
-        """batch: device tensors with the keys of vlmap_memft/datasets/dataset_vlmap.py:128-236 that the
-        model reads; masks: uint8 keep-masks (or None = no dropout) keyed '<kind>/att|bf_joint|ws_joint'."""
-        p, n, R, D, H, W = self.params, self.n, self.R, self.D, self.H, self.W
-        img = batch["image_ft"].contiguous()
-        self._img = img
-        self._mask_att = {k: masks[k + "/att"] for k in KINDS} if masks is not None else {}
-        B = img.shape[0]
-        Bn = B * n
-        spat = batch["spatial_ft"].reshape(B * R, 6).contiguous()
-        nb = batch["num_boxes"].to(torch.int32).contiguous()
-        t = {"B": B, "kinds": {}}
-        stats_all = {}
-        mk = (lambda key: masks[key]) if masks is not None else (lambda key: None)
+    def _param_struct(self, table):
+        def fc(scope, n_ln):
+            f = _lib.PtFc(w=table[scope + "/fc/weights"].data_ptr(), b=table[scope + "/fc/biases"].data_ptr())
+            for i in range(n_ln):
+                f.beta[i] = table[ln_name(scope, i) + "/beta"].data_ptr()
+                f.gamma[i] = table[ln_name(scope, i) + "/gamma"].data_ptr()
+            return f
+        g = "encode_L_blank/rnn/gru_cell/"
+        return _lib.PtParams(
+            wordset_map=table["wordset_map/learn"].data_ptr(), l_glove=table["L_GloVe/embed_map"].data_ptr(),
+            spat_v_linear_v=fc("spat_v_linear_v", 2), spat_q_linear_v=fc("spat_q_linear_v", 2),
+            spat_att_score=fc("spat_att/compute/score", 0), gru_wg=table[g + "gates/kernel"].data_ptr(),
+            gru_bg=table[g + "gates/bias"].data_ptr(), gru_wc=table[g + "candidate/kernel"].data_ptr(),
+            gru_bc=table[g + "candidate/bias"].data_ptr(), pooled_linear_l=fc("pooled_linear_l", 4),
+            q_linear_l=fc("q_linear_l", 4), joint_fc=fc("joint_fc", 4), wordset_ft=fc("wordset_ft", 2),
+            classifier=fc("classifier", 0))
+
+    def _dev(self, v, dtype):
+        t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _batch_struct(self, batch, masks):
+        """C view of one batch (device tensors with the keys of vlmap_memft/datasets/dataset_vlmap.py:128-236 that
+        the model reads).  Converted tensors are cached on the batch dict, so a batch that is fed again (the input
+        pipeline caches its batches) costs no conversion."""
+        cache = batch.setdefault("_pt_dev", {}) if isinstance(batch, dict) else {}
+        def get(key, dtype):
+            if key not in cache:
+                cache[key] = self._dev(batch[key], dtype)
+            return cache[key]
+        keep = [cache, masks]
+        bs = _lib.PtBatch(image_ft=get("image_ft", torch.float32).data_ptr(),
+                          spatial_ft=get("spatial_ft", torch.float32).data_ptr(),
+                          num_boxes=get("num_boxes", torch.int32).data_ptr())
+        B = cache["image_ft"].shape[0]
+        L = None
         for ki, k in enumerate(KINDS):
-            kt = {}
-            key = batch[k + "_blank_fill/normal_boxes"].reshape(Bn, 4)
-            key6 = torch.cat([key, key[:, 2:3] - key[:, 0:1], key[:, 3:4] - key[:, 1:2]], 1).contiguous()
-            v, kt["v_t"] = self._fc_ln(spat, "spat_v_linear_v", ki, R, "relu")            # once per image
-            qv, kt["qv_t"] = self._fc_ln(key6, "spat_q_linear_v", ki, n, "relu")          # LN over (n, H)
-            att, pooled = ops.attn_pool_fwd_rep(v.view(B, R, H), qv, img, nb, p["spat_att/compute/score/fc/weights"],
-                                                p["spat_att/compute/score/fc/biases"], n, mk(k + "/att"), KEEP_ATT)
-            kt.update(v=v, qv=qv, att=att, pooled=pooled)
-            valid = (torch.arange(n, device=self.device)[None, :] < batch[k + "_blank_fill/num"][:, None]) \
-                .float().reshape(Bn).contiguous()
-            inv_valid = (1.0 / valid.sum()).reshape(1).contiguous()
-            fills = batch[k + "_blank_fill/fills"].reshape(Bn).to(torch.int32).contiguous()
-            kt.update(valid=valid)
+            pre = k + "_blank_fill/"
+            kb = bs.kind[ki]
+            kb.normal_boxes = get(pre + "normal_boxes", torch.float32).data_ptr()
+            for f in ("fills", "blanks", "blanks_len", "wordsets", "num"):
+                setattr(kb, f, get(pre + f, torch.int32).data_ptr())
+            Lk = int(cache[pre + "blanks"].shape[-1])
+            assert L is None or L == Lk, "object / attribute captions must be padded to one length"
+            L = Lk
+            if masks is not None:
+                kb.keep_att = masks[k + "/att"].data_ptr()
+                kb.keep_bf_joint = masks[k + "/bf_joint"].data_ptr()
+                kb.keep_ws_joint = masks[k + "/ws_joint"].data_ptr()
+            srt = batch.get(pre + "sort")
+            if srt is not None:       # captions in length order: the recurrence skips finished ones (add_length_sort)
+                if "_dev" not in srt:
+                    live = np.ascontiguousarray(srt["live_rows"], dtype=np.int32)
+                    assert live.shape == (Lk,)
+                    srt["_dev"] = (self._dev(np.asarray(srt["perm"]), torch.int32),
+                                   self._dev(np.asarray(srt["inv"]), torch.int32), live)
+                perm, inv, live = srt["_dev"]
+                kb.perm, kb.inv, kb.live_rows = perm.data_ptr(), inv.data_ptr(), live.ctypes.data
+                keep.append(srt["_dev"])
+        return bs, B, L, keep
 
-            def head(l_ft, ln_idx, jmask, tag):
-                vl, t_vl = self._fc_ln(pooled, "pooled_linear_l", ln_idx, n, "relu")
-                ll, t_ll = self._fc_ln(l_ft, "q_linear_l", ln_idx, n, "relu")
-                jin = ops.mul(vl, ll)
-                j, t_j = self._fc_ln(jin, "joint_fc", ln_idx, n, "relu", jmask, KEEP_JOINT)
-                z = ops.gemm(j, p["classifier/fc/weights"], bias=p["classifier/fc/biases"])
-                stats, dz = ops.softmax_ce(z, fills, valid, inv_valid, TOP_K, want_dz=True)
-                kt[tag] = dict(vl=vl, ll=ll, t_vl=t_vl, t_ll=t_ll, t_j=t_j, j=j, z=z, dz=dz)
-                stats_all[k + "_" + tag] = (stats, inv_valid)
+    def tensor(self, name, dtype=torch.float32):
+        """Named intermediate of the last forward as a torch view of the workspace (vqa_pretrain_tensor)."""
+        off, n = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.vqa_pretrain_tensor(C.byref(self.dims), name.encode(), C.byref(off), C.byref(n)),
+                   "vqa_pretrain_tensor(%s)" % name)
+        return self.workspace[off.value:off.value + 4 * n.value].view(dtype)
 
-            # blank fill: GRU over the caption with a blank (L_GloVe embedding)
-            blanks = batch[k + "_blank_fill/blanks"].reshape(Bn, -1).to(torch.int32).contiguous()
-            L = blanks.shape[1]
-            lens = batch[k + "_blank_fill/blanks_len"].reshape(Bn).to(torch.int32).contiguous()
-            srt = batch.get(k + "_blank_fill/sort")
-            live = None
-            if srt is not None:        # captions in length order: the recurrence skips finished ones (add_length_sort)
-                perm = torch.as_tensor(srt["perm"], device=self.device)
-                kt["inv"], kt["perm"], live = torch.as_tensor(srt["inv"], device=self.device), perm, srt["live_rows"]
-                blanks, lens = blanks.index_select(0, perm).contiguous(), lens.index_select(0, perm).contiguous()
-            x_tm = ops.embed_fwd(p["L_GloVe/embed_map"], blanks)                           # [L, Bn, W]
-            Wg, Wc = p["encode_L_blank/rnn/gru_cell/gates/kernel"], p["encode_L_blank/rnn/gru_cell/candidate/kernel"]
-            xp = torch.empty(L * Bn, 3 * H, dtype=torch.float32, device=self.device)
-            x2 = x_tm.view(L * Bn, W)
-            ops.gemm(x2, Wg[:W], bias=p["encode_L_blank/rnn/gru_cell/gates/bias"], out=xp[:, :2 * H])
-            ops.gemm(x2, Wc[:W], bias=p["encode_L_blank/rnn/gru_cell/candidate/bias"], out=xp[:, 2 * H:])
-            hs, gtape = ops.gru_seq_fwd(xp, Wg[W:], Wc[W:], lens, L, Bn, H, live_rows=live)
-            kt.update(blanks=blanks, lens=lens, x_tm=x_tm, hs=hs, gtape=gtape, L=L, live=live)
-            head(hs[L] if live is None else hs[L].index_select(0, kt["inv"]), ki, mk(k + "/bf_joint"), "blank_fill")
-            # word set: tanh(embedding) -> FC + LN + tanh
-            wsid = batch[k + "_blank_fill/wordsets"].reshape(Bn, 1).to(torch.int32).contiguous()
-            wse = ops.embed_fwd(p["wordset_map/learn"], wsid).view(Bn, W)
-            ws = ops.tanh_fwd(wse)
-            wf, kt["wf_t"] = self._fc_ln(ws, "wordset_ft", ki, n, "tanh")
-            kt.update(wsid=wsid, ws=ws)
-            head(wf, 2 + ki, mk(k + "/ws_joint"), "wordset")
-            t["kinds"][k] = kt
-        self._tape, self._stats = t, stats_all
-        return stats_all
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, batch, masks, want_dz=True):
+        """batch: dict of arrays / tensors (keys of dataset_vlmap's batches; optional '<kind>_blank_fill/sort' from
+        add_length_sort); masks: uint8 keep-masks keyed '<kind>/att|bf_joint|ws_joint' or None (no dropout)."""
+        bs, B, L, keep = self._batch_struct(batch, masks)
+        d = _lib.PtDims(B=B, n=self.n, R=self.R, D=self.D, H=self.H, W=self.W, A=self.A, Vq=self.Vq, n_ws=self.n_ws, L=L,
+                        flags=_lib.FLAG_DETERMINISTIC if self.deterministic else 0, keep_att=KEEP_ATT,
+                        keep_joint=KEEP_JOINT)
+        need = int(self.lib.vqa_pretrain_workspace_bytes(C.byref(d)))
+        if need <= 0:
+            raise _lib.VqaHotError("vqa_pretrain_workspace_bytes rejected the dims")
+        if self.workspace is None or need > self.workspace.numel():
+            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        self.dims, self._bs, self._keepalive = d, bs, keep
+        _lib.check(self.lib.vqa_pretrain_forward(C.byref(d), C.byref(self._p_struct), C.byref(bs),
+                                                 C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
+                                                 1 if want_dz else 0, self._stream()), "vqa_pretrain_forward")
+        Bn = B * self.n
+        self._tape = {"B": B, "kinds": {
+            k: {"att": self.tensor(k + "/att").view(Bn, self.R), "pooled": self.tensor(k + "/pooled").view(Bn, self.D),
+                "blank_fill": {"z": self.tensor(k + "/bf/z").view(Bn, self.A)},
+                "wordset": {"z": self.tensor(k + "/ws/z").view(Bn, self.A)}} for k in KINDS}}
 
     def fetch_report(self):
         """report dict of the reference (13 scalars): <kind>_<task>_{loss,acc,top_5_acc}, total_loss"""
-        rep, total = {}, 0.0
-        for key, (stats, inv) in self._stats.items():
-            s = (stats.sum(0) * inv).cpu().numpy()
-            rep[key + "_loss"], rep[key + "_acc"] = float(s[0]), float(s[1])
-            rep[key + "_top_%d_acc" % TOP_K] = float(s[2])
-            total += float(s[0])
-        rep["total_loss"] = total
-        self.report = rep
-        return rep
+        r = self.tensor("report")[:13].cpu().numpy()
+        self.report = {self.lib.vqa_pretrain_report_key(i).decode(): float(r[i]) for i in range(13)}
+        return self.report
 
-    # ------------------------------------------------------------------ backward
     def backward(self):
-        p, n, R, D, H, W = self.params, self.n, self.R, self.D, self.H, self.W
-        t = self._tape
-        B = t["B"]
-        Bn = B * n
-        self._touched = set()
-        for k in SPARSE_VARS:
-            self.grads[k].zero_()
-        slice_sq = []
-        Wc_cls = p["classifier/fc/weights"]
-        for ki, k in enumerate(KINDS):
-            kt = t["kinds"][k]
-            dpooled = None
-
-            def head_bwd(tag):
-                nonlocal dpooled
-                h = kt[tag]
-                gw = self.grads["classifier/fc/weights"]
-                if "classifier/fc/weights" in self._touched:
-                    ops.gemm(h["j"], h["dz"], transA=True, addend=gw, out=gw)
-                else:
-                    ops.gemm(h["j"], h["dz"], transA=True, out=gw)
-                    self._touched.add("classifier/fc/weights")
-                self._acc("classifier/fc/biases", ops.colsum(h["dz"]))
-                dj = ops.gemm(h["dz"], Wc_cls, transB=True)
-                djin = self._fc_ln_bwd(dj, h["t_j"])
-                dvl, dll = ops.mul_bwd(djin, h["vl"], h["ll"])
-                dpl = self._fc_ln_bwd(dvl, h["t_vl"])
-                dpooled = dpl if dpooled is None else ops.add_inplace(dpooled, dpl)
-                return self._fc_ln_bwd(dll, h["t_ll"])
-
-            # blank fill -> GRU -> L_GloVe
-            dbf = head_bwd("blank_fill")
-            L = kt["L"]
-            Wg, Wc = p["encode_L_blank/rnn/gru_cell/gates/kernel"], p["encode_L_blank/rnn/gru_cell/candidate/kernel"]
-            if kt.get("live") is not None:
-                dbf = dbf.index_select(0, kt["perm"]).contiguous()      # into the length-sorted caption order
-            dxp = ops.gru_seq_bwd(dbf, Wg[W:], Wc[W:], kt["lens"], kt["hs"], kt["gtape"], L, Bn, H,
-                                  live_rows=kt.get("live")).view(L * Bn, 3 * H)
-            x2 = kt["x_tm"].view(L * Bn, W)
-            hs_prev = kt["hs"][:L].reshape(L * Bn, H)
-            rh = kt["gtape"][3].view(L * Bn, H)
-            gWg, gWc = self.grads["encode_L_blank/rnn/gru_cell/gates/kernel"], \
-                self.grads["encode_L_blank/rnn/gru_cell/candidate/kernel"]
-            first = "gru" not in self._touched
-            for A_, B_, out in ((x2, dxp[:, :2 * H], gWg[:W]), (hs_prev, dxp[:, :2 * H], gWg[W:]),
-                                (x2, dxp[:, 2 * H:], gWc[:W]), (rh, dxp[:, 2 * H:], gWc[W:])):
-                ops.gemm(A_, B_, transA=True, out=out, addend=None if first else out)
-            bsum = ops.colsum(dxp)
-            self._acc("encode_L_blank/rnn/gru_cell/gates/bias", bsum[:2 * H])
-            self._acc("encode_L_blank/rnn/gru_cell/candidate/bias", bsum[2 * H:])
-            self._touched.add("gru")
-            dx = ops.gemm(dxp[:, :2 * H], Wg[:W], transB=True)
-            ops.gemm(dxp[:, 2 * H:], Wc[:W], transB=True, addend=dx, out=dx)
-            ops.embed_bwd_into(dx.view(L, Bn, W), kt["blanks"], self.grads["L_GloVe/embed_map"], lens=kt["lens"])
-            slice_sq.append(ops.sumsq(dx.view(-1)))
-            # word set -> wordset_ft -> tanh -> wordset_map
-            dwf = head_bwd("wordset")
-            dws = self._fc_ln_bwd(dwf, kt["wf_t"])
-            dwse = ops.tanh_bwd(dws, kt["ws"])
-            ops.embed_bwd_into(dwse.view(1, Bn, W), kt["wsid"], self.grads["wordset_map/learn"])
-            slice_sq.append(ops.sumsq(dwse.view(-1)))
-            # spatial attention
-            dv, dqv, dw, db = ops.attn_pool_bwd_rep(dpooled, kt["v"].view(B, R, H), kt["qv"], self._img, kt["att"],
-                                                    p["spat_att/compute/score/fc/weights"], n, self._mask_att.get(k),
-                                                    KEEP_ATT)
-            self._acc("spat_att/compute/score/fc/weights", dw)
-            self._acc("spat_att/compute/score/fc/biases", db)
-            self._fc_ln_bwd(dv.view(B * R, H), kt["v_t"], need_dx=False)
-            self._fc_ln_bwd(dqv, kt["qv_t"], need_dx=False)
-        self.grad_flat[self.n_train] = torch.stack(slice_sq).sum()
+        tail = self.grad_flat[self.n_train:]
+        _lib.check(self.lib.vqa_pretrain_backward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct),
+                                                  C.byref(self._bs), C.c_void_p(self.workspace.data_ptr()),
+                                                  self.workspace.numel(), C.c_void_p(tail.data_ptr()), self._stream()),
+                   "vqa_pretrain_backward")
 
     def optimizer_step(self, lr):
         """clip_by_global_norm(20) + Adam; the two embedding tables contribute their UN-AGGREGATED slice
