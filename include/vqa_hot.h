@@ -272,14 +272,16 @@ int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, fl
 typedef struct {
     int32_t B, R, D, H, T, W, A, Vq;
     int64_t N_img;
-    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard */
+    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec */
     float keep_att;          /* 0.8  vlmap/modules.py:82 */
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
     int32_t flags;           /* VQA_FLAG_* bit mask, per call (no process-wide state) */
 } vqa_dims_t;
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
-#define VQA_FLAG_SEPARATE_GATHER 2  /* run the feature gather as its own pass instead of inside v_linear_v's GEMM */
+#define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
+                                     * (vqa_gemm_f32_gather); default: gather on a helper stream beside the question
+                                     * branch's projection GEMMs */
 
 /* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
 typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;
@@ -294,7 +296,9 @@ typedef struct {
     vqa_fc_t pooled_linear_l;           /* [D,H] */
     vqa_fc_t q_linear_l;                /* [H,H] */
     vqa_fc_t joint_fc;                  /* [H,2H] */
-    vqa_fc_t head;                      /* WordWeightAnswer | reasoning/classifier [2H,A] */
+    vqa_fc_t head;                      /* WordWeightAnswer | reasoning/classifier [2H,A]  ([2H,W] for standard_word2vec) */
+    float* answer_glove;                /* standard_word2vec only: constant [W,A] GloVe matrix of the answers
+                                         * (vqa/model_standard_word2vec.py:185-188); NULL otherwise */
 } vqa_params_t;
 
 typedef struct {

@@ -84,8 +84,10 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     ll = _fc_ln_relu(h, P, sc["q_linear_l"])
     j = _fc_ln_relu(pl * ll, P, sc["joint_fc"]) * m_j / O.KEEP_JOINT
     z = F.linear(j, P[sc["head"] + "/fc/weights"].t(), P[sc["head"] + "/fc/biases"])
+    if model_type == "standard_word2vec":
+        z = z @ P[sc["glove"]].detach()
     ell = F.binary_cross_entropy_with_logits(z, tgt, reduction="none")
-    if model_type == "vlmap_answer":
+    if model_type in ("vlmap_answer", "standard_word2vec"):
         loss = (ell * _t(answer_masks["train"], dtype)).sum(-1).mean()
     else:
         loss = ell.sum(-1).mean()

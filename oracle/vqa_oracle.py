@@ -22,6 +22,9 @@ Reference lines restated (paths relative to /root/reference):
   * fusion MLP + head         vqa/model_vlmap_answer.py:163-187 (WordWeightAnswer
                               vlmap/modules.py:589-627); vqa/model_standard.py:251-275
   * loss + report             vqa/model_vlmap_answer.py:192-288; vqa/model_standard.py:281-374
+  * word2vec head variant     vqa/model_standard_word2vec.py:180-202 (classifier FC 2048 -> 300, logits =
+                              joint2 x a fixed [300, A] GloVe matrix of the answers; train loss masked by the
+                              train-answer mask like vlmap_answer)
   * optimiser                 vqa/trainer.py:87-114 (optimize_loss: global-norm
                               clip 20.0 then Adam)
 TF semantics followed: SURVEY.md section 5.2 items 1-9.
@@ -41,6 +44,13 @@ FC_LN_SCOPES_VLMAP = ["v_linear_v", "q_linear_v", "pooled_linear_l", "q_linear_l
 FROZEN_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer")
 TRANSFER_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc")
 
+OUTPUT_GLOVE = "reasoning/output_glove:const"
+
+
+def is_const(name):
+    return name.endswith(":const")
+
+
 REPORT_KEYS = [
     "answer_train_loss", "answer_report_loss", "answer_acc", "exist_acc", "test_acc",
     "normal_test_acc", "normal_test_object_acc", "normal_test_attribute_acc",
@@ -59,12 +69,15 @@ def scope_names(model_type: str) -> dict:
     if model_type == "vlmap_answer":
         pre = ""
         head = "WordWeightAnswer"
-    elif model_type == "standard":
+    elif model_type in ("standard", "standard_word2vec"):
         pre = "reasoning/"
         head = "reasoning/classifier"
     else:
         raise ValueError("unknown model_type %r" % (model_type,))
     return {
+        # standard_word2vec only: the constant [W, A] answer-GloVe matrix (a tf.constant, not a variable:
+        # vqa/model_standard_word2vec.py:185-188); kept beside the variables under a name no filter selects
+        "glove": OUTPUT_GLOVE,
         "embed": "LearnGloVe/embed_map",
         "v_linear_v": "v_linear_v",
         "gru_gates": "encode_L/rnn/gru_cell/gates",
@@ -80,16 +93,16 @@ def scope_names(model_type: str) -> dict:
 
 def train_var_names(params: dict, model_type: str) -> list:
     """filter_train_vars: vqa/model_vlmap_answer.py:81-89, vqa/model_standard.py:80-84."""
-    names = sorted(params.keys())
-    if model_type == "standard":
+    names = sorted(n for n in params.keys() if not is_const(n))
+    if model_type in ("standard", "standard_word2vec"):
         return names
     return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
 
 
 def transfer_var_names(params: dict, model_type: str) -> list:
     """filter_transfer_vars: vqa/model_vlmap_answer.py:91-100 (standard: :86-93)."""
-    names = sorted(params.keys())
-    if model_type == "standard":
+    names = sorted(n for n in params.keys() if not is_const(n))
+    if model_type in ("standard", "standard_word2vec"):
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
     return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
 
@@ -132,7 +145,10 @@ def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=
     fc(sc["pooled_linear_l"], D, H, True)
     fc(sc["q_linear_l"], H, H, True)
     fc(sc["joint_fc"], H, 2 * H, True)
-    if head == "untrained":
+    if model_type == "standard_word2vec":
+        fc(sc["head"], 2 * H, W, False)                     # 'classifier' FC to the 300-d word space
+        p[sc["glove"]] = (0.3 * rng.standard_normal((W, A))).astype(dtype)   # stands in for the answers' GloVe vectors
+    elif head == "untrained":
         p[sc["head"] + "/fc/weights"] = np.zeros((2 * H, A), dtype)
         p[sc["head"] + "/fc/biases"] = np.full(A, -100.0, dtype)
     else:
@@ -251,7 +267,7 @@ def loss_and_report(z, tgt, answer_masks, model_type):
     obj, attr, exist = answer_masks["obj"], answer_masks["attr"], answer_masks["exist"]
     ell = sigmoid_ce(z, tgt)
     report_loss = ell.sum(axis=1).mean()
-    if model_type == "vlmap_answer":
+    if model_type in ("vlmap_answer", "standard_word2vec"):     # model_standard_word2vec.py:199-201 masks too
         train_loss = (ell * train).sum(axis=1).mean()
     else:
         train_loss = report_loss
@@ -333,6 +349,10 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
     j0, t_j = fc_ln_relu_forward(jin, params, sc["joint_fc"])            # a9
     j = j0 * masks["joint"] * dt(1.0 / KEEP_JOINT)
     z = fc_forward(j, params[sc["head"] + "/fc/weights"], params[sc["head"] + "/fc/biases"])  # a10
+    j2 = None
+    if model_type == "standard_word2vec":                   # logit = joint2 x output_glove
+        j2 = z
+        z = j2 @ params[sc["glove"]]
     loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)  # a11
     out["att_score"] = att
     out["logit"] = z
@@ -341,7 +361,7 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
            "pred": out["pred"], "v_linear_v": v, "condition": h, "V_ft": V}
     tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att,
                 feat=feat, p=p, pl=pl, t_pl=t_pl, ll=ll, t_ll=t_ll, jin=jin, j0=j0, t_j=t_j,
-                j=j, z=z)
+                j=j, z=z, j2=j2)
     return loss, report, out, mid, tape
 
 
@@ -381,9 +401,11 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     B = z.shape[0]
     tgt = batch["answer_target"]
     dz = (sigmoid(z) - tgt) / dt(B)
-    if model_type == "vlmap_answer":
+    if model_type in ("vlmap_answer", "standard_word2vec"):
         dz = dz * answer_masks["train"]
     Wh = params[sc["head"] + "/fc/weights"]
+    if model_type == "standard_word2vec":
+        dz = dz @ params[sc["glove"]].T                     # gradient wrt joint2; the GloVe matrix is a constant
     g[sc["head"] + "/fc/weights"] = tape["j"].T @ dz
     g[sc["head"] + "/fc/biases"] = dz.sum(axis=0)
     dj = dz @ Wh.T

@@ -24,9 +24,11 @@ def make_case(seed, model_type, B, R, T, N, dims, dtype=np.float32, full_boxes=F
 
 def make_engine(model_type, p, table, nbox, am, B, R, T, dims, global_batch=None, **kw):
     from vqa_transfer_externaldata_amd import fusion as F
+    if model_type == "standard_word2vec":      # the constant answer-GloVe matrix travels beside the variables
+        kw.setdefault("answer_glove", p[O.OUTPUT_GLOVE].astype(np.float32))
     eng = F.FusionEngine(model_type=model_type, B=B, R=R, T=T, N_img=table.shape[0],
-                         params={k: v.astype(np.float32) for k, v in p.items()}, global_batch=global_batch, **dims,
-                         **kw)
+                         params={k: v.astype(np.float32) for k, v in p.items() if not O.is_const(k)},
+                         global_batch=global_batch, **dims, **kw)
     eng.bind_inputs(table=dev(table.astype(np.float32)), nbox_table=dev(nbox),
                     answer_masks={k: dev(v.astype(np.float32)) for k, v in am.items()})
     return eng

@@ -20,7 +20,7 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
     return p, table, nbox, batch, am, masks
 
 
-@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard"])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -31,8 +31,29 @@ def test_forward_and_grads_match_torch_autograd(model_type):
               "l_linear_l", "joint", "logit"):
         np.testing.assert_allclose(mid[k], tmid[k], rtol=1e-9, atol=1e-11, err_msg=k)
     for k in p:
+        if O.is_const(k):
+            assert k not in grads and k not in O.train_var_names(p, model_type)    # a tf.constant: no gradient
+            continue
         np.testing.assert_allclose(grads[k], tgrads[k], rtol=1e-7, atol=1e-11, err_msg=k)
     np.testing.assert_allclose(dx, tdx, rtol=1e-7, atol=1e-12)
+
+
+def test_word2vec_head_known_answers():
+    """vqa/model_standard_word2vec.py:180-202: classifier FC to 300-d, logits = joint2 x fixed answer-GloVe matrix,
+    train loss masked by the train-answer mask, report loss not."""
+    p, table, nbox, batch, am, masks = _case(15, "standard_word2vec")
+    sc = O.scope_names("standard_word2vec")
+    assert p[sc["head"] + "/fc/weights"].shape == (2 * DIMS["H"], DIMS["W"]) and p[sc["glove"]].shape == (DIMS["W"], DIMS["A"])
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, "standard_word2vec")
+    j2 = mid["joint"] @ p[sc["head"] + "/fc/weights"] + p[sc["head"] + "/fc/biases"]
+    np.testing.assert_allclose(mid["logit"], j2 @ p[sc["glove"]], rtol=1e-12)
+    ell = O.sigmoid_ce(mid["logit"], batch["answer_target"])
+    assert report["answer_train_loss"] == pytest.approx((ell * am["train"]).sum(1).mean(), rel=1e-12)
+    assert report["answer_report_loss"] == pytest.approx(ell.sum(1).mean(), rel=1e-12)
+    assert loss == report["answer_train_loss"] and report["answer_train_loss"] < report["answer_report_loss"]
+    # a zero GloVe column gives logit 0 for that answer whatever the input
+    p[sc["glove"]][:, 3] = 0
+    assert np.all(O.forward(p, batch, table, nbox, am, masks, "standard_word2vec")[3]["logit"][:, 3] == 0)
 
 
 def test_finite_differences_on_selected_params():

@@ -35,7 +35,7 @@ class Params(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("v_linear_v", Fc),
                 ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
                 ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
-                ("joint_fc", Fc), ("head", Fc)]
+                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p)]
 
 
 class Batch(C.Structure):

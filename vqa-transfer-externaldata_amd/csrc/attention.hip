@@ -105,72 +105,79 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_pool_fwd_kernel(
 // anything else -- they do not depend on the scores and land during the score phase, (b) a wave issues the loads of
 // all rows of a score batch (3 + 2 of its <= 5 rows) before the first use, so the batch costs one memory latency
 // instead of one per row, (c) the pooling loop keeps 7 rows per thread in flight.
+// (hipcc note: the loads are written on a native 4-float vector type and are UNCONDITIONAL -- row indices are clamped
+// and rows past R get weight zero.  With HIP's float4 struct a guarded `in ? load : zero` becomes four scalar loads
+// in four branches, each waited for before the next is issued.)
 constexpr int FAST_PF = 8, FAST_POOL_BATCH = 7;
-template <int H4L, int D4T>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// scores of CNT rows (row0, row0 + 8, ...) of one wave: every load of the batch is issued before the first use
+template <int H4L, int CNT, bool MASK>
+__device__ __forceinline__ void attn_score_rows(const f32x4v* __restrict__ vb4, const unsigned* __restrict__ mb4,
+                                                const f32x4v* qw4, float* s, int R, int row0, float inv_keep, float bias0,
+                                                int lane, bool sync_first) {
+    constexpr int H4 = H4L * 64;
+    f32x4v x[CNT][H4L];
+    unsigned m[CNT][H4L];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const int r = min(row0 + 8 * i, R - 1);
+#pragma unroll
+        for (int k = 0; k < H4L; ++k) {
+            x[i][k] = vb4[(int64_t)r * H4 + lane + 64 * k];
+            if (MASK) m[i][k] = mb4[(int64_t)r * H4 + lane + 64 * k];
+        }
+    }
+    if (sync_first) __syncthreads();                 // qw is complete
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < H4L; ++k) {
+            const f32x4v q = qw4[lane + 64 * k];
+            if (MASK) {
+                const unsigned mm = m[i][k];
+                acc += (x[i][k].x * q.x * (float)(mm & 0xFFu) + x[i][k].y * q.y * (float)((mm >> 8) & 0xFFu) +
+                        x[i][k].z * q.z * (float)((mm >> 16) & 0xFFu) + x[i][k].w * q.w * (float)(mm >> 24)) * inv_keep;
+            } else {
+                acc += x[i][k].x * q.x + x[i][k].y * q.y + x[i][k].z * q.z + x[i][k].w * q.w;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0 && row0 + 8 * i < R) s[row0 + 8 * i] = acc + bias0;
+    }
+}
+
+template <int H4L, int D4T, bool MASK>
 __global__ __launch_bounds__(FWD_THREADS, 4) void attn_pool_fwd_fast_kernel(
     const float* __restrict__ v, const float* __restrict__ qv, const float* __restrict__ V,
     const int32_t* __restrict__ nb, const float* __restrict__ w, const float* __restrict__ bias,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ att_out, float* __restrict__ pooled, int R,
     int rep) {
-    constexpr int H = H4L * 256, D = D4T * 2048;
+    constexpr int H = H4L * 256, D = D4T * 2048, D4 = D / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // qw[H] | s[R]
     float* qw = lds;
     float* s = lds + H;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // b = query index
     const int mem = b / rep;
-    const float* vb = v + (int64_t)mem * R * H;
-    const uint8_t* mb = keepmask ? keepmask + (int64_t)b * R * H : nullptr;
-    const float* Vb = V + (int64_t)mem * R * D;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4v* vb4 = reinterpret_cast<const f32x4v*>(v + (int64_t)mem * R * H);
+    const unsigned* mb4 = MASK ? reinterpret_cast<const unsigned*>(keepmask + (int64_t)b * R * H) : nullptr;
+    const f32x4v* Vb4 = reinterpret_cast<const f32x4v*>(V + (int64_t)mem * R * D);
 
     // (a) first rows of this thread's V columns
-    float4 xv[FAST_PF][D4T];
+    f32x4v xv[FAST_PF][D4T];
 #pragma unroll
     for (int j = 0; j < FAST_PF; ++j)
 #pragma unroll
-        for (int c = 0; c < D4T; ++c)
-            xv[j][c] = (j < R) ? reinterpret_cast<const float4*>(Vb + (int64_t)j * D)[threadIdx.x + c * FWD_THREADS] : zero4;
+        for (int c = 0; c < D4T; ++c) xv[j][c] = Vb4[(int64_t)min(j, R - 1) * D4 + threadIdx.x + c * FWD_THREADS];
 
     for (int h = threadIdx.x; h < H; h += FWD_THREADS) qw[h] = qv[(int64_t)b * H + h] * w[h];
     const float bias0 = bias[0];
 
-    // (b) scores: wave `wave` owns rows wave + 8 i
-    auto score_batch = [&](const int i0, const int cnt, const bool need_sync) {
-        float4 x[3][H4L];
-        uchar4 m[3][H4L];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = wave + 8 * (i0 + i);
-            if (i < cnt && r < R) {
-#pragma unroll
-                for (int k = 0; k < H4L; ++k) {
-                    x[i][k] = reinterpret_cast<const float4*>(vb + (int64_t)r * H)[lane + 64 * k];
-                    if (mb != nullptr) m[i][k] = reinterpret_cast<const uchar4*>(mb + (int64_t)r * H)[lane + 64 * k];
-                }
-            }
-        }
-        if (need_sync) __syncthreads();                 // qw is complete
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = wave + 8 * (i0 + i);
-            if (i < cnt && r < R) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < H4L; ++k) {
-                    const float4 q = reinterpret_cast<const float4*>(qw)[lane + 64 * k];
-                    if (mb != nullptr)
-                        acc += (x[i][k].x * q.x * m[i][k].x + x[i][k].y * q.y * m[i][k].y + x[i][k].z * q.z * m[i][k].z +
-                                x[i][k].w * q.w * m[i][k].w) * inv_keep;
-                    else
-                        acc += x[i][k].x * q.x + x[i][k].y * q.y + x[i][k].z * q.z + x[i][k].w * q.w;
-                }
-                acc = wave_sum(acc);
-                if (lane == 0) s[r] = acc + bias0;
-            }
-        }
-    };
-    score_batch(0, 3, true);
-    score_batch(3, 2, false);
+    // (b) scores: wave `wave` owns rows wave + 8 i, i < 5 (R <= 40)
+    const f32x4v* qw4 = reinterpret_cast<const f32x4v*>(qw);
+    attn_score_rows<H4L, 3, MASK>(vb4, mb4, qw4, s, R, wave, inv_keep, bias0, lane, true);
+    attn_score_rows<H4L, 2, MASK>(vb4, mb4, qw4, s, R, wave + 24, inv_keep, bias0, lane, false);
     __syncthreads();
 
     if (wave == 0) {
@@ -197,41 +204,32 @@ __global__ __launch_bounds__(FWD_THREADS, 4) void attn_pool_fwd_fast_kernel(
     }
     __syncthreads();
 
-    // (c) pooling: rows in order, so the sums match the generic kernel bit for bit
-    float4 acc[D4T];
+    // (c) pooling, rows in order
+    f32x4v acc[D4T];
 #pragma unroll
-    for (int c = 0; c < D4T; ++c) acc[c] = zero4;
+    for (int c = 0; c < D4T; ++c) acc[c] = (f32x4v)(0.f);
 #pragma unroll
     for (int j = 0; j < FAST_PF; ++j) {
-        if (j < R) {
-            const float a = s[j];
+        const float a = (j < R) ? s[min(j, R - 1)] : 0.f;
 #pragma unroll
-            for (int c = 0; c < D4T; ++c) {
-                acc[c].x += a * xv[j][c].x; acc[c].y += a * xv[j][c].y; acc[c].z += a * xv[j][c].z; acc[c].w += a * xv[j][c].w;
-            }
-        }
+        for (int c = 0; c < D4T; ++c) acc[c] += a * xv[j][c];
     }
     for (int r0 = FAST_PF; r0 < R; r0 += FAST_POOL_BATCH) {
-        float4 y[FAST_POOL_BATCH][D4T];
+        f32x4v y[FAST_POOL_BATCH][D4T];
 #pragma unroll
         for (int j = 0; j < FAST_POOL_BATCH; ++j)
 #pragma unroll
-            for (int c = 0; c < D4T; ++c)
-                y[j][c] = (r0 + j < R) ? reinterpret_cast<const float4*>(Vb + (int64_t)(r0 + j) * D)[threadIdx.x + c * FWD_THREADS]
-                                       : zero4;
+            for (int c = 0; c < D4T; ++c) y[j][c] = Vb4[(int64_t)min(r0 + j, R - 1) * D4 + threadIdx.x + c * FWD_THREADS];
 #pragma unroll
         for (int j = 0; j < FAST_POOL_BATCH; ++j) {
-            if (r0 + j < R) {
-                const float a = s[r0 + j];
+            const float a = (r0 + j < R) ? s[min(r0 + j, R - 1)] : 0.f;
 #pragma unroll
-                for (int c = 0; c < D4T; ++c) {
-                    acc[c].x += a * y[j][c].x; acc[c].y += a * y[j][c].y; acc[c].z += a * y[j][c].z; acc[c].w += a * y[j][c].w;
-                }
-            }
+            for (int c = 0; c < D4T; ++c) acc[c] += a * y[j][c];
         }
     }
 #pragma unroll
-    for (int c = 0; c < D4T; ++c) reinterpret_cast<float4*>(pooled + (int64_t)b * D)[threadIdx.x + c * FWD_THREADS] = acc[c];
+    for (int c = 0; c < D4T; ++c)
+        reinterpret_cast<f32x4v*>(pooled + (int64_t)b * D)[threadIdx.x + c * FWD_THREADS] = acc[c];
 }
 
 // Backward.  One workgroup per MEMORY walks its `rep` queries, so dv (the gradient of the shared
@@ -357,7 +355,7 @@ int g_attn_fast = 1;   // tuning / A-B switch (vqa_attn_set_fast)
 }  // namespace
 
 extern "C" int vqa_attn_set_fast(int on) {
-    g_attn_fast = on ? 1 : 0;
+    g_attn_fast = on;      // 0 generic, 1 fast kernel for one query per memory, 2 fast kernel for every rep
     return VQA_OK;
 }
 
@@ -381,12 +379,18 @@ extern "C" int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const floa
     const size_t lds = (size_t)(H + R) * sizeof(float);
     const float ik = keepmask ? 1.f / keep_prob : 1.f;
     hipStream_t st = (hipStream_t)stream;
-    const bool fast = g_attn_fast && R <= 40 && H % 256 == 0 && H <= 1024 && D % 2048 == 0 && D <= 4096 &&
+    const bool fast = g_attn_fast && (rep == 1 || g_attn_fast > 1) && R <= 40 && H % 256 == 0 && H <= 1024 && D % 2048 == 0 && D <= 4096 &&
                       vqa_aligned16(qv) && vqa_aligned16(w);
     if (fast) {
-#define VQA_ATTN_FAST(h4l, d4t)                                                                                        \
-    hipLaunchKernelGGL((attn_pool_fwd_fast_kernel<h4l, d4t>), dim3(B * rep), dim3(FWD_THREADS), lds, st, v, qv, V, nb, w, \
-                       bias, keepmask, ik, att, pooled, R, rep)
+#define VQA_ATTN_FAST(h4l, d4t)                                                                                         \
+    do {                                                                                                                \
+        if (keepmask != nullptr)                                                                                        \
+            hipLaunchKernelGGL((attn_pool_fwd_fast_kernel<h4l, d4t, true>), dim3(B * rep), dim3(FWD_THREADS), lds, st, v, \
+                               qv, V, nb, w, bias, keepmask, ik, att, pooled, R, rep);                                  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((attn_pool_fwd_fast_kernel<h4l, d4t, false>), dim3(B * rep), dim3(FWD_THREADS), lds, st, v, \
+                               qv, V, nb, w, bias, keepmask, ik, att, pooled, R, rep);                                  \
+    } while (0)
         const int h4l = H / 256, d4t = D / 2048;
         if (d4t == 1) {
             if (h4l == 1) VQA_ATTN_FAST(1, 1); else if (h4l == 2) VQA_ATTN_FAST(2, 1);

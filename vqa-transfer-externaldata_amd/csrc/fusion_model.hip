@@ -60,12 +60,14 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("pre_ll", B * H); L.add("l_linear_l", B * H); L.add("mean_ll", B); L.add("rstd_ll", B);
     L.add("joint_in", B * H);
     L.add("pre_j", B * 2 * H); L.add("joint", B * 2 * H); L.add("mean_j", B); L.add("rstd_j", B);
+    L.add("joint2", B * W);      // standard_word2vec: classifier output in the 300-d word space
     L.add("logit", B * A);
     L.add("stats", B * VQA_STAT_COUNT);
     L.add("pred", B);
     L.add("report", 16);
     L.add("dlogit", B * A);
     // backward scratch
+    L.add("d_joint2", B * W);
     L.add("d_joint", B * 2 * H); L.add("d_pre_j", B * 2 * H);
     L.add("d_joint_in", B * H);
     L.add("d_pl", B * H); L.add("d_ll", B * H); L.add("d_pre_pl", B * H); L.add("d_pre_ll", B * H);
@@ -89,12 +91,14 @@ Layout make_layout(const vqa_dims_t& d) {
     g(1, 0, D, H, B); g(1, 0, H, H, B); g(0, 1, B, H, H); g(1, 0, D, H, B * R); g(1, 0, W, 2 * H, T * B);
     g(1, 0, H, 2 * H, T * B); g(1, 0, W, H, T * B); g(1, 0, H, H, T * B); g(0, 1, T * B, W, 2 * H);
     g(0, 1, T * B, W, H);                                                         // backward
+    g(0, 0, B, W, 2 * H); g(0, 0, B, A, W); g(0, 1, B, W, A); g(1, 0, 2 * H, W, B); g(0, 1, B, 2 * H, W);  // word2vec head
     L.add("gemm_ws", max64(gw, 4));
     L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
     int64_t cw = 0;
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * B), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)W));
     L.add("colsum_ws", max64(3 * cw, 4));    // x3: vqa_colsum3 reduces three partial matrices per launch
     L.add("colsum_ws1", max64(3 * cw, 4));
     L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
@@ -174,6 +178,32 @@ Side& gru_stream() {
     }
     return x;
 }
+// Helper stream for the feature gather: a pure HBM stream (302 MB) that runs beside the MFMA-bound x-projection
+// GEMMs of the question branch.  Always available (no environment switch); falls back to the caller's stream.
+Side& gather_stream() {
+    static Side sd[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Side& x = sd[dev & 63];
+    if (!x.tried) {
+        x.tried = true;
+        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return x;
+}
+// how V_ft = features[image_idx] is produced: 0 = on the helper stream beside the question branch (default),
+// 1 = fused into v_linear_v's GEMM operand load, 2 = inline on the caller's stream
+int gather_mode(const vqa_dims_t* dims) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("VQA_HOT_GATHER");
+        env = e == nullptr ? -1 : (strcmp(e, "fused") == 0 ? 1 : strcmp(e, "inline") == 0 ? 2 : 0);
+    }
+    if (env >= 0) return env;
+    return (dims->flags & VQA_FLAG_FUSED_GATHER) ? 1 : 0;
+}
 bool fork_side(const Ctx& c, Side& sd) {
     if (!sd.ok) return false;
     return hipEventRecord(sd.fork, c.st) == hipSuccess && hipStreamWaitEvent(sd.s, sd.fork, 0) == hipSuccess;
@@ -227,7 +257,7 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && (d->model_type == 0 || d->model_type == 1);
+           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 2;
 }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
@@ -298,31 +328,40 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     ProbeScope ps_all("forward", c.st);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
 
-    // visual branch (a1 + a2) on the side stream, question branch (a3-a5) on the caller's
+    // visual branch (a1 + a2) and the input projections of the question branch (a3, first half of a4).
+    //  * default: the feature gather V_ft = features[image_idx] (a pure HBM stream, 302 MB) runs on a helper stream
+    //    beside the MFMA-bound x-projection GEMMs; v_linear_v's GEMM then reads V_ft out of the Infinity Cache;
+    //  * VQA_FLAG_FUSED_GATHER: no gather pass -- v_linear_v's GEMM reads the table rows through image_idx in its
+    //    operand loader and leaves the gathered block behind as a by-product (151 MB less HBM traffic, but the GEMM
+    //    then streams its left operand from HBM: +37 us, tools/gather_gemm_bench.py);
+    //  * VQA_HOT_OVERLAP=1: the whole visual branch on the side stream (round-1 experiment).
     Side& sd = side_stream();
     const bool forked = fork_side(c, sd);
     Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
-    // a1 + a2: V_ft = features[image_idx] is not a pass of its own -- v_linear_v's GEMM reads the table rows through
-    // image_idx in its operand loader and leaves the gathered [B*R, D] block in the workspace as a by-product (attention
-    // pooling, its backward and dW of v_linear_v re-read it).  LN statistics over the whole [R,H] block of a sample.
-    const bool fuse_gather = (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table) && !(dims->flags & VQA_FLAG_SEPARATE_GATHER);
-    if (fuse_gather) {
-        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, nullptr, cv.i32("num_V_ft"), (int)B, (int)R,
-                                (int)D, dims->N_img, cv.st));
-        {
-            ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
-            TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
-                                    P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
-                                    cv.st));
+    const int gmode = gather_mode(dims);
+    const bool fuse_gather = gmode == 1 && (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table);
+    Side& gs = gather_stream();
+    const bool gather_aside = !fuse_gather && gmode == 0 && !forked && gs.ok && fork_side(c, gs);
+    auto visual_gemm = [&]() -> int {
+        if (fuse_gather) {
+            {
+                ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
+                TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
+                                        P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"),
+                                        (int)D, cv.st));
+            }
+            return vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
+                                   cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st);
         }
-        TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
-                            cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
-    } else {
-        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, cv.f("V_ft"), cv.i32("num_V_ft"), (int)B,
-                                (int)R, (int)D, dims->N_img, cv.st));
-        TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v",
-                           "rstd_v", nullptr, 1.f));
-    }
+        return fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
+                              nullptr, 1.f);
+    };
+    // a1: V_ft = features[image_idx], num_V_ft = num_boxes[image_idx]
+    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
+                            cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, gather_aside ? gs.s : cv.st));
+    if (gather_aside && !join_side_record(gs)) return VQA_ERR_LAUNCH;
+    // a2 (when nothing runs beside it): v_linear_v, LN statistics over the whole [R,H] block of a sample
+    if (!gather_aside) TRY(visual_gemm());
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
@@ -330,6 +369,10 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     float* xp = c.f("xp");
     TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
     TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+    if (gather_aside) {       // the gather has been running beside the projections; now a2
+        if (hipStreamWaitEvent(c.st, gs.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
+        TRY(visual_gemm());
+    }
     float* hs = c.f("hs");
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
     const float* Wg_h = P->gru_wg + W * 2 * H;
@@ -372,13 +415,20 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     TRY(fc_ln_relu_fwd(c, c.f("joint_in"), B, H, 2 * H, P->joint_fc, 1, "pre_j", "joint", "mean_j", "rstd_j",
                        bt->keep_joint, dims->keep_joint));
     // a10
-    {
+    if (dims->model_type == 2) {
+        // standard_word2vec (vqa/model_standard_word2vec.py:180-188): classifier FC into the 300-d word space, then
+        // logits = joint2 x the constant [W, A] GloVe matrix of the answers
+        VQA_REQUIRE(P->answer_glove != nullptr, VQA_ERR_ARG);
+        ProbeScope ps("head.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, W, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)W, c.f("joint2"), (int)W, P->head.b));
+        TRY(gemm(c, 0, 0, B, A, W, c.f("joint2"), (int)W, P->answer_glove, (int)A, c.f("logit"), (int)A));
+    } else {
         ProbeScope ps("head.fwd_gemm", c.st);
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
     }
-    // a11
+    // a11 (the train loss is masked by the train-answer mask in vlmap_answer and standard_word2vec, not in standard)
     TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
-                     dims->model_type == 0 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
+                     dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
                      want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
     TRY(vqa_report_reduce(c.f("stats"), (int)B, c.f("report"), c.st));
     return VQA_OK;
@@ -411,12 +461,23 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     float* dxp = c.f("dxp");
 
     if (phases & 1) {
+    if (dims->model_type == 2) {
+        // word2vec head: d_joint2 = dlogit * G^T (the GloVe matrix is a constant), then the classifier FC
+        VQA_REQUIRE(P->answer_glove != nullptr, VQA_ERR_ARG);
+        TRY(gemm(c, 0, 1, B, W, A, c.f("dlogit"), (int)A, P->answer_glove, (int)A, c.f("d_joint2"), (int)W));
+        if (G->head.w != nullptr) {
+            TRY(gemm(c, 1, 0, 2 * H, W, B, c.f("joint"), (int)(2 * H), c.f("d_joint2"), (int)W, G->head.w, (int)W));
+            TRY(colsum(c, c.f("d_joint2"), B, W, (int)W, G->head.b));
+        }
+        TRY(gemm(c, 0, 1, B, 2 * H, W, c.f("d_joint2"), (int)W, P->head.w, (int)W, c.f("d_joint"), (int)(2 * H)));
+    } else {
     // head: logit = joint*W + b
     if (G->head.w != nullptr) {
         TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit"), (int)A, G->head.w, (int)A));
         TRY(colsum(c, c.f("dlogit"), B, A, (int)A, G->head.b));
     }
     TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head.w, (int)A, c.f("d_joint"), (int)(2 * H)));
+    }
     // joint_fc (dropout mask folded into the LN/ReLU backward)
     TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("joint_in"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j", "mean_j",
                        "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_joint_in"), false));

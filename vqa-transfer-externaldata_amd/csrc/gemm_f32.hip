@@ -567,6 +567,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
         // the global-load latency, so the loads need two phases of cover.
         Stager<BM, BK, A_KC, NT> sa0, sa1;
         Stager<BN, BK, B_KC, NT> sb0, sb1;
+        // (Measured and rejected: rotating each workgroup's k-tile order so that co-running workgroups stream
+        // different k slices -- the recurrence got 4 % / 7 % SLOWER; workgroups that walk k in lockstep share the
+        // weight slices of their column panel in L2.  profiles/r2_gru_krot*.txt)
         auto ld0 = [&](int tile) {
             sa0.load_fast(rsA, p.lda, m0, kbeg + tile * BK, p.M, kend);
             sb0.load_fast(rsB, p.ldb, n0, kbeg + tile * BK, p.N, kend);

@@ -40,7 +40,7 @@ def scope_names(model_type):
     vqa/model_standard.py:223-275)."""
     if model_type == "vlmap_answer":
         pre, head = "", "WordWeightAnswer"
-    elif model_type == "standard":
+    elif model_type in ("standard", "standard_word2vec"):
         pre, head = "reasoning/", "reasoning/classifier"
     else:
         raise ValueError("unknown model_type %r" % (model_type,))
@@ -73,20 +73,21 @@ def variable_shapes(model_type, Vq, W, D, H, A):
     fc(sc["pooled_linear_l"], D, H, True)
     fc(sc["q_linear_l"], H, H, True)
     fc(sc["joint_fc"], H, 2 * H, True)
-    fc(sc["head"], 2 * H, A, False)
+    # standard_word2vec: the classifier maps into the 300-d word space (vqa/model_standard_word2vec.py:180-183)
+    fc(sc["head"], 2 * H, W if model_type == "standard_word2vec" else A, False)
     return s
 
 
 def filter_train_vars(names, model_type):
     """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
-    if model_type == "standard":
+    if model_type in ("standard", "standard_word2vec"):
         return list(names)
     return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
 
 
 def filter_transfer_vars(names, model_type):
     """vqa/model_vlmap_answer.py:91-100 / vqa/model_standard.py:86-93."""
-    if model_type == "standard":
+    if model_type in ("standard", "standard_word2vec"):
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
     return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
 
@@ -96,8 +97,10 @@ def _pad4(n):
 
 
 class FusionEngine:
+    MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2}
+
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
-                 keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None):
+                 keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None):
         """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
         from float atomics to an atomic-free kernel, ~30 us slower at bs 512).  Per engine: the choice travels in
         vqa_dims_t.flags with every call, no process-wide library state is touched."""
@@ -108,7 +111,7 @@ class FusionEngine:
         self.model_type = model_type
         self.sc = scope_names(model_type)
         self.dims = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N_img,
-                              model_type=0 if model_type == "vlmap_answer" else 1,
+                              model_type=self.MODEL_TYPE_ID[model_type],
                               keep_att=keep_att, keep_joint=keep_joint,
                               inv_global_batch=1.0 / float(global_batch or B),
                               flags=_lib.FLAG_DETERMINISTIC if deterministic else 0)
@@ -155,6 +158,16 @@ class FusionEngine:
             self.grads[n] = self.grad_flat[off:off + cnt].view(self.shapes[n])
         for n, (off, cnt) in self._frozen_tab.items():
             self.params[n] = self.frozen_flat[off:off + cnt].view(self.shapes[n])
+        # standard_word2vec: the constant [W, A] GloVe matrix of the answers -- a tf.constant in the reference, so it
+        # is neither a variable, nor trained, nor in checkpoints
+        self.answer_glove = None
+        if model_type == "standard_word2vec":
+            if answer_glove is None:
+                raise ValueError("standard_word2vec needs answer_glove [W, A]")
+            g = torch.as_tensor(np.asarray(answer_glove) if not torch.is_tensor(answer_glove) else answer_glove)
+            if tuple(g.shape) != (W, A):
+                raise ValueError("answer_glove has shape %s, expected %s" % (tuple(g.shape), (W, A)))
+            self.answer_glove = g.to(device=self.device, dtype=torch.float32).contiguous()
         self.load_params(params)
 
         ws_bytes = int(self.lib.vqa_fusion_workspace_bytes(C.byref(self.dims)))
@@ -222,7 +235,8 @@ class FusionEngine:
             gru_wc=ptr(sc["gru_cand"] + "/kernel"), gru_bc=ptr(sc["gru_cand"] + "/bias"),
             q_linear_v=fc(sc["q_linear_v"], True), score=fc(sc["score"], False),
             pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
-            joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False))
+            joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False),
+            answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None)
 
     def resize(self, B, T, global_batch=None):
         """Re-target the engine to another batch size / padded question length (the reference pads

@@ -44,11 +44,13 @@ def _load_pickle(path):
             return pickle.load(f, encoding="latin1")
 
 
-def learn_glove_init(vocab, glove=None, rng=None):
+def learn_glove_init(vocab, glove=None, rng=None, oov_mean_initialize=False):
     """modules.LearnGloVe (vlmap/modules.py:415-448): rows of words found in GloVe get
     their vector, others zeros.  `glove` = {'dict': word->row, 'param': [n,300]} or None
     (GloVe files are download-only; then every row starts at zero like an OOV word, or
-    small uniform noise when an rng is given for synthetic runs)."""
+    small uniform noise when an rng is given for synthetic runs).
+    oov_mean_initialize (the answer matrix of model_standard_word2vec): an entry that is not a GloVe word but a
+    phrase of GloVe words gets the mean of their vectors; any other non-empty entry raises, as the reference does."""
     n = len(vocab["vocab"])
     w = np.zeros([n, W_DIM], np.float32)
     if glove is not None:
@@ -56,6 +58,11 @@ def learn_glove_init(vocab, glove=None, rng=None):
             j = glove["dict"].get(word)
             if j is not None and j < glove["param"].shape[0]:
                 w[i] = glove["param"][j]
+            elif oov_mean_initialize and word != "":
+                words = word.split()
+                if not all(x in glove["dict"] for x in words):
+                    raise Exception("Unkown words {}".format(words))          # (sic) vlmap/modules.py:438
+                w[i] = np.mean([glove["param"][glove["dict"][x]] for x in words], 0)
     elif rng is not None:
         w = rng.uniform(-0.01, 0.01, size=w.shape).astype(np.float32)
     return w
@@ -201,10 +208,14 @@ class Model(object):
                 p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
             else:
                 p[n] = np.zeros(s, np.float32)
-        if self.MODEL_TYPE == "vlmap_answer":
+        if self.MODEL_TYPE == "vlmap_answer":      # the other heads keep their Xavier / zero initialisation
             w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
             p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
         return p
+
+    def _engine_kwargs(self):
+        """extra FusionEngine arguments of a model variant (none for the two base models)"""
+        return {}
 
     def _to_dev(self, a, dtype):
         t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
@@ -216,7 +227,7 @@ class Model(object):
         eng = F.FusionEngine(model_type=self.MODEL_TYPE, B=B, R=self.max_box_num, D=self.vfeat_dim, H=V_DIM, T=T,
                              W=W_DIM, A=self.num_answer, Vq=Vq, N_img=len(self.features),
                              params=self._initial_params(shapes), device=self.device,
-                             global_batch=getattr(self.config, "global_batch", None))
+                             global_batch=getattr(self.config, "global_batch", None), **self._engine_kwargs())
         eng.bind_inputs(
             table=self._to_dev(self.features, torch.float32),        # the whole table lives in HBM (a1)
             nbox_table=self._to_dev(self.num_boxes, torch.int32),
