@@ -126,3 +126,48 @@ def test_extractor_layout():
     assert np.all(out["num_boxes"] == 4) and int(out["vfeat_dim"]) == blocks[-1][1] * 4
     nb = batches[0]["normal_box"].cpu().numpy()[1]
     np.testing.assert_allclose(out["spatial_features"][1, :, 4], nb[:, 2] - nb[:, 0], rtol=1e-6)
+
+
+def test_extractor_cli_from_images_on_disk_to_reference_hdf5(tmp_path):
+    """vqa/vfeat_extractor_tf_record_memft.py end to end: JPEG files + DenseCap boxes (HDF5) + image_info.json ->
+    input pipeline -> HIP conv stack + ROI crop -> the reference's feature HDF5, readable by load_image_features."""
+    import json
+    import os
+    from PIL import Image
+    from vqa_transfer_externaldata_amd import dataset_vfeat as DV, hdf5_io, model_vlmap_answer as MV, vfeat as VF
+    from vqa_transfer_externaldata_amd import vfeat_extractor as VX
+    rng = np.random.default_rng(3)
+    img_dir, dc_dir, rec_dir = tmp_path / "images", tmp_path / "densecap", tmp_path / "tf_record_memft"
+    os.makedirs(img_dir / "val2014"); os.makedirs(dc_dir / "val2014"); os.makedirs(rec_dir)
+    paths, tree = [], {}
+    for i in range(5):
+        w, h = int(rng.integers(80, 160)), int(rng.integers(80, 160))
+        p = "val2014/COCO_val2014_%012d.jpg" % i
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(str(img_dir / p), quality=95)
+        n = int(rng.integers(2, 9))
+        tree[p.replace("/", "-")] = {"boxes": np.concatenate([rng.random((n, 2)) * [w / 2, h / 2],
+                                                              rng.random((n, 2)) * [w / 2, h / 2] + 4], 1).astype(np.float32)}
+        paths.append(p)
+    hdf5_io.write(str(dc_dir / "val2014" / DV.DENSECAP_FILENAME), tree)
+    ids = [p.replace("/", "-") for p in paths]
+    json.dump({"image_id2idx": {k: i for i, k in enumerate(ids)}, "image_path2idx": {p: i for i, p in enumerate(paths)},
+               "image_num2path": {str(i): p for i, p in enumerate(paths)}}, open(rec_dir / "image_info.json", "w"))
+    blocks = [(n, b // 4, 1, s) for (n, b, u, s) in VF.BLOCKS_R50_B3]            # narrow stack: the plumbing is under test
+    cfg = VX.build_parser().parse_args(["--tf_record_memft_dir", str(rec_dir), "--image_dir", str(img_dir),
+                                        "--densecap_dir", str(dc_dir), "--pretrained_param_path", "random:7",
+                                        "--batch_size", "2", "--model_type", "resnet"])
+    out = VX.run(cfg, blocks=blocks)
+    feats, spat, boxes, nb, max_box, dim = MV.load_image_features(cfg.save_path)
+    assert (max_box, dim) == (50, blocks[-1][1] * 4) and feats.shape == (5, 50, dim)
+    np.testing.assert_array_equal(np.asarray(feats), out["image_features"])
+    # one image recomputed directly: same pixels, same boxes, same network
+    ds = DV.create_dataset(paths, str(img_dir), str(dc_dir))
+    d = ds.get_data(3)
+    model = VF.VfeatResnetModel(VX.load_params("random:7", "resnet", blocks), blocks)
+    v = model.build({"image": dev(d["image"][None]), "normal_box": dev(d["normal_box"][None])}).cpu().numpy()[0]
+    n = int(d["num_box"])
+    np.testing.assert_allclose(np.asarray(feats)[3, :n], v[:n], rtol=1e-5, atol=1e-5)
+    assert np.all(np.asarray(feats)[3, n:] == 0)
+    np.testing.assert_allclose(np.asarray(spat)[3, :n, 4], d["normal_box"][:, 2] - d["normal_box"][:, 0], rtol=1e-6)
+    with pytest.raises(ValueError, match="do not overwrite"):
+        VX.run(cfg, blocks=blocks)

@@ -1,0 +1,54 @@
+"""Batch provider of the region-feature extractor with the contract of vqa/datasets/input_ops_vfeat.py:15-81:
+ids (optionally shuffled) -> dataset.get_data on 8 parallel workers -> padded batches -> a prefetch queue.
+
+A batch is a dict of NumPy arrays: id i32[B], image f32[B,540,540,3], box / normal_box f32[B,maxn,4] zero padded to
+the batch's longest box list (tf.data padded_batch), num_box i32[B], image_id list[str], image_id_len i32[B].
+Decoding + resizing runs in a thread pool (PIL releases the GIL inside its C loops) `prefetch` batches ahead of the
+consumer, so the GPU's conv stack does not wait for JPEG decoding; the last batch may be short."""
+from __future__ import annotations
+
+import collections
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def _collate(ids, items):
+    B = len(items)
+    maxn = max([int(x["num_box"]) for x in items] + [1])
+    box = np.zeros((B, maxn, 4), np.float32)
+    nbox = np.zeros((B, maxn, 4), np.float32)
+    for i, x in enumerate(items):
+        n = int(x["num_box"])
+        box[i, :n], nbox[i, :n] = x["box"], x["normal_box"]
+    return {"id": np.asarray(ids, np.int32), "image": np.stack([x["image"] for x in items], 0), "box": box,
+            "normal_box": nbox, "num_box": np.array([int(x["num_box"]) for x in items], np.int32),
+            "image_id": [x["image_id"] for x in items],
+            "image_id_len": np.array([int(x["image_id_len"]) for x in items], np.int32)}
+
+
+def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=True, seed=123, num_parallel_calls=8,
+           prefetch=10, repeat=1000):
+    ids = list(dataset.ids)
+    if is_train and shuffle:
+        np.random.RandomState(seed).shuffle(ids)
+    chunks = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
+
+    def gen():
+        with ThreadPoolExecutor(max_workers=max(1, num_parallel_calls)) as pool:
+            for _ in range(repeat if is_train else 1):
+                pending = collections.deque()
+                it = iter(chunks)
+
+                def submit():
+                    c = next(it, None)
+                    if c is not None:
+                        pending.append((c, [pool.submit(dataset.get_data, i) for i in c]))
+                for _ in range(max(1, prefetch)):
+                    submit()
+                while pending:
+                    c, futs = pending.popleft()
+                    items = [f.result() for f in futs]
+                    submit()
+                    yield _collate(c, items)
+    return gen()

@@ -58,6 +58,17 @@ def init_random_params(rng, blocks, scope="resnet_v1_50", dtype=np.float32):
     return p
 
 
+def init_random_head_params(rng, p, enc_dim, v_dim, dtype=np.float32):
+    """random-init I_reduce_dim / I2V variables of model_vfeat (vlmap/modules.py:219-239; layers.conv2d + batch_norm)"""
+    for scope, k, ci in (("I_reduce_dim/conv2d", 1, enc_dim), ("I2V/conv2d_1", 3, v_dim)):
+        p[scope + "/conv2d/weights"] = (rng.standard_normal((k, k, ci, v_dim)) * np.sqrt(2.0 / (k * k * ci))).astype(dtype)
+        p[scope + "/BatchNorm/gamma"] = (1 + 0.1 * rng.standard_normal(v_dim)).astype(dtype)
+        p[scope + "/BatchNorm/beta"] = (0.1 * rng.standard_normal(v_dim)).astype(dtype)
+        p[scope + "/BatchNorm/moving_mean"] = (0.1 * rng.standard_normal(v_dim)).astype(dtype)
+        p[scope + "/BatchNorm/moving_variance"] = (1 + 0.2 * rng.random(v_dim)).astype(dtype)
+    return p
+
+
 def conv_flops_per_image(blocks, H, W, c0=64):
     """Algorithmic 2*MAC of conv1 + the bottleneck blocks for one HxW image."""
     fl = 0

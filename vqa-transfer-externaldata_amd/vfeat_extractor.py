@@ -1,0 +1,95 @@
+"""Command-line region-feature extraction: the counterpart of vqa/vfeat_extractor_tf_record_memft.py:13-215.
+
+    python -m vqa_transfer_externaldata_amd.vfeat_extractor --pretrained_param_path <weights.npz | random:SEED> \
+        [--tf_record_memft_dir DIR --save_name vfeat_extracted.hdf5 --image_dir ... --densecap_dir ... \
+         --batch_size 96 --model_type vfeat|resnet]
+
+reads `<tf_record_memft_dir>/image_info.json` (image_id2idx / image_path2idx / image_num2path), runs every image
+through the HIP conv stack + ROI crop (vfeat.VfeatModel / VfeatResnetModel) and writes the dense
+[N, max_roi, D] tables to `<tf_record_memft_dir>/<save_name>` in the reference's HDF5 layout (hdf5_io).
+The slim ResNet checkpoint of the reference (data/nets/resnet_v1_50.ckpt) is a download-only TensorFlow file;
+weights are taken from an .npz with slim's variable names, or `random:SEED` for synthetic runs."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import dataset_vfeat, input_ops_vfeat, vfeat
+from .log import log
+
+
+def get_model_class(model_type="vfeat"):
+    if model_type == "vfeat":
+        return vfeat.VfeatModel
+    if model_type == "resnet":
+        return vfeat.VfeatResnetModel
+    raise ValueError("Unknown model_type")
+
+
+def load_params(spec, model_type, blocks):
+    if spec.startswith("random:"):
+        rng = np.random.default_rng(int(spec.split(":", 1)[1]))
+        p = vfeat.init_random_params(rng, blocks)
+        if model_type == "vfeat":
+            p = vfeat.init_random_head_params(rng, p, blocks[-1][1] * 4, 512)
+        return p
+    z = np.load(spec)
+    return {k: z[k] for k in z.files}
+
+
+def device_batches(batches, device):
+    for b in batches:
+        out = dict(b)
+        out["image"] = torch.from_numpy(b["image"]).to(device, non_blocking=True)
+        out["normal_box"] = torch.from_numpy(b["normal_box"]).to(device, non_blocking=True)
+        yield out
+
+
+def check_config(config):
+    if os.path.exists(config.save_path):
+        raise ValueError("specified save_path exists already. do not overwrite: {}".format(config.save_path))
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--tf_record_memft_dir", type=str,
+                        default="data/preprocessed/vqa_v2/new_qa_split_thres1_500_thres2_50/tf_record_memft", help=" ")
+    parser.add_argument("--save_name", type=str, default="vfeat_extracted.hdf5", help=" ")
+    parser.add_argument("--image_dir", type=str, default="data/VQA_v2/images", help=" ")
+    parser.add_argument("--densecap_dir", type=str, default="data/VQA_v2/densecap", help=" ")
+    parser.add_argument("--pretrained_param_path", type=str, default=None, required=True)
+    parser.add_argument("--batch_size", type=int, default=96, help=" ")
+    parser.add_argument("--model_type", type=str, default="vfeat", help=" ", choices=["vfeat", "resnet"])
+    return parser
+
+
+def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device="cuda:0"):
+    config.image_info_path = os.path.join(config.tf_record_memft_dir, "image_info.json")
+    config.save_path = os.path.join(config.tf_record_memft_dir, config.save_name)
+    check_config(config)
+    log.infov("loading image_info: {}".format(config.image_info_path))
+    with open(config.image_info_path) as f:
+        image_info = json.load(f)
+    if dataset is None:
+        dataset = dataset_vfeat.create_dataset(list(image_info["image_path2idx"].keys()), config.image_dir,
+                                               config.densecap_dir, is_train=False)
+    params = load_params(config.pretrained_param_path, config.model_type, blocks)
+    model = get_model_class(config.model_type)(params, blocks, device=device)
+    batches = input_ops_vfeat.create(dataset, config.batch_size, is_train=False, scope="batch_ops", shuffle=False)
+    ex = vfeat.Extractor(model, image_info["image_id2idx"], dataset.get_config().max_roi_num,
+                         config.pretrained_param_path)
+    out = ex.extract(device_batches(batches, device), config.save_path)
+    log.warning("vfeat extraction is done: {}".format(config.save_path))
+    return out
+
+
+def main(argv=None):
+    return run(build_parser().parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()
