@@ -280,8 +280,8 @@ typedef struct {
 } vqa_dims_t;
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
 #define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
-                                     * (vqa_gemm_f32_gather); default: gather on a helper stream beside the question
-                                     * branch's projection GEMMs */
+                                     * (vqa_gemm_f32_gather) and leaves V_ft behind as a by-product; default: a gather
+                                     * pass in front of the GEMM (same step time, see csrc/fusion_model.hip) */
 
 /* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
 typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;

@@ -360,3 +360,24 @@ def test_standard_word2vec_train_steps_and_model_class(tmp_path):
     c.answer_dict["vocab"][1] = "fire hydrant"
     with pytest.raises(Exception, match="Unkown words"):
         importer.get_model_class("standard_word2vec")(b, c, is_train=True, image_features=feats)
+
+
+@pytest.mark.parametrize("cfg", [("med", MED, 32, 36, 14, 64), ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
+def test_fused_feature_gather_equals_gather_pass(cfg):
+    """VQA_FLAG_FUSED_GATHER: V_ft = features[image_idx] read inside v_linear_v's GEMM instead of a pass of its own --
+    the gathered block left in the workspace is bit-identical, everything downstream agrees to rounding."""
+    name, dims, B, R, T, N = cfg
+    p, table, nbox, batch, am, masks = make_case(61, "vlmap_answer", B, R, T, N, dims)
+    a = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
+    b = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims, fused_gather=True)
+    run_engine(a, batch, masks)
+    run_engine(b, batch, masks)
+    assert torch.equal(a.tensor("V_ft"), b.tensor("V_ft")) and torch.equal(a.tensor("num_V_ft"), b.tensor("num_V_ft"))
+    want = table[batch["image_idx"]].astype(np.float32).reshape(-1)
+    np.testing.assert_array_equal(b.tensor("V_ft").cpu().numpy(), want)
+    for k in MID_KEYS:
+        x, y = a.tensor(k).cpu().numpy(), b.tensor(k).cpu().numpy()
+        assert np.abs(x - y).max() <= 1e-5 * max(1.0, np.abs(x).max()), k
+    assert torch.equal(a.tensor("pred"), b.tensor("pred"))
+    ga, gb = a.grad_flat.cpu().numpy(), b.grad_flat.cpu().numpy()
+    assert np.abs(ga - gb).max() <= 1e-5 * np.abs(ga).max()

@@ -25,6 +25,7 @@ class Dims(C.Structure):
 
 
 FLAG_DETERMINISTIC = 1
+FLAG_FUSED_GATHER = 2
 
 
 class Fc(C.Structure):

@@ -178,28 +178,17 @@ Side& gru_stream() {
     }
     return x;
 }
-// Helper stream for the feature gather: a pure HBM stream (302 MB) that runs beside the MFMA-bound x-projection
-// GEMMs of the question branch.  Always available (no environment switch); falls back to the caller's stream.
-Side& gather_stream() {
-    static Side sd[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    Side& x = sd[dev & 63];
-    if (!x.tried) {
-        x.tried = true;
-        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-    }
-    return x;
-}
-// how V_ft = features[image_idx] is produced: 0 = on the helper stream beside the question branch (default),
-// 1 = fused into v_linear_v's GEMM operand load, 2 = inline on the caller's stream
+// how V_ft = features[image_idx] is produced: 0 = a gather pass in front of v_linear_v's GEMM (default), 1 = fused
+// into that GEMM's operand load (VQA_FLAG_FUSED_GATHER or VQA_HOT_GATHER=fused).  Measured at bs 512
+// (profiles/r2_gather_mode_ab.txt, r2_gather_gemm_bench.txt): 3.73 ms per step either way -- the 46 us gather pass
+// doubles as a prefetch of V_ft into the Infinity Cache, from where the GEMM streams its left operand 37 us faster than
+// the fused form streams it from HBM.  A third form, the gather on a helper stream beside the question branch's
+// projection GEMMs, lost 0.13 ms to the cross-stream fork / join.
 int gather_mode(const vqa_dims_t* dims) {
     static int env = -2;
     if (env == -2) {
         const char* e = getenv("VQA_HOT_GATHER");
-        env = e == nullptr ? -1 : (strcmp(e, "fused") == 0 ? 1 : strcmp(e, "inline") == 0 ? 2 : 0);
+        env = e == nullptr ? -1 : (strcmp(e, "fused") == 0 ? 1 : 0);
     }
     if (env >= 0) return env;
     return (dims->flags & VQA_FLAG_FUSED_GATHER) ? 1 : 0;
@@ -328,40 +317,28 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     ProbeScope ps_all("forward", c.st);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
 
-    // visual branch (a1 + a2) and the input projections of the question branch (a3, first half of a4).
-    //  * default: the feature gather V_ft = features[image_idx] (a pure HBM stream, 302 MB) runs on a helper stream
-    //    beside the MFMA-bound x-projection GEMMs; v_linear_v's GEMM then reads V_ft out of the Infinity Cache;
-    //  * VQA_FLAG_FUSED_GATHER: no gather pass -- v_linear_v's GEMM reads the table rows through image_idx in its
-    //    operand loader and leaves the gathered block behind as a by-product (151 MB less HBM traffic, but the GEMM
-    //    then streams its left operand from HBM: +37 us, tools/gather_gemm_bench.py);
-    //  * VQA_HOT_OVERLAP=1: the whole visual branch on the side stream (round-1 experiment).
+    // visual branch (a1 + a2) on the side stream (VQA_HOT_OVERLAP=1 only), question branch (a3-a5) on the caller's
     Side& sd = side_stream();
     const bool forked = fork_side(c, sd);
     Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
-    const int gmode = gather_mode(dims);
-    const bool fuse_gather = gmode == 1 && (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table);
-    Side& gs = gather_stream();
-    const bool gather_aside = !fuse_gather && gmode == 0 && !forked && gs.ok && fork_side(c, gs);
-    auto visual_gemm = [&]() -> int {
-        if (fuse_gather) {
-            {
-                ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
-                TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
-                                        P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"),
-                                        (int)D, cv.st));
-            }
-            return vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
-                                   cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st);
-        }
-        return fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
-                              nullptr, 1.f);
-    };
-    // a1: V_ft = features[image_idx], num_V_ft = num_boxes[image_idx]
+    const bool fuse_gather = gather_mode(dims) == 1 && (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table);
+    // a1: V_ft = features[image_idx] (a pass of its own, or inside the GEMM below), num_V_ft = num_boxes[image_idx]
     TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
-                            cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, gather_aside ? gs.s : cv.st));
-    if (gather_aside && !join_side_record(gs)) return VQA_ERR_LAUNCH;
-    // a2 (when nothing runs beside it): v_linear_v, LN statistics over the whole [R,H] block of a sample
-    if (!gather_aside) TRY(visual_gemm());
+                            cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, cv.st));
+    // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
+    if (fuse_gather) {
+        {
+            ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
+            TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
+                                    P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
+                                    cv.st));
+        }
+        TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
+                            cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
+    } else {
+        TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
+                           nullptr, 1.f));
+    }
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
@@ -369,10 +346,6 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     float* xp = c.f("xp");
     TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
     TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
-    if (gather_aside) {       // the gather has been running beside the projections; now a2
-        if (hipStreamWaitEvent(c.st, gs.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
-        TRY(visual_gemm());
-    }
     float* hs = c.f("hs");
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
     const float* Wg_h = P->gru_wg + W * 2 * H;

@@ -100,10 +100,13 @@ class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
-                 keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None):
+                 keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
+                 fused_gather=False):
         """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
         from float atomics to an atomic-free kernel, ~30 us slower at bs 512).  Per engine: the choice travels in
-        vqa_dims_t.flags with every call, no process-wide library state is touched."""
+        vqa_dims_t.flags with every call, no process-wide library state is touched.
+        fused_gather=True: no feature-gather pass; v_linear_v's GEMM reads the table rows through image_idx
+        (vqa_gemm_f32_gather).  Same step time as the default at bs 512, 151 MB less HBM traffic."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
@@ -114,7 +117,8 @@ class FusionEngine:
                               model_type=self.MODEL_TYPE_ID[model_type],
                               keep_att=keep_att, keep_joint=keep_joint,
                               inv_global_batch=1.0 / float(global_batch or B),
-                              flags=_lib.FLAG_DETERMINISTIC if deterministic else 0)
+                              flags=(_lib.FLAG_DETERMINISTIC if deterministic else 0) |
+                                    (_lib.FLAG_FUSED_GATHER if fused_gather else 0))
         self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
         names = sorted(self.shapes)
         embed = self.sc["embed"]
