@@ -112,6 +112,9 @@ int vqa_gemm_set_tall_config(int cfg);
  * of a sample; rows = 1 otherwise), gamma/beta on the last axis, eps 1e-12.
  * vlmap/modules.py:647-650 (layers.layer_norm + relu), vqa/model_vlmap_answer.py:180
  * (tf.nn.dropout 0.5).  pre,y [G*rows,N]; mean,rstd [G]; keepmask u8 [G*rows,N] or NULL. */
+/* tuning / A-B switch: 1 (default) = register-resident kernels for groups of 5..36 rows x 1024 columns (v_linear_v's
+ * 36 x 1024 block per sample), 0 = generic kernels */
+int vqa_ln_set_fast(int on);
 int vqa_ln_relu_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask,
                     float keep_prob, float* y, float* mean, float* rstd, int G, int rows, int N, void* stream);
 /* backward.  dy [G*rows,N] -> dpre; per-group partial sums of d(gamma), d(beta),

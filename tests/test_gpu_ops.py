@@ -375,3 +375,28 @@ def test_attention_fast_forward_equals_generic(B, rep, R, H, D, drop):
     torch.testing.assert_close(res[1][1], res[0][1], rtol=2e-6, atol=1e-7)
     a = res[1][0].cpu().numpy().reshape(B, rep, R)
     assert np.all(a[np.broadcast_to(np.arange(R)[None, None, :] >= nbv[:, None, None], a.shape)] == 0)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_ln_register_resident_kernels_equal_generic(drop):
+    """Groups of 36 x 1024 (v_linear_v's block per sample) take the register-resident LN kernels; they compute what the
+    generic kernels do (same per-thread order; equal up to the compiler's fused multiply-adds)."""
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    G, rows, N = 9, 36, 1024
+    rng = np.random.default_rng(77)
+    f = lambda a: dev(a.astype(np.float32))
+    pre = f(rng.standard_normal((G * rows, N)) * 2 + 0.5)
+    gamma, beta = f(1 + 0.2 * rng.standard_normal(N)), f(0.2 * rng.standard_normal(N))
+    dy = f(rng.standard_normal((G * rows, N)))
+    km = dev((rng.random((G * rows, N)) < 0.5).astype(np.uint8)) if drop else None
+    res = []
+    try:
+        for fast in (0, 1):
+            lib.vqa_ln_set_fast(fast)
+            y, mean, rs = ops.ln_relu_fwd(pre, gamma, beta, rows, km, 0.5)
+            res.append((y, mean, rs) + tuple(ops.ln_relu_bwd(dy, pre, mean, rs, gamma, beta, rows, km, 0.5)))
+    finally:
+        lib.vqa_ln_set_fast(1)
+    for a, b in zip(res[0], res[1]):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))

@@ -101,6 +101,7 @@ SIGNATURES = {
     "vqa_gru_seq_bwd_live": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_gru_fill_finished": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "vqa_gru_zero_finished": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vqa_ln_set_fast": (_I, [_I]),
     "vqa_ln_relu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_act_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -209,6 +209,136 @@ __global__ void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __
     }
 }
 
+// Register-resident forms for wide groups with N == 1024 (v_linear_v: 36 x 1024 per sample): thread (cx, ry) owns the
+// float4 column unit cx of rows ry, ry + 4, ... (exactly RPT of them: rows == 4 RPT) and fetches ALL of them up front -- one memory
+// latency for the whole group instead of one per row and pass, and no second / third read of the group.  Same
+// per-thread element order as the generic kernels.  (Native vector type + clamped, unconditional loads: see
+// attention.hip on what hipcc does with guarded float4 loads.)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int REG_CUT = 256, REG_RY = 4;
+
+template <int RPT, bool MASK>
+__global__ __launch_bounds__(REG_CUT * REG_RY) void ln_fwd_reg_kernel(
+    const float* __restrict__ pre, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, int rows) {
+    constexpr int N4 = REG_CUT;
+    __shared__ float red[16];
+    const int g = blockIdx.x, cx = threadIdx.x % REG_CUT, ry = threadIdx.x / REG_CUT;
+    const int64_t base4 = (int64_t)g * rows * N4;
+    const f32x4v* p4 = reinterpret_cast<const f32x4v*>(pre) + base4;
+    const unsigned* m4 = MASK ? reinterpret_cast<const unsigned*>(keepmask) + base4 : nullptr;
+    const float invL = 1.f / ((float)rows * (float)(N4 * 4));
+    f32x4v x[RPT];
+    unsigned km[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int o = (ry + REG_RY * i) * N4 + cx;          // rows == REG_RY * RPT exactly: no clamp, no guard
+        x[i] = p4[o];
+        if (MASK) km[i] = m4[o];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) { s += x[i].x; s += x[i].y; s += x[i].z; s += x[i].w; }
+    const float mean = block_sum(s, red) * invL;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = x[i][j] - mean; q += d * d; }
+    }
+    const float var = block_sum(q, red) * invL;
+    const float rstd = 1.f / sqrtf(var + LN_EPS);
+    if (threadIdx.x == 0) { mean_out[g] = mean; rstd_out[g] = rstd; }
+    const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx], be = reinterpret_cast<const f32x4v*>(beta)[cx];
+    f32x4v* y4 = reinterpret_cast<f32x4v*>(y) + base4;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        f32x4v o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ln = (x[i][j] - mean) * rstd * ga[j] + be[j];
+            float v = fmaxf(ln, 0.f);                           // ReLU only (tanh layers use the generic kernel)
+            if (MASK) v = v * (float)((km[i] >> (8 * j)) & 0xFFu) * inv_keep;
+            o[j] = v;
+        }
+        y4[(ry + REG_RY * i) * N4 + cx] = o;
+    }
+}
+
+template <int RPT, bool MASK>
+__global__ __launch_bounds__(REG_CUT * REG_RY) void ln_bwd_reg_kernel(
+    const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dpre, float* __restrict__ part_dgamma,
+    float* __restrict__ part_dbeta, float* __restrict__ part_dbias, int rows) {
+    constexpr int N4 = REG_CUT, N = N4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];  // [2][RY*CUt*4]
+    __shared__ float red[16];
+    const int g = blockIdx.x, cx = threadIdx.x % REG_CUT, ry = threadIdx.x / REG_CUT;
+    const int64_t base4 = (int64_t)g * rows * N4;
+    const f32x4v* p4 = reinterpret_cast<const f32x4v*>(pre) + base4;
+    const f32x4v* d4 = reinterpret_cast<const f32x4v*>(dy) + base4;
+    const unsigned* m4 = MASK ? reinterpret_cast<const unsigned*>(keepmask) + base4 : nullptr;
+    const float invL = 1.f / ((float)rows * (float)N);
+    const float mean = mean_in[g], rstd = rstd_in[g];
+    float* buf0 = dyn;
+    float* buf1 = dyn + (size_t)REG_RY * REG_CUT * 4;
+    f32x4v x[RPT], d[RPT];
+    unsigned km[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int o = (ry + REG_RY * i) * N4 + cx;
+        x[i] = p4[o];
+        d[i] = d4[o];
+        if (MASK) km[i] = m4[o];
+    }
+    const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx], be = reinterpret_cast<const f32x4v*>(beta)[cx];
+    float s1 = 0.f, s2 = 0.f;
+    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
+    // pass 1 (registers only): d[i] is overwritten by dxh = dln * gamma, x[i] by xhat
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (x[i][j] - mean) * rstd;
+            const float ln = xh * ga[j] + be[j];
+            float gg = d[i][j];
+            if (MASK) gg = gg * (float)((km[i] >> (8 * j)) & 0xFFu) * inv_keep;
+            const float dln = ln > 0.f ? gg : 0.f;                    // ReLU only (tanh layers use the generic kernel)
+            const float dxh = dln * ga[j];
+            s1 += dxh; s2 += dxh * xh; cb[j] += dln; cg[j] += dln * xh;
+            x[i][j] = xh;
+            d[i][j] = dxh;
+        }
+    }
+    if (part_dgamma != nullptr) {
+        col_reduce_store<4>(buf0, cb, part_dbeta + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
+        col_reduce_store<4>(buf1, cg, part_dgamma + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
+    }
+    const float m1 = block_sum(s1, red) * invL;
+    const float m2 = block_sum(s2, red) * invL;
+    float cbias[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4v* o4 = reinterpret_cast<f32x4v*>(dpre) + base4;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        f32x4v o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dp = rstd * (d[i][j] - m1 - x[i][j] * m2);
+            o[j] = dp;
+            cbias[j] += dp;
+        }
+        o4[(ry + REG_RY * i) * N4 + cx] = o;
+    }
+    if (part_dbias != nullptr) col_reduce_store<4>(buf0, cbias, part_dbias + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
+}
+
+int g_ln_reg = 1;   // A/B switch (vqa_ln_set_fast)
+
+// register-resident kernels apply: 16-byte path, N == 1024, rows == 36 (= REG_RY * 9: v_linear_v's block per sample)
+inline bool reg_ok(int U, int rows, int N) { return g_ln_reg && U == 4 && N == REG_CUT * 4 && rows == REG_RY * 9; }
+
 struct Shape { int U, CUt, RY, threads; };
 Shape pick(const void* a, const void* b, const void* c, int rows, int N, bool mask) {
     Shape s;
@@ -225,6 +355,11 @@ Shape pick(const void* a, const void* b, const void* c, int rows, int N, bool ma
 }
 
 }  // namespace
+
+extern "C" int vqa_ln_set_fast(int on) {
+    g_ln_reg = on ? 1 : 0;
+    return VQA_OK;
+}
 
 extern "C" int vqa_ln_relu_fwd(const float* pre, const float* gamma, const float* beta, const uint8_t* keepmask,
                                float keep_prob, float* y, float* mean, float* rstd, int G, int rows, int N,
@@ -246,7 +381,14 @@ extern "C" int vqa_ln_act_fwd(const float* pre, const float* gamma, const float*
     s.threads = s.CUt * s.RY;
     const float inv_keep = keepmask ? 1.f / keep_prob : 1.f;
     hipStream_t st = (hipStream_t)stream;
-    if (s.U == 4)
+    if (reg_ok(s.U, rows, N) && act == 0) {
+        if (keepmask != nullptr)
+            hipLaunchKernelGGL((ln_fwd_reg_kernel<9, true>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre, gamma, beta, keepmask,
+                               inv_keep, y, mean, rstd, rows);
+        else
+            hipLaunchKernelGGL((ln_fwd_reg_kernel<9, false>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre, gamma, beta, keepmask,
+                               inv_keep, y, mean, rstd, rows);
+    } else if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_fwd_kernel<4>, dim3(G), dim3(s.threads), 0, st, pre, gamma, beta, keepmask, inv_keep,
                            y, mean, rstd, rows, N, s.CUt, s.RY, act);
     else
@@ -283,7 +425,15 @@ extern "C" int vqa_ln_act_bwd(const float* dy, const float* pre, const float* me
     const float inv_keep = keepmask ? 1.f / keep_prob : 1.f;
     const size_t dyn = s.RY > 1 ? (size_t)2 * s.RY * s.CUt * s.U * sizeof(float) : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (s.U == 4)
+    if (reg_ok(s.U, rows, N) && act == 0) {
+        const size_t dyn_reg = (size_t)2 * REG_RY * REG_CUT * 4 * sizeof(float);
+        if (keepmask != nullptr)
+            hipLaunchKernelGGL((ln_bwd_reg_kernel<9, true>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st, dy, pre, mean, rstd,
+                               gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows);
+        else
+            hipLaunchKernelGGL((ln_bwd_reg_kernel<9, false>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st, dy, pre, mean, rstd,
+                               gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows);
+    } else if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_bwd_kernel<4>, dim3(G), dim3(s.threads), dyn, st, dy, pre, mean, rstd, gamma, beta,
                            keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY, act);
     else
