@@ -152,7 +152,7 @@ def test_extractor_cli_from_images_on_disk_to_reference_hdf5(tmp_path):
     ids = [p.replace("/", "-") for p in paths]
     json.dump({"image_id2idx": {k: i for i, k in enumerate(ids)}, "image_path2idx": {p: i for i, p in enumerate(paths)},
                "image_num2path": {str(i): p for i, p in enumerate(paths)}}, open(rec_dir / "image_info.json", "w"))
-    blocks = [(n, b // 4, 1, s) for (n, b, u, s) in VF.BLOCKS_R50_B3]            # narrow stack: the plumbing is under test
+    blocks = [(n, b // 2, 1, s) for (n, b, u, s) in VF.BLOCKS_R50_B3]            # narrow stack: the plumbing is under test
     cfg = VX.build_parser().parse_args(["--tf_record_memft_dir", str(rec_dir), "--image_dir", str(img_dir),
                                         "--densecap_dir", str(dc_dir), "--pretrained_param_path", "random:7",
                                         "--batch_size", "2", "--model_type", "resnet"])
