@@ -192,6 +192,20 @@ int vqa_gru_seq_bwd_live(float* dh_T, const float* Wg_h, const float* Wc_h, cons
 int vqa_gru_fill_finished(float* hs, float* rh, const int32_t* len, int T, int B, int H, void* stream);
 int vqa_gru_zero_finished(float* dxp, const int32_t* len, int T, int B, int H, void* stream);
 
+/* The whole forward recurrence in ONE persistent launch (csrc/gru_persistent.hip): the two halves of the batch run as
+ * two independent chains on two co-resident workgroups per CU, a per-chain grid barrier replaces each kernel boundary
+ * and hides behind the other chain's matrix work.  Same tensors as vqa_gru_seq_fwd plus `sync`, a device scratch of
+ * vqa_gru_persistent_sync_bytes() that the call zeroes itself; after the stream has run, a non-zero 32-bit word at
+ * byte offset 128 of `sync` reports a barrier time-out (results invalid).  VQA_ERR_UNSUPPORTED when the shape or the
+ * device does not qualify (vqa_gru_fwd_persistent_supported: H % 64 == 0, B >= 64, every workgroup co-resident). */
+int vqa_gru_seq_fwd_persistent(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
+                               float* r, float* u, float* c, float* rh, int T, int B, int H, unsigned* sync,
+                               void* stream);
+int vqa_gru_fwd_persistent_supported(int T, int B, int H);
+int64_t vqa_gru_persistent_sync_bytes(void);
+int vqa_gru_set_persistent(int mode);   /* -1 automatic, 0 never, 1 whenever supported */
+int vqa_gru_persistent_set_census(unsigned* dev_words);   /* placement study (tools/gru_tune.py); NULL = off */
+
 /* The same restricted to batch rows [row0, row0+rows): samples are independent, so disjoint
  * row windows may run concurrently on different streams. */
 int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,

@@ -43,6 +43,48 @@ def tm(f, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+sync = torch.zeros(int(lib.vqa_gru_persistent_sync_bytes()) // 4, dtype=torch.int32, device="cuda")
+
+
+def fwd_persistent():
+    _lib.check(lib.vqa_gru_seq_fwd_persistent(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(sync),
+                                              None), "fwd_persistent")
+
+
+if os.environ.get("PERSIST") == "1":
+    fwd(); torch.cuda.synchronize()
+    ref = [x.clone() for x in (hs, r, u, c, rh)]
+    for x in (r, u, c, rh):
+        x.fill_(float("nan"))
+    hs[1:].fill_(float("nan"))
+    fwd_persistent(); torch.cuda.synchronize()
+    print("persistent: sync words", sync[[0, 16, 32]].tolist(), flush=True)
+    census = torch.zeros(1024 + 2 * 64 * 4 * 2, dtype=torch.int32, device="cuda")
+    lib.vqa_gru_persistent_set_census(P(census)); fwd_persistent(); torch.cuda.synchronize(); lib.vqa_gru_persistent_set_census(None)
+    cz = census[:512].cpu().numpy().astype("int64")
+    where = {}
+    for b, w in enumerate(cz):
+        key = (int(w >> 16) & 15, int(w >> 13) & 7, int(w >> 12) & 1, int(w >> 8) & 15)      # xcc, se, sh, cu
+        where.setdefault(key, []).append(b)
+    pairs = sorted(where.values())
+    print("  placement: %d distinct CUs; workgroups per CU: %s" % (len(where), sorted(set(len(v) for v in pairs))))
+    print("  first CUs:", pairs[:6], " xcc of blocks 0..9:", [int(w >> 16) & 15 for w in cz[:10]])
+    st = census[1024:].cpu().numpy().view("uint64").reshape(2, 64, 4).astype("float64") / 100.0     # 100 MHz -> us
+    t0 = st[:, 0, 0].min()
+    for ch in range(2):
+        print("  chain %d workgroup: phase (start, wait, k-loop, epilogue) in us relative to launch" % ch)
+        for ph in range(min(2 * T, 8)):
+            a0, a1, a2, a3 = st[ch, ph]
+            print("    %s t=%d  start %7.2f  wait %6.2f  kloop %6.2f  epi %6.2f" % ("G" if ph % 2 == 0 else "C", ph // 2, a0 - t0, a1 - a0, a2 - a1, a3 - a2))
+        print("    ... last phase ends at %.2f us" % (st[ch, 2 * T - 1, 3] - t0))
+    same = sum(1 for v in pairs if len(v) == 2 and (v[0] < 256) == (v[1] < 256))
+    print("  CUs whose two workgroups are in the SAME chain (blocks both < 256 or both >= 256): %d of %d" % (same, len(pairs)), flush=True)
+    for name, a, b in zip(("hs", "r", "u", "c", "rh"), ref, (hs, r, u, c, rh)):
+        print("  max |%s - stepwise| = %.3e  (max |.| %.3e)" % (name, float((a - b).abs().max()), float(a.abs().max())), flush=True)
+    for rep in range(3):
+        print("  forward: stepwise %.1f us   persistent %.1f us" % (tm(fwd), tm(fwd_persistent)), flush=True)
+    sys.exit(0)
+
 cfgs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "11,16,17,18").split(",")]
 best = {k: [1e9, 1e9] for k in cfgs}
 ref = None

@@ -94,6 +94,11 @@ SIGNATURES = {
     "vqa_gemm_set_config": (_I, [_I]),
     "vqa_gemm_set_gru_config": (_I, [_I]),
     "vqa_gru_seq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_seq_fwd_persistent": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "vqa_gru_fwd_persistent_supported": (_I, [_I, _I, _I]),
+    "vqa_gru_persistent_sync_bytes": (_L, []),
+    "vqa_gru_set_persistent": (_I, [_I]),
+    "vqa_gru_persistent_set_census": (_I, [_P]),
     "vqa_gru_seq_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
