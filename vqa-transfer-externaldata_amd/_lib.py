@@ -92,6 +92,7 @@ SIGNATURES = {
     "vqa_gemm_set_max_blocks": (_I, [_I]),
     "vqa_gemm_set_order": (_I, [_I]),
     "vqa_gemm_set_config": (_I, [_I]),
+    "vqa_conv_set_config": (_I, [_I]),
     "vqa_gemm_set_gru_config": (_I, [_I]),
     "vqa_gru_seq_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_gru_seq_fwd_persistent": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),

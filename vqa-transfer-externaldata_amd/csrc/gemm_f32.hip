@@ -1005,6 +1005,7 @@ int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 // L2<->fabric traffic of the weight matrix, which no XCD's 4 MiB L2 can hold (8 MB).
 int g_tall_cfg = 20;
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
+int g_conv_cfg = 0;     // tile config of the implicit-GEMM convolutions (vqa_conv_set_config)
 // Tile config of the fused GRU-step GEMMs: many waves with small per-wave tiles (32x32), in-block split-k and two
 // tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU, and
 // every k group finishes its share of the rows in the epilogue (recurrence at B 512, H 1024, T 14: 622 -> 523 us
@@ -1365,6 +1366,7 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
         const int cfg = (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) ? g_force_cfg : 3;
         return launch_by_id(cfg, 0, 0, a, 1, st, 0);
     }
+    const int ccfg = g_conv_cfg;
     // one 32-deep k tile per filter tap, or 4-channel pixels with a K that is a whole number of tiles (conv1)
     VQA_REQUIRE((Ci % 32 == 0 || (Ci == 4 && K % 32 == 0)) && vqa_aligned16(x), VQA_ERR_ALIGN);
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1377,5 +1379,16 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     const EpiArgs ep{};
     // 64x64 tiles also for wide layers: more workgroups per launch beat the 64x128 tile's operand reuse
     // (ResNet-101 @448, batch 64: 1737 -> 1803 images/s)
-    return launch_one<64, 64, 32, 32, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
+    switch (ccfg) {
+        case 1: return launch_one<128, 64, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, true, false, 512>(a, ep, 1, st, 0);
+        case 2: return launch_one<64, 128, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, true, false, 512>(a, ep, 1, st, 0);
+        case 3: return launch_one<128, 128, 64, 32, 1, 32, 0, true, false, EPI_PLAIN, true, false, 512>(a, ep, 1, st, 0);
+        default: return launch_one<64, 64, 32, 32, 1, 32, false, true, false, EPI_PLAIN, true>(a, ep, 1, st, 0);
+    }
+}
+
+extern "C" int vqa_conv_set_config(int cfg) {
+    VQA_REQUIRE(cfg >= 0 && cfg <= 3, VQA_ERR_ARG);
+    g_conv_cfg = cfg;
+    return VQA_OK;
 }
