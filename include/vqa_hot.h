@@ -422,8 +422,9 @@ int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_pa
 int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co,
                     int stride, int pad_t, int pad_l, int Ho, int Wo, const float* scale, const float* shift,
                     const float* residual, int relu, float* y, void* stream);
-/* tuning: tile configuration of the implicit-GEMM path (0 = 64x64 / 4 waves, 1 = 128x64, 2 = 64x128, 3 = 128x128, all
- * 8 waves); process-wide, like vqa_gemm_set_config (which the 1x1 path follows). */
+/* tuning: tile configuration of the implicit-GEMM path (-1 = chosen by shape, the default; 0 = 64x64 / 4 waves,
+ * 1 = 128x64, 2 = 64x128, 3 = 128x128, all 8 waves; >= 0 also pins the 1x1 path to 64x64 unless vqa_gemm_set_config
+ * forces another); process-wide, like vqa_gemm_set_config. */
 int vqa_conv_set_config(int cfg);
 /* y [B,Hi,Wi,4] = (x [B,Hi,Wi,3] - mean_host, 0): 16-byte pixels, so that conv1 (7x7/2 on RGB, vlmap/modules.py:170-190)
  * runs through vqa_conv2d_nhwc as an implicit GEMM with Ci = 4 and an 8-wide zero-padded filter row (K = 7*8*4). */

@@ -89,8 +89,8 @@ for key, cnt in sorted(shapes.items(), key=lambda kv: -kv[1]):
             if d > 1e-3 * ref.abs().max().item():
                 print("  !! cfg %d differs from first cfg by %.3e" % (c, d))
     lib.vqa_gemm_set_config(-1)
-    lib.vqa_conv_set_config(0)
-    d0 = res_t[3 if plain else 0]
+    lib.vqa_conv_set_config(-1)
+    d0, _ = time_shape(key)               # the shipped per-shape choice
     b = min(res_t, key=res_t.get)
     tot_def += cnt * d0
     tot_best += cnt * res_t[b]

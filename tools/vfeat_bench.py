@@ -15,6 +15,9 @@ rng = np.random.default_rng(1234)
 if os.environ.get("VQA_GEMM_CFG"):   # tuning only
     from vqa_transfer_externaldata_amd import _lib
     _lib.load().vqa_gemm_set_config(int(os.environ["VQA_GEMM_CFG"]))
+if os.environ.get("VQA_CONV_CFG"):   # tuning only: one tile config for every implicit-GEMM convolution
+    from vqa_transfer_externaldata_amd import _lib
+    _lib.load().vqa_conv_set_config(int(os.environ["VQA_CONV_CFG"]))
 model = VF.VfeatResnetModel(VF.init_random_params(rng, VF.BLOCKS_R101_FULL), VF.BLOCKS_R101_FULL)
 g = torch.Generator(device="cuda").manual_seed(1)
 img = torch.rand(batch, 448, 448, 3, generator=g, device="cuda") * 255.0

@@ -1005,7 +1005,8 @@ int g_force_cfg = -1;   // tuning override (vqa_gemm_set_config)
 // L2<->fabric traffic of the weight matrix, which no XCD's 4 MiB L2 can hold (8 MB).
 int g_tall_cfg = 20;
 int g_max_blocks = 0;   // tuning override for vqa_gemm_f32 (vqa_gemm_set_max_blocks)
-int g_conv_cfg = 0;     // tile config of the implicit-GEMM convolutions (vqa_conv_set_config)
+int g_conv_cfg = -1;    // tile config of the implicit-GEMM convolutions (vqa_conv_set_config); -1 = by shape
+int g_conv_cfg_plain = -1;
 // Tile config of the fused GRU-step GEMMs: many waves with small per-wave tiles (32x32), in-block split-k and two
 // tiles of register prefetch hide the per-tile barrier and load latency better than 4 waves of 64x32 per CU, and
 // every k group finishes its share of the rows in the epilogue (recurrence at B 512, H 1024, T 14: 622 -> 523 us
@@ -1362,11 +1363,21 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     a.scale = scale;
     a.relu = relu;
     if (plain) {
-        // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M
-        const int cfg = (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) ? g_force_cfg : 3;
+        // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M.  The expansions
+        // (Co >= 2 Ci: k loop of 2..16 tiles, then an epilogue that reads the residual and writes 4x the input)
+        // amortise that epilogue better on 128x128 tiles of 8 waves once there are enough of them
+        // (tools/conv_tune.py, profiles/r2_conv_tune.txt: 256 -> 1024 @28x28: 477 -> 465 us, 64 -> 256 @112x112:
+        // 894 -> 814 us); the 256 -> 64 reduction at 112x112 likes 128x64.
+        int cfg = 3;
+        if (Co >= 256 && Co >= 2 * Ci && (int64_t)M * Co >= (1ll << 25)) cfg = 16;
+        else if (Co <= 64 && Ci >= 256) cfg = 20;
+        if (g_conv_cfg_plain >= 0) cfg = g_conv_cfg_plain;
+        if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
         return launch_by_id(cfg, 0, 0, a, 1, st, 0);
     }
-    const int ccfg = g_conv_cfg;
+    // 3x3: 128x64 tiles of 8 waves for the stride-1 layers up to 256 channels (256 @28x28: 1014 -> 938 us), the
+    // 64x64 / 4-wave tile for the deep narrow-M layers and the strided ones (profiles/r2_conv_tune.txt)
+    const int ccfg = g_conv_cfg >= 0 ? g_conv_cfg : (((stride == 1 && Ci <= 256) || Ci <= 64) && Ci >= 32 ? 1 : 0);
     // one 32-deep k tile per filter tap, or 4-channel pixels with a K that is a whole number of tiles (conv1)
     VQA_REQUIRE((Ci % 32 == 0 || (Ci == 4 && K % 32 == 0)) && vqa_aligned16(x), VQA_ERR_ALIGN);
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1388,7 +1399,8 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
 }
 
 extern "C" int vqa_conv_set_config(int cfg) {
-    VQA_REQUIRE(cfg >= 0 && cfg <= 3, VQA_ERR_ARG);
+    VQA_REQUIRE(cfg >= -1 && cfg <= 3, VQA_ERR_ARG);
     g_conv_cfg = cfg;
+    g_conv_cfg_plain = cfg < 0 ? -1 : 3;     // a forced config also pins the 1x1 path to its 64x64 tile
     return VQA_OK;
 }
