@@ -232,7 +232,9 @@ int vqa_attn_pool_bwd(const float* dpooled, const float* v, const float* qv, con
  * same regions, vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:323-364, without materialising the
  * x5 tile): v [B,R,H], V [B,R,D], nb [B] per memory; qv [B*rep,H], keepmask [B*rep,R,H], att
  * [B*rep,R], pooled [B*rep,D] per query; dv [B,R,H] is summed over the queries of a memory. */
-/* tuning / A-B switch: 1 (default) = the loads-in-flight forward kernel for the models' shapes, 0 = generic kernel */
+/* tuning / A-B switch: 0 = generic kernel; 1 (default) = the loads-in-flight forward kernel for the models' shapes when
+ * rep == 1 and the one-workgroup-per-memory kernel when rep == 5; 2 = also the per-query fast kernel for other reps;
+ * 3 = the per-query fast kernel for every rep */
 int vqa_attn_set_fast(int on);
 int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const float* V, const int32_t* nb, const float* w,
                           const float* bias, const uint8_t* keepmask, float keep_prob, float* att, float* pooled,

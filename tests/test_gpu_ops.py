@@ -349,7 +349,8 @@ def test_gather_fused_gemm_equals_gather_then_gemm(B, R, N, K, Nt):
     assert lib.vqa_gemm_f32_gather(B * R, N, K - 4, P(t_d), K, P(i_d), R, Nt, P(w_d), N, P(out), N, None, None, 0, None) == -4
 
 
-@pytest.mark.parametrize("B,rep,R,H,D", [(5, 1, 36, 1024, 2048), (3, 5, 36, 1024, 2048), (4, 1, 20, 512, 4096), (2, 2, 40, 256, 2048)])
+@pytest.mark.parametrize("B,rep,R,H,D", [(5, 1, 36, 1024, 2048), (3, 5, 36, 1024, 2048), (4, 1, 20, 512, 4096), (2, 2, 40, 256, 2048),
+                                         (2, 5, 40, 256, 4096), (3, 5, 17, 768, 2048), (2, 5, 1, 512, 2048)])
 @pytest.mark.parametrize("drop", [False, True])
 def test_attention_fast_forward_equals_generic(B, rep, R, H, D, drop):
     """The loads-in-flight forward kernel (H | 256, D | 2048) computes what the generic kernel does: same summation
@@ -366,13 +367,14 @@ def test_attention_fast_forward_equals_generic(B, rep, R, H, D, drop):
     km = dev((rng.random((B * rep, R, H)) < 0.8).astype(np.uint8)) if drop else None
     res = []
     try:
-        for fast in (0, 1):
+        for fast in (0, 1, 3):      # generic | default (per-memory kernel at rep 5) | per-query fast kernel
             lib.vqa_attn_set_fast(fast)
             res.append(ops.attn_pool_fwd_rep(v, qv, V, nb, w, bias, rep, km, 0.8))
     finally:
         lib.vqa_attn_set_fast(1)
-    torch.testing.assert_close(res[1][0], res[0][0], rtol=2e-6, atol=1e-8)
-    torch.testing.assert_close(res[1][1], res[0][1], rtol=2e-6, atol=1e-7)
+    for k in (1, 2):
+        torch.testing.assert_close(res[k][0], res[0][0], rtol=2e-6, atol=1e-8)
+        torch.testing.assert_close(res[k][1], res[0][1], rtol=2e-6, atol=1e-7)
     a = res[1][0].cpu().numpy().reshape(B, rep, R)
     assert np.all(a[np.broadcast_to(np.arange(R)[None, None, :] >= nbv[:, None, None], a.shape)] == 0)
 

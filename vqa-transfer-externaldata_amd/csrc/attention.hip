@@ -232,6 +232,138 @@ __global__ __launch_bounds__(FWD_THREADS, 4) void attn_pool_fwd_fast_kernel(
         reinterpret_cast<f32x4v*>(pooled + (int64_t)b * D)[threadIdx.x + c * FWD_THREADS] = acc[c];
 }
 
+// `REP` queries per memory (the pre-training model: 5 key boxes per image), one workgroup per MEMORY: v and V are read
+// once per image instead of once per query (the per-query form re-reads them REP times through L2: 1.2 GB of requests
+// for 0.32 GB of distinct bytes at 512 images), only the keep masks are per query.  Same three phases as above; a
+// wave scores its rows for all REP queries from one load of the row, waves 0..REP-1 run the REP softmaxes, and the
+// pooling loop keeps REP accumulators per thread over one stream of V.
+constexpr int REP_PF = 4, REP_POOL_BATCH = 6;
+template <int H4L, int CNT, bool MASK, int REP>
+__device__ __forceinline__ void attn_score_rows_rep(const f32x4v* __restrict__ vb4, const unsigned* __restrict__ mb4,
+                                                    const f32x4v* qw4, float* s, int R, int row0, float inv_keep,
+                                                    float bias0, int lane, bool sync_first) {
+    constexpr int H4 = H4L * 64;
+    f32x4v x[CNT][H4L];
+    int rr[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        rr[i] = min(row0 + 8 * i, R - 1);
+#pragma unroll
+        for (int k = 0; k < H4L; ++k) x[i][k] = vb4[(int64_t)rr[i] * H4 + lane + 64 * k];
+    }
+    if (sync_first) __syncthreads();                 // qw is complete
+#pragma unroll
+    for (int j = 0; j < REP; ++j) {
+        unsigned m[CNT][H4L];
+        if (MASK) {
+#pragma unroll
+            for (int i = 0; i < CNT; ++i)
+#pragma unroll
+                for (int k = 0; k < H4L; ++k) m[i][k] = mb4[((int64_t)j * R + rr[i]) * H4 + lane + 64 * k];
+        }
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < H4L; ++k) {
+                const f32x4v q = qw4[j * H4 + lane + 64 * k];
+                if (MASK) {
+                    const unsigned mm = m[i][k];
+                    acc += (x[i][k].x * q.x * (float)(mm & 0xFFu) + x[i][k].y * q.y * (float)((mm >> 8) & 0xFFu) +
+                            x[i][k].z * q.z * (float)((mm >> 16) & 0xFFu) + x[i][k].w * q.w * (float)(mm >> 24)) * inv_keep;
+                } else {
+                    acc += x[i][k].x * q.x + x[i][k].y * q.y + x[i][k].z * q.z + x[i][k].w * q.w;
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && row0 + 8 * i < R) s[j * 40 + row0 + 8 * i] = acc + bias0;
+        }
+    }
+}
+
+template <int H4L, int D4T, bool MASK, int REP>
+__global__ __launch_bounds__(FWD_THREADS, 2) void attn_pool_fwd_rep_kernel(
+    const float* __restrict__ v, const float* __restrict__ qv, const float* __restrict__ V,
+    const int32_t* __restrict__ nb, const float* __restrict__ w, const float* __restrict__ bias,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ att_out, float* __restrict__ pooled, int R) {
+    static_assert(REP <= FWD_THREADS / 64, "one softmax wave per query");
+    constexpr int H = H4L * 256, D = D4T * 2048, D4 = D / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // qw[REP][H] | s[REP][40]
+    float* qw = lds;
+    float* s = lds + REP * H;
+    const int mem = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q0 = (int64_t)mem * REP;                         // first query of this memory
+    const f32x4v* vb4 = reinterpret_cast<const f32x4v*>(v + (int64_t)mem * R * H);
+    const unsigned* mb4 = MASK ? reinterpret_cast<const unsigned*>(keepmask + q0 * R * H) : nullptr;
+    const f32x4v* Vb4 = reinterpret_cast<const f32x4v*>(V + (int64_t)mem * R * D);
+
+    f32x4v xv[REP_PF][D4T];
+#pragma unroll
+    for (int j = 0; j < REP_PF; ++j)
+#pragma unroll
+        for (int c = 0; c < D4T; ++c) xv[j][c] = Vb4[(int64_t)min(j, R - 1) * D4 + threadIdx.x + c * FWD_THREADS];
+
+    for (int i = threadIdx.x; i < REP * H; i += FWD_THREADS) qw[i] = qv[q0 * H + i] * w[i % H];
+    const float bias0 = bias[0];
+
+    const f32x4v* qw4 = reinterpret_cast<const f32x4v*>(qw);
+    attn_score_rows_rep<H4L, 2, MASK, REP>(vb4, mb4, qw4, s, R, wave, inv_keep, bias0, lane, true);
+    attn_score_rows_rep<H4L, 2, MASK, REP>(vb4, mb4, qw4, s, R, wave + 16, inv_keep, bias0, lane, false);
+    attn_score_rows_rep<H4L, 1, MASK, REP>(vb4, mb4, qw4, s, R, wave + 32, inv_keep, bias0, lane, false);
+    __syncthreads();
+
+    if (wave < REP) {
+        float* sj = s + wave * 40;
+        const int n_valid = nb[mem];
+        const float x = (lane < R && lane < n_valid) ? sj[min(lane, R - 1)] : -INFINITY;      // R <= 40 < 64: one lane per row
+        const float mx = wave_max(x);
+        const float e = (lane < R) ? expf(x - mx) : 0.f;  // all -inf (nb == 0) -> NaN, like TF
+        const float sum = wave_sum(e);
+        if (lane < R) {
+            const float a = e / sum;
+            sj[lane] = a;
+            att_out[(q0 + wave) * R + lane] = a;
+        }
+    }
+    __syncthreads();
+
+    f32x4v acc[REP][D4T];
+#pragma unroll
+    for (int j = 0; j < REP; ++j)
+#pragma unroll
+        for (int c = 0; c < D4T; ++c) acc[j][c] = (f32x4v)(0.f);
+#pragma unroll
+    for (int r = 0; r < REP_PF; ++r) {
+#pragma unroll
+        for (int j = 0; j < REP; ++j) {
+            const float a = (r < R) ? s[j * 40 + min(r, R - 1)] : 0.f;
+#pragma unroll
+            for (int c = 0; c < D4T; ++c) acc[j][c] += a * xv[r][c];
+        }
+    }
+    for (int r0 = REP_PF; r0 < R; r0 += REP_POOL_BATCH) {
+        f32x4v y[REP_POOL_BATCH][D4T];
+#pragma unroll
+        for (int i = 0; i < REP_POOL_BATCH; ++i)
+#pragma unroll
+            for (int c = 0; c < D4T; ++c) y[i][c] = Vb4[(int64_t)min(r0 + i, R - 1) * D4 + threadIdx.x + c * FWD_THREADS];
+#pragma unroll
+        for (int i = 0; i < REP_POOL_BATCH; ++i) {
+#pragma unroll
+            for (int j = 0; j < REP; ++j) {
+                const float a = (r0 + i < R) ? s[j * 40 + min(r0 + i, R - 1)] : 0.f;
+#pragma unroll
+                for (int c = 0; c < D4T; ++c) acc[j][c] += a * y[i][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < REP; ++j)
+#pragma unroll
+        for (int c = 0; c < D4T; ++c)
+            reinterpret_cast<f32x4v*>(pooled + (q0 + j) * D)[threadIdx.x + c * FWD_THREADS] = acc[j][c];
+}
+
 // Backward.  One workgroup per MEMORY walks its `rep` queries, so dv (the gradient of the shared
 // v block) is accumulated over the queries in registers and written once.  512 threads: the last
 // phase gives every float4 column of v to TWO threads that take alternate rows (dv rows are
@@ -355,7 +487,9 @@ int g_attn_fast = 1;   // tuning / A-B switch (vqa_attn_set_fast)
 }  // namespace
 
 extern "C" int vqa_attn_set_fast(int on) {
-    g_attn_fast = on;      // 0 generic, 1 fast kernel for one query per memory, 2 fast kernel for every rep
+    // 0 generic; 1 (default) fast kernel for one query per memory and the per-memory kernel for rep 5; 2 per-query fast
+    // kernel for the other reps as well; 3 per-query fast kernel for every rep (A/B of the per-memory kernel)
+    g_attn_fast = on;
     return VQA_OK;
 }
 
@@ -379,9 +513,30 @@ extern "C" int vqa_attn_pool_fwd_rep(const float* v, const float* qv, const floa
     const size_t lds = (size_t)(H + R) * sizeof(float);
     const float ik = keepmask ? 1.f / keep_prob : 1.f;
     hipStream_t st = (hipStream_t)stream;
-    const bool fast = g_attn_fast && (rep == 1 || g_attn_fast > 1) && R <= 40 && H % 256 == 0 && H <= 1024 && D % 2048 == 0 && D <= 4096 &&
+    const bool fast = g_attn_fast && (rep == 1 || rep == 5 || g_attn_fast > 1) && R <= 40 && H % 256 == 0 && H <= 1024 && D % 2048 == 0 && D <= 4096 &&
                       vqa_aligned16(qv) && vqa_aligned16(w);
-    if (fast) {
+    if (fast && rep == 5 && g_attn_fast != 3) {
+        // one workgroup per memory for the pre-training model's 5 queries per image
+        const size_t lds5 = (size_t)(5 * H + 5 * 40) * sizeof(float);
+#define VQA_ATTN_REP5(h4l, d4t)                                                                                        \
+    do {                                                                                                                \
+        if (keepmask != nullptr)                                                                                        \
+            hipLaunchKernelGGL((attn_pool_fwd_rep_kernel<h4l, d4t, true, 5>), dim3(B), dim3(FWD_THREADS), lds5, st, v,  \
+                               qv, V, nb, w, bias, keepmask, ik, att, pooled, R);                                       \
+        else                                                                                                            \
+            hipLaunchKernelGGL((attn_pool_fwd_rep_kernel<h4l, d4t, false, 5>), dim3(B), dim3(FWD_THREADS), lds5, st, v, \
+                               qv, V, nb, w, bias, keepmask, ik, att, pooled, R);                                       \
+    } while (0)
+        const int h4l = H / 256, d4t = D / 2048;
+        if (d4t == 1) {
+            if (h4l == 1) VQA_ATTN_REP5(1, 1); else if (h4l == 2) VQA_ATTN_REP5(2, 1);
+            else if (h4l == 3) VQA_ATTN_REP5(3, 1); else VQA_ATTN_REP5(4, 1);
+        } else {
+            if (h4l == 1) VQA_ATTN_REP5(1, 2); else if (h4l == 2) VQA_ATTN_REP5(2, 2);
+            else if (h4l == 3) VQA_ATTN_REP5(3, 2); else VQA_ATTN_REP5(4, 2);
+        }
+#undef VQA_ATTN_REP5
+    } else if (fast) {
 #define VQA_ATTN_FAST(h4l, d4t)                                                                                         \
     do {                                                                                                                \
         if (keepmask != nullptr)                                                                                        \

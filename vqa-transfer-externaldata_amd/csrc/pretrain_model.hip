@@ -108,7 +108,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
         L.add(p + "key6", Bn * 6);
         L.add(p + "v_pre", B * R * H); L.add(p + "v", B * R * H); L.add(p + "v_mean", B); L.add(p + "v_rstd", B);
         L.add(p + "qv_pre", Bn * H); L.add(p + "qv", Bn * H); L.add(p + "qv_mean", B); L.add(p + "qv_rstd", B);
-        L.add(p + "att", Bn * R); L.add(p + "pooled", Bn * D);
+        L.add(p + "att", Bn * R); L.add(p + "pooled", Bn * D); L.add(p + "vl_pre", Bn * H);
         L.add(p + "valid", Bn); L.add(p + "inv_valid", 4);
         L.add(p + "blanks_s", Bn * T); L.add(p + "lens_s", Bn);
         L.add(p + "x_tm", T * Bn * W); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
@@ -119,7 +119,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
         L.add(p + "wf_pre", Bn * H); L.add(p + "wf", Bn * H); L.add(p + "wf_mean", B); L.add(p + "wf_rstd", B);
         for (int t = 0; t < 2; ++t) {
             const std::string q = p + HEAD[t] + "/";
-            L.add(q + "vl_pre", Bn * H); L.add(q + "vl", Bn * H); L.add(q + "vl_mean", B); L.add(q + "vl_rstd", B);
+            L.add(q + "vl", Bn * H); L.add(q + "vl_mean", B); L.add(q + "vl_rstd", B);
             L.add(q + "ll_pre", Bn * H); L.add(q + "ll", Bn * H); L.add(q + "ll_mean", B); L.add(q + "ll_rstd", B);
             L.add(q + "jin", Bn * H);
             L.add(q + "j_pre", Bn * 2 * H); L.add(q + "j", Bn * 2 * H); L.add(q + "j_mean", B); L.add(q + "j_rstd", B);
@@ -129,8 +129,8 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     L.add("report", 16);
     // backward scratch, shared by the two categories
     L.add("d_j", Bn * 2 * H); L.add("d_jpre", Bn * 2 * H); L.add("d_jin", Bn * H);
-    L.add("d_vl", Bn * H); L.add("d_ll", Bn * H); L.add("d_vlpre", Bn * H); L.add("d_llpre", Bn * H);
-    L.add("d_pl", Bn * D); L.add("d_pooled", Bn * D);
+    L.add("d_vl", Bn * H); L.add("d_ll", Bn * H); L.add("d_vlpre", Bn * H); L.add("d_vlpre0", Bn * H); L.add("d_llpre", Bn * H);
+    L.add("d_pooled", Bn * D);
     L.add("d_state", Bn * H); L.add("d_state_s", Bn * H); L.add("d_hscratch", Bn * H);
     L.add("dxp", T * Bn * 3 * H); L.add("dx", T * Bn * W);
     L.add("d_wf", Bn * H); L.add("d_wfpre", Bn * H); L.add("d_ws", Bn * W); L.add("d_wse", Bn * W);
@@ -233,17 +233,30 @@ struct Acc {
     }
 };
 
-// backward of fc_ln_fwd: dy -> d_pre (named), parameter gradients accumulated, optional dx = d_pre * W^T
-int fc_ln_bwd(const Ctx& c, Acc& acc, const float* dy, const float* x, int64_t M, int64_t K, int64_t N, const vqa_pt_fc_t& p,
-              const vqa_pt_fc_t& g, int ln, int rows, int act, const std::string& pre, const std::string& mean,
-              const std::string& rstd, const uint8_t* keep, float keep_prob, const std::string& d_pre, float* dx) {
+// backward of the LayerNorm / activation half of fc_ln_fwd: dy -> d_pre (named); gamma, beta and bias gradients accumulated
+int ln_bwd(const Ctx& c, Acc& acc, const float* dy, int64_t M, int64_t N, const vqa_pt_fc_t& p, const vqa_pt_fc_t& g, int ln,
+           int rows, int act, const std::string& pre, const std::string& mean, const std::string& rstd, const uint8_t* keep,
+           float keep_prob, const std::string& d_pre) {
     const int64_t G = M / rows;
     TRY(vqa_ln_act_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma[ln], p.beta[ln], keep, keep_prob, c.f(d_pre),
                        c.f("part_a"), c.f("part_b"), c.f("part_c"), (int)G, rows, (int)N, act, c.st));
-    TRY(acc.colsum3(c.f("part_a"), c.f("part_b"), c.f("part_c"), G, N, g.gamma[ln], g.beta[ln], g.b));
+    return acc.colsum3(c.f("part_a"), c.f("part_b"), c.f("part_c"), G, N, g.gamma[ln], g.beta[ln], g.b);
+}
+
+// backward of the FC half: dW (+)= x^T d_pre, optional dx = d_pre * W^T
+int fc_bwd(const Ctx& c, Acc& acc, const std::string& d_pre, const float* x, int64_t M, int64_t K, int64_t N,
+           const vqa_pt_fc_t& p, const vqa_pt_fc_t& g, float* dx) {
     TRY(acc.weight(g.w, x, (int)K, c.f(d_pre), (int)N, K, N, M));
     if (dx != nullptr) TRY(c.gemm(0, 1, M, K, N, c.f(d_pre), (int)N, p.w, (int)N, dx, (int)K));
     return VQA_OK;
+}
+
+// backward of fc_ln_fwd
+int fc_ln_bwd(const Ctx& c, Acc& acc, const float* dy, const float* x, int64_t M, int64_t K, int64_t N, const vqa_pt_fc_t& p,
+              const vqa_pt_fc_t& g, int ln, int rows, int act, const std::string& pre, const std::string& mean,
+              const std::string& rstd, const uint8_t* keep, float keep_prob, const std::string& d_pre, float* dx) {
+    TRY(ln_bwd(c, acc, dy, M, N, p, g, ln, rows, act, pre, mean, rstd, keep, keep_prob, d_pre));
+    return fc_bwd(c, acc, d_pre, x, M, K, N, p, g, dx);
 }
 
 int gather_rows(const void* in, const int32_t* index, void* out, int64_t rows, int64_t cols, hipStream_t st) {
@@ -317,8 +330,13 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         auto head = [&](int t, const float* l_ft, const uint8_t* jmask) -> int {
             const std::string q = p + HEAD[t] + "/";
             const int ln = (t == 0) ? k : 2 + k;
-            TRY(fc_ln_fwd(c, c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, ln, (int)n, 0, q + "vl_pre", q + "vl",
-                          q + "vl_mean", q + "vl_rstd", nullptr, 1.f));
+            // pooled_linear_l: both heads of a kind apply the SAME FC to the same pooled features (only the LayerNorm
+            // parameters differ, modules.fc_layer's scope per head), so the product is computed once per kind
+            if (t == 0)
+                TRY(c.gemm(0, 0, Bn, H, D, c.f(p + "pooled"), (int)D, P->pooled_linear_l.w, (int)H, c.f(p + "vl_pre"), (int)H,
+                           P->pooled_linear_l.b));
+            TRY(vqa_ln_act_fwd(c.f(p + "vl_pre"), P->pooled_linear_l.gamma[ln], P->pooled_linear_l.beta[ln], nullptr, 1.f,
+                               c.f(q + "vl"), c.f(q + "vl_mean"), c.f(q + "vl_rstd"), (int)B, (int)n, (int)H, 0, c.st));
             TRY(fc_ln_fwd(c, l_ft, Bn, H, H, P->q_linear_l, ln, (int)n, 0, q + "ll_pre", q + "ll", q + "ll_mean",
                           q + "ll_rstd", nullptr, 1.f));
             TRY(vqa_mul(c.f(q + "vl"), c.f(q + "ll"), c.f(q + "jin"), Bn * H, c.st));
@@ -386,7 +404,6 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
     for (int k = 0; k < 2; ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         const std::string p = std::string(KIND[k]) + "/";
-        bool have_dpooled = false;
         auto head_bwd = [&](int t, const float* l_ft, const uint8_t* jmask, float* d_lft) -> int {
             const std::string q = p + HEAD[t] + "/";
             const int ln = (t == 0) ? k : 2 + k;
@@ -396,11 +413,14 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
             TRY(fc_ln_bwd(c, acc, c.f("d_j"), c.f(q + "jin"), Bn, H, 2 * H, P->joint_fc, G->joint_fc, ln, (int)n, 0,
                           q + "j_pre", q + "j_mean", q + "j_rstd", jmask, dims->keep_joint, "d_jpre", c.f("d_jin")));
             TRY(vqa_mul_bwd(c.f("d_jin"), c.f(q + "vl"), c.f(q + "ll"), c.f("d_vl"), c.f("d_ll"), Bn * H, c.st));
-            float* dpl = have_dpooled ? c.f("d_pl") : c.f("d_pooled");
-            TRY(fc_ln_bwd(c, acc, c.f("d_vl"), c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, G->pooled_linear_l, ln,
-                          (int)n, 0, q + "vl_pre", q + "vl_mean", q + "vl_rstd", nullptr, 1.f, "d_vlpre", dpl));
-            if (have_dpooled) TRY(vqa_add_inplace(c.f("d_pooled"), dpl, Bn * D, c.st));
-            have_dpooled = true;
+            // the shared product's gradient: the two heads' d_pre meet before ONE dW and ONE dx GEMM per kind
+            TRY(ln_bwd(c, acc, c.f("d_vl"), Bn, H, P->pooled_linear_l, G->pooled_linear_l, ln, (int)n, 0, p + "vl_pre",
+                       q + "vl_mean", q + "vl_rstd", nullptr, 1.f, t == 0 ? "d_vlpre0" : "d_vlpre"));
+            if (t == 1) {
+                TRY(vqa_add_inplace(c.f("d_vlpre"), c.f("d_vlpre0"), Bn * H, c.st));
+                TRY(fc_bwd(c, acc, "d_vlpre", c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, G->pooled_linear_l,
+                           c.f("d_pooled")));
+            }
             return fc_ln_bwd(c, acc, c.f("d_ll"), l_ft, Bn, H, H, P->q_linear_l, G->q_linear_l, ln, (int)n, 0, q + "ll_pre",
                              q + "ll_mean", q + "ll_rstd", nullptr, 1.f, "d_llpre", d_lft);
         };
