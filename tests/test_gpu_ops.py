@@ -379,13 +379,14 @@ def test_attention_fast_forward_equals_generic(B, rep, R, H, D, drop):
     assert np.all(a[np.broadcast_to(np.arange(R)[None, None, :] >= nbv[:, None, None], a.shape)] == 0)
 
 
+@pytest.mark.parametrize("G,rows,N", [(9, 36, 1024), (7, 5, 1024), (6, 5, 2048), (4, 8, 2048), (3, 2, 1024), (5, 7, 1024)])
 @pytest.mark.parametrize("drop", [False, True])
-def test_ln_register_resident_kernels_equal_generic(drop):
-    """Groups of 36 x 1024 (v_linear_v's block per sample) take the register-resident LN kernels; they compute what the
-    generic kernels do (same per-thread order; equal up to the compiler's fused multiply-adds)."""
+def test_ln_register_resident_kernels_equal_generic(drop, G, rows, N):
+    """Groups of 36 x 1024 (v_linear_v's block per sample) and of <= 8 rows x 1024 / 2048 (the pre-training model's 5 key
+    boxes per image) take the register-resident LN kernels; they compute what the generic kernels do (same per-thread
+    order; equal up to the compiler's fused multiply-adds)."""
     from vqa_transfer_externaldata_amd import _lib
     lib = _lib.load()
-    G, rows, N = 9, 36, 1024
     rng = np.random.default_rng(77)
     f = lambda a: dev(a.astype(np.float32))
     pre = f(rng.standard_normal((G * rows, N)) * 2 + 0.5)

@@ -32,6 +32,16 @@ SHAPES = [
     ("dWg_x", "tn", 300, 2048, 7168),
 ]
 
+if os.environ.get("TUNE_SET") == "pretrain":      # cfg-5 pre-training step: 2560 rows per category
+    SHAPES = [
+        ("pl_fwd", "nn", 2560, 1024, 2048), ("q_fwd", "nn", 2560, 1024, 1024), ("j_fwd", "nn", 2560, 2048, 1024),
+        ("cls_fwd", "nn", 2560, 4000, 2048), ("d_j", "nt", 2560, 2048, 4000), ("d_jin", "nt", 2560, 1024, 2048),
+        ("d_lft", "nt", 2560, 1024, 1024), ("d_pooled", "nt", 2560, 2048, 1024), ("xp_g", "nn", 25600, 2048, 300),
+        ("xp_c", "nn", 25600, 1024, 300), ("dx_g", "nt", 25600, 300, 2048), ("dWc", "tn", 2048, 4000, 2560),
+        ("dWj", "tn", 1024, 2048, 2560), ("dWq", "tn", 1024, 1024, 2560), ("dWpl", "tn", 2048, 1024, 2560),
+        ("dWg_x", "tn", 300, 2048, 25600), ("dWg_h", "tn", 1024, 2048, 25600),
+    ]
+
 
 CFGS = [int(x) for x in os.environ.get('TUNE_CFGS', '0,1,3,4,6,7,10,11,12,13').split(',')]
 

@@ -19,6 +19,7 @@
 // permutation, so every k is consumed exactly once.
 
 #include "vqa_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -987,8 +988,11 @@ int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st)
         case 9: return launch_one<32, 64, 32, 32, 2, 64, false, true, BKC, EPI>(a, ep, 1, st);
         case 10: return launch_one<64, 64, 32, 32, 1, 64, true, true, BKC, EPI>(a, ep, 1, st);
         case 11: return launch_one<64, 32, 32, 32, 2, 64, true, true, BKC, EPI>(a, ep, 1, st);
+        case 12: return launch_one<64, 64, 32, 32, 1, 32, true, true, BKC, EPI>(a, ep, 1, st);
         case 13: return launch_one<64, 32, 32, 32, 2, 32, true, true, BKC, EPI>(a, ep, 1, st);
         case 16: return launch_one<32, 32, 32, 32, 4, 32, true, true, BKC, EPI>(a, ep, 1, st);
+        case 20: return launch_one<128, 64, 32, 32, 1, 32, 0, true, BKC, EPI, false, false, 512>(a, ep, 1, st);
+        case 21: return launch_one<64, 128, 32, 32, 1, 32, 0, true, BKC, EPI, false, false, 512>(a, ep, 1, st);
         case 17: return launch_one<64, 32, 32, 32, 4, 32, 1, true, BKC, EPI, false, false, 512>(a, ep, 1, st);
         case 18:   // one 16-wave workgroup per CU: 64x64 tiles for the 2H-wide gate GEMM, 64x32 for the H-wide ones
             if (EPI == EPI_GATES) return launch_one<64, 64, 32, 32, 4, 64, 1, true, BKC, EPI, false, false, 1024>(a, ep, 1, st);
@@ -1015,7 +1019,8 @@ int g_conv_cfg_plain = -1;
 // vqa_gemm_set_gru_config(cfg) forces one config on both directions (tests, tuning); -1 = defaults.
 int g_gru_cfg = -1;
 // Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
-inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 10 : rows > 256 ? 18 : 16); }
+// (2560 rows, T 10: forward 1637 us with 64x64 BK 64, 1550 with BK 32 -- profiles/r2_gru_tune_b2560.txt)
+inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 12 : rows > 256 ? 18 : 16); }
 inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 256 ? 18 : 16); }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
@@ -1027,10 +1032,21 @@ inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 
 //  * batch-sized M (512) or narrow N: 64x32 tiles, in-block split-k and two tiles of register prefetch
 //    (one workgroup per CU cannot hide a global load behind a single tile's MFMAs) -- 8 waves / 4 k groups
 //    (512x1024x1024: 14.4 us against 16.0 with 4 waves / 2 k groups), 4 waves for the wide answer head.
+inline int tall_small_cfg() {      // VQA_HOT_TALL_SMALL_CFG: tuning override (-1 = keep the 128x64 tile)
+    static const int v = [] { const char* e = getenv("VQA_HOT_TALL_SMALL_CFG"); return e ? atoi(e) : 12; }();
+    return v < NUM_CFG ? v : 12;
+}
+
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
     if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
-    else if (M >= 2048) { cfg = (N >= 512) ? (K >= 2048 ? g_tall_cfg : 22) : 13; target = 256; }
+    else if (M >= 2048) {
+        cfg = (N >= 512) ? (K >= 2048 ? g_tall_cfg : 22) : 13;
+        target = 256;
+        // a few thousand rows only (the pre-training model's 2560 per category): fewer than four 128x64 tiles per CU
+        // leave a partial last round (320 tiles = 1.25 per CU), 64x64 tiles with two tiles of prefetch fill it
+        if (N >= 512 && cdiv(M, 128) * cdiv(N, 64) < 1024 && tall_small_cfg() >= 0) cfg = tall_small_cfg();
+    }
     else { cfg = (!tB && N > 2048) ? 13 : 23; target = 256; }
     if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
@@ -1074,7 +1090,8 @@ extern "C" int vqa_gemm_set_config(int cfg) {
 }
 
 extern "C" int vqa_gemm_set_gru_config(int cfg) {
-    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 11) || cfg == 13 || (cfg >= 16 && cfg <= 18), VQA_ERR_ARG);
+    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 13) || (cfg >= 16 && cfg <= 18) || cfg == 20 || cfg == 21,
+                VQA_ERR_ARG);
     g_gru_cfg = cfg;   // -1 restores the defaults
     return VQA_OK;
 }

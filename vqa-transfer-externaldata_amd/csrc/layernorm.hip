@@ -217,62 +217,82 @@ __global__ void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int REG_CUT = 256, REG_RY = 4;
 
-template <int RPT, bool MASK>
+// RPT rows and CPT float4 column units (cx, cx + 256) per thread; EXACT: rows == REG_RY * RPT, no clamp and no guard
+// (the 36-row kernel must not grow: 117 VGPRs in the backward); otherwise rows <= REG_RY * RPT, row indices are
+// clamped for the (unconditional) loads and rows past the group count for nothing.  Per-thread element order as in
+// the generic kernels: column units outer, rows inner.
+template <int RPT, int CPT, bool MASK, bool EXACT>
 __global__ __launch_bounds__(REG_CUT * REG_RY) void ln_fwd_reg_kernel(
     const float* __restrict__ pre, const float* __restrict__ gamma, const float* __restrict__ beta,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ y, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, int rows) {
-    constexpr int N4 = REG_CUT;
+    constexpr int N4 = REG_CUT * CPT;
     __shared__ float red[16];
     const int g = blockIdx.x, cx = threadIdx.x % REG_CUT, ry = threadIdx.x / REG_CUT;
     const int64_t base4 = (int64_t)g * rows * N4;
     const f32x4v* p4 = reinterpret_cast<const f32x4v*>(pre) + base4;
     const unsigned* m4 = MASK ? reinterpret_cast<const unsigned*>(keepmask) + base4 : nullptr;
     const float invL = 1.f / ((float)rows * (float)(N4 * 4));
-    f32x4v x[RPT];
-    unsigned km[RPT];
+    f32x4v x[CPT][RPT];
+    unsigned km[CPT][RPT];
+    bool ok[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int o = (ry + REG_RY * i) * N4 + cx;          // rows == REG_RY * RPT exactly: no clamp, no guard
-        x[i] = p4[o];
-        if (MASK) km[i] = m4[o];
-    }
+    for (int i = 0; i < RPT; ++i) ok[i] = EXACT || (ry + REG_RY * i < rows);
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = EXACT ? ry + REG_RY * i : min(ry + REG_RY * i, rows - 1);
+            const int o = r * N4 + cx + REG_CUT * c;
+            x[c][i] = p4[o];
+            if (MASK) km[c][i] = m4[o];
+        }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) { s += x[i].x; s += x[i].y; s += x[i].z; s += x[i].w; }
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            if (ok[i]) { s += x[c][i].x; s += x[c][i].y; s += x[c][i].z; s += x[c][i].w; }
     const float mean = block_sum(s, red) * invL;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
+    for (int c = 0; c < CPT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = x[i][j] - mean; q += d * d; }
-    }
+        for (int i = 0; i < RPT; ++i) {
+            if (!ok[i]) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = x[c][i][j] - mean; q += d * d; }
+        }
     const float var = block_sum(q, red) * invL;
     const float rstd = 1.f / sqrtf(var + LN_EPS);
     if (threadIdx.x == 0) { mean_out[g] = mean; rstd_out[g] = rstd; }
-    const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx], be = reinterpret_cast<const f32x4v*>(beta)[cx];
     f32x4v* y4 = reinterpret_cast<f32x4v*>(y) + base4;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        f32x4v o;
+    for (int c = 0; c < CPT; ++c) {
+        const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx + REG_CUT * c];
+        const f32x4v be = reinterpret_cast<const f32x4v*>(beta)[cx + REG_CUT * c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ln = (x[i][j] - mean) * rstd * ga[j] + be[j];
-            float v = fmaxf(ln, 0.f);                           // ReLU only (tanh layers use the generic kernel)
-            if (MASK) v = v * (float)((km[i] >> (8 * j)) & 0xFFu) * inv_keep;
-            o[j] = v;
+        for (int i = 0; i < RPT; ++i) {
+            f32x4v o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ln = (x[c][i][j] - mean) * rstd * ga[j] + be[j];
+                float v = fmaxf(ln, 0.f);                           // ReLU only (tanh layers use the generic kernel)
+                if (MASK) v = v * (float)((km[c][i] >> (8 * j)) & 0xFFu) * inv_keep;
+                o[j] = v;
+            }
+            if (ok[i]) y4[(ry + REG_RY * i) * N4 + cx + REG_CUT * c] = o;
         }
-        y4[(ry + REG_RY * i) * N4 + cx] = o;
     }
 }
 
-template <int RPT, bool MASK>
+template <int RPT, int CPT, bool MASK, bool EXACT>
 __global__ __launch_bounds__(REG_CUT * REG_RY) void ln_bwd_reg_kernel(
     const float* __restrict__ dy, const float* __restrict__ pre, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, const float* __restrict__ beta,
     const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dpre, float* __restrict__ part_dgamma,
     float* __restrict__ part_dbeta, float* __restrict__ part_dbias, int rows) {
-    constexpr int N4 = REG_CUT, N = N4 * 4;
+    constexpr int N4 = REG_CUT * CPT, N = N4 * 4;
     extern __shared__ __attribute__((aligned(16))) float dyn[];  // [2][RY*CUt*4]
     __shared__ float red[16];
     const int g = blockIdx.x, cx = threadIdx.x % REG_CUT, ry = threadIdx.x / REG_CUT;
@@ -284,60 +304,81 @@ __global__ __launch_bounds__(REG_CUT * REG_RY) void ln_bwd_reg_kernel(
     const float mean = mean_in[g], rstd = rstd_in[g];
     float* buf0 = dyn;
     float* buf1 = dyn + (size_t)REG_RY * REG_CUT * 4;
-    f32x4v x[RPT], d[RPT];
-    unsigned km[RPT];
+    f32x4v x[CPT][RPT], d[CPT][RPT];
+    unsigned km[CPT][RPT];
+    bool ok[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const int o = (ry + REG_RY * i) * N4 + cx;
-        x[i] = p4[o];
-        d[i] = d4[o];
-        if (MASK) km[i] = m4[o];
-    }
-    const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx], be = reinterpret_cast<const f32x4v*>(beta)[cx];
-    float s1 = 0.f, s2 = 0.f;
-    float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
-    // pass 1 (registers only): d[i] is overwritten by dxh = dln * gamma, x[i] by xhat
+    for (int i = 0; i < RPT; ++i) ok[i] = EXACT || (ry + REG_RY * i < rows);
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
+    for (int c = 0; c < CPT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xh = (x[i][j] - mean) * rstd;
-            const float ln = xh * ga[j] + be[j];
-            float gg = d[i][j];
-            if (MASK) gg = gg * (float)((km[i] >> (8 * j)) & 0xFFu) * inv_keep;
-            const float dln = ln > 0.f ? gg : 0.f;                    // ReLU only (tanh layers use the generic kernel)
-            const float dxh = dln * ga[j];
-            s1 += dxh; s2 += dxh * xh; cb[j] += dln; cg[j] += dln * xh;
-            x[i][j] = xh;
-            d[i][j] = dxh;
+        for (int i = 0; i < RPT; ++i) {
+            const int r = EXACT ? ry + REG_RY * i : min(ry + REG_RY * i, rows - 1);
+            const int o = r * N4 + cx + REG_CUT * c;
+            x[c][i] = p4[o];
+            d[c][i] = d4[o];
+            if (MASK) km[c][i] = m4[o];
         }
-    }
-    if (part_dgamma != nullptr) {
-        col_reduce_store<4>(buf0, cb, part_dbeta + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
-        col_reduce_store<4>(buf1, cg, part_dgamma + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
+    float s1 = 0.f, s2 = 0.f;
+    // pass 1 (registers only): d is overwritten by dxh = dln * gamma, x by xhat
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const f32x4v ga = reinterpret_cast<const f32x4v*>(gamma)[cx + REG_CUT * c];
+        const f32x4v be = reinterpret_cast<const f32x4v*>(beta)[cx + REG_CUT * c];
+        float cb[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (x[c][i][j] - mean) * rstd;
+                const float ln = xh * ga[j] + be[j];
+                float gg = ok[i] ? d[c][i][j] : 0.f;
+                if (MASK) gg = gg * (float)((km[c][i] >> (8 * j)) & 0xFFu) * inv_keep;
+                const float dln = ln > 0.f ? gg : 0.f;                    // ReLU only (tanh layers use the generic kernel)
+                const float dxh = dln * ga[j];
+                s1 += dxh; s2 += dxh * xh; cb[j] += dln; cg[j] += dln * xh;
+                x[c][i][j] = xh;
+                d[c][i][j] = dxh;
+            }
+        }
+        if (part_dgamma != nullptr) {
+            col_reduce_store<4>(buf0, cb, part_dbeta + (int64_t)g * N, cx + REG_CUT * c, N4, cx, ry, REG_CUT, REG_RY);
+            col_reduce_store<4>(buf1, cg, part_dgamma + (int64_t)g * N, cx + REG_CUT * c, N4, cx, ry, REG_CUT, REG_RY);
+        }
     }
     const float m1 = block_sum(s1, red) * invL;
     const float m2 = block_sum(s2, red) * invL;
-    float cbias[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4v* o4 = reinterpret_cast<f32x4v*>(dpre) + base4;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        f32x4v o;
+    for (int c = 0; c < CPT; ++c) {
+        float cbias[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float dp = rstd * (d[i][j] - m1 - x[i][j] * m2);
-            o[j] = dp;
-            cbias[j] += dp;
+        for (int i = 0; i < RPT; ++i) {
+            f32x4v o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dp = rstd * (d[c][i][j] - m1 - x[c][i][j] * m2);
+                o[j] = dp;
+                cbias[j] += ok[i] ? dp : 0.f;
+            }
+            if (ok[i]) o4[(ry + REG_RY * i) * N4 + cx + REG_CUT * c] = o;
         }
-        o4[(ry + REG_RY * i) * N4 + cx] = o;
+        if (part_dbias != nullptr)
+            col_reduce_store<4>(buf0, cbias, part_dbias + (int64_t)g * N, cx + REG_CUT * c, N4, cx, ry, REG_CUT, REG_RY);
     }
-    if (part_dbias != nullptr) col_reduce_store<4>(buf0, cbias, part_dbias + (int64_t)g * N, cx, N4, cx, ry, REG_CUT, REG_RY);
 }
 
 int g_ln_reg = 1;   // A/B switch (vqa_ln_set_fast)
 
-// register-resident kernels apply: 16-byte path, N == 1024, rows == 36 (= REG_RY * 9: v_linear_v's block per sample)
-inline bool reg_ok(int U, int rows, int N) { return g_ln_reg && U == 4 && N == REG_CUT * 4 && rows == REG_RY * 9; }
+// register-resident kernels apply (16-byte path, ReLU): 1 = N 1024, rows == 36 (v_linear_v's block per sample);
+// 2 = N 1024, rows <= 8; 3 = N 2048, rows <= 8 (the pre-training model's groups of 5 key boxes per image)
+inline int reg_mode(int U, int rows, int N) {
+    if (!g_ln_reg || U != 4) return 0;
+    if (N == REG_CUT * 4 && rows == REG_RY * 9) return 1;
+    if (N == REG_CUT * 4 && rows >= 2 && rows <= REG_RY * 2) return 2;
+    if (N == REG_CUT * 8 && rows >= 2 && rows <= REG_RY * 2) return 3;
+    return 0;
+}
 
 struct Shape { int U, CUt, RY, threads; };
 Shape pick(const void* a, const void* b, const void* c, int rows, int N, bool mask) {
@@ -381,13 +422,19 @@ extern "C" int vqa_ln_act_fwd(const float* pre, const float* gamma, const float*
     s.threads = s.CUt * s.RY;
     const float inv_keep = keepmask ? 1.f / keep_prob : 1.f;
     hipStream_t st = (hipStream_t)stream;
-    if (reg_ok(s.U, rows, N) && act == 0) {
-        if (keepmask != nullptr)
-            hipLaunchKernelGGL((ln_fwd_reg_kernel<9, true>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre, gamma, beta, keepmask,
-                               inv_keep, y, mean, rstd, rows);
-        else
-            hipLaunchKernelGGL((ln_fwd_reg_kernel<9, false>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre, gamma, beta, keepmask,
-                               inv_keep, y, mean, rstd, rows);
+    const int rm = act == 0 ? reg_mode(s.U, rows, N) : 0;
+    if (rm != 0) {
+#define VQA_LN_FWD_REG(rpt, cpt, exact)                                                                                    \
+    do {                                                                                                                 \
+        if (keepmask != nullptr)                                                                                         \
+            hipLaunchKernelGGL((ln_fwd_reg_kernel<rpt, cpt, true, exact>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre,    \
+                               gamma, beta, keepmask, inv_keep, y, mean, rstd, rows);                                    \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ln_fwd_reg_kernel<rpt, cpt, false, exact>), dim3(G), dim3(REG_CUT * REG_RY), 0, st, pre,   \
+                               gamma, beta, keepmask, inv_keep, y, mean, rstd, rows);                                    \
+    } while (0)
+        if (rm == 1) VQA_LN_FWD_REG(9, 1, true); else if (rm == 2) VQA_LN_FWD_REG(2, 1, false); else VQA_LN_FWD_REG(2, 2, false);
+#undef VQA_LN_FWD_REG
     } else if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_fwd_kernel<4>, dim3(G), dim3(s.threads), 0, st, pre, gamma, beta, keepmask, inv_keep,
                            y, mean, rstd, rows, N, s.CUt, s.RY, act);
@@ -425,14 +472,22 @@ extern "C" int vqa_ln_act_bwd(const float* dy, const float* pre, const float* me
     const float inv_keep = keepmask ? 1.f / keep_prob : 1.f;
     const size_t dyn = s.RY > 1 ? (size_t)2 * s.RY * s.CUt * s.U * sizeof(float) : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (reg_ok(s.U, rows, N) && act == 0) {
+    const int rm = act == 0 ? reg_mode(s.U, rows, N) : 0;
+    if (rm != 0) {
         const size_t dyn_reg = (size_t)2 * REG_RY * REG_CUT * 4 * sizeof(float);
-        if (keepmask != nullptr)
-            hipLaunchKernelGGL((ln_bwd_reg_kernel<9, true>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st, dy, pre, mean, rstd,
-                               gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows);
-        else
-            hipLaunchKernelGGL((ln_bwd_reg_kernel<9, false>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st, dy, pre, mean, rstd,
-                               gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows);
+#define VQA_LN_BWD_REG(rpt, cpt, exact)                                                                                    \
+    do {                                                                                                                 \
+        if (keepmask != nullptr)                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_reg_kernel<rpt, cpt, true, exact>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st,   \
+                               dy, pre, mean, rstd, gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta,      \
+                               part_dbias, rows);                                                                        \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ln_bwd_reg_kernel<rpt, cpt, false, exact>), dim3(G), dim3(REG_CUT * REG_RY), dyn_reg, st,  \
+                               dy, pre, mean, rstd, gamma, beta, keepmask, inv_keep, dpre, part_dgamma, part_dbeta,      \
+                               part_dbias, rows);                                                                        \
+    } while (0)
+        if (rm == 1) VQA_LN_BWD_REG(9, 1, true); else if (rm == 2) VQA_LN_BWD_REG(2, 1, false); else VQA_LN_BWD_REG(2, 2, false);
+#undef VQA_LN_BWD_REG
     } else if (s.U == 4)
         hipLaunchKernelGGL(ln_relu_bwd_kernel<4>, dim3(G), dim3(s.threads), dyn, st, dy, pre, mean, rstd, gamma, beta,
                            keepmask, inv_keep, dpre, part_dgamma, part_dbeta, part_dbias, rows, N, s.CUt, s.RY, act);
