@@ -379,6 +379,36 @@ def test_attention_fast_forward_equals_generic(B, rep, R, H, D, drop):
     assert np.all(a[np.broadcast_to(np.arange(R)[None, None, :] >= nbv[:, None, None], a.shape)] == 0)
 
 
+@pytest.mark.parametrize("B,rep,R", [(5, 1, 36), (3, 5, 36), (2, 5, 17), (3, 1, 40), (2, 5, 1), (2, 1, 9)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_attention_fast_backward_equals_generic(B, rep, R, drop):
+    """The loads-in-flight backward kernel (H 1024, D 2048, 1 or 5 queries per memory) against the generic one: same
+    per-lane summation order, equal up to the compiler's fused multiply-adds."""
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    H, D = 1024, 2048
+    rng = np.random.default_rng(100 + B + rep + R)
+    f = lambda a: dev(a.astype(np.float32))
+    v, qv = f(np.maximum(rng.standard_normal((B, R, H)), 0)), f(np.maximum(rng.standard_normal((B * rep, H)), 0))
+    V = f(np.maximum(rng.standard_normal((B, R, D)), 0))
+    w, bias = f(rng.standard_normal(H) * 0.1), f(np.array([0.2]))
+    nbv = rng.integers(1, R + 1, size=B).astype(np.int32); nbv[0] = R
+    km = dev((rng.random((B * rep, R, H)) < 0.8).astype(np.uint8)) if drop else None
+    dp = f(rng.standard_normal((B * rep, D)))
+    att, _ = ops.attn_pool_fwd_rep(v, qv, V, dev(nbv), w, bias, rep, km, 0.8)
+    res = []
+    try:
+        for fast in (0, 1):
+            lib.vqa_attn_set_fast(fast)
+            res.append(ops.attn_pool_bwd_rep(dp, v, qv, V, att, w, rep, km, 0.8))
+    finally:
+        lib.vqa_attn_set_fast(1)
+    for a, b, name in zip(res[0], res[1], ("dv", "dqv", "dw")):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6 * float(a.abs().max()) + 1e-9, msg=lambda m: name + ": " + m)
+    # the score bias gradient is analytically zero (a softmax gradient sums to zero): rounding noise on both sides
+    assert float(res[0][3].abs().max()) < 1e-3 and float(res[1][3].abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("G,rows,N", [(9, 36, 1024), (7, 5, 1024), (6, 5, 2048), (4, 8, 2048), (3, 2, 1024), (5, 7, 1024)])
 @pytest.mark.parametrize("drop", [False, True])
 def test_ln_register_resident_kernels_equal_generic(drop, G, rows, N):

@@ -482,6 +482,143 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_pool_bwd_kernel(
     }
 }
 
+// The same backward for the models' shapes (D == 2048, H == 1024, R <= 40; 1 or 5 queries per memory), restructured around loads in
+// flight like the forward: the generic kernel walks its queries one after the other (load dpooled[q], then one V row
+// per wave at a time: REP x ~6 dependent memory latencies with two workgroups per CU), and its last phase keeps two
+// rows per thread in flight.  Here dpooled of ALL queries of the memory sits in LDS, a wave reads each of its V rows
+// ONCE (two rows in flight) and scores it against the REP queries, the REP softmax backwards run in REP waves, and
+// the dv phase keeps four rows (+ their REP mask words) per thread in flight.  Same per-lane summation order.
+template <int REP, bool MASK>
+__global__ __launch_bounds__(BWD_THREADS) void attn_pool_bwd_fast_kernel(
+    const float* __restrict__ dpooled, const float* __restrict__ v, const float* __restrict__ qv,
+    const float* __restrict__ V, const float* __restrict__ att, const float* __restrict__ w,
+    const uint8_t* __restrict__ keepmask, float inv_keep, float* __restrict__ dv, float* __restrict__ dqv,
+    float* __restrict__ part_dw, float* __restrict__ part_db, int R, int H) {
+    constexpr int D = 2048, D4 = D / 4, DL = D4 / 64, NW = BWD_THREADS / 64, RB = 4;
+    static_assert(REP <= NW, "one softmax wave per query");
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // dp[REP][D] | ds[REP][40] | comb[REP][H]
+    float* ds = lds + REP * D;
+    float* comb = ds + REP * 40;
+    const int mem = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q0 = (int64_t)mem * REP;
+    f32x4v* dp4 = reinterpret_cast<f32x4v*>(lds);
+    {
+        const f32x4v* g4 = reinterpret_cast<const f32x4v*>(dpooled + q0 * D);
+        f32x4v t[REP];
+#pragma unroll
+        for (int j = 0; j < REP; ++j) t[j] = g4[j * D4 + threadIdx.x];       // D4 == BWD_THREADS
+#pragma unroll
+        for (int j = 0; j < REP; ++j) dp4[j * D4 + threadIdx.x] = t[j];
+    }
+    __syncthreads();
+    // datt[j][r] = <dpooled[q0 + j], V[mem, r]>
+    const f32x4v* Vb4 = reinterpret_cast<const f32x4v*>(V + (int64_t)mem * R * D);
+    for (int r0 = wave; r0 < R; r0 += 2 * NW) {
+        const int rb = min(r0 + NW, R - 1);
+        const bool okb = r0 + NW < R;
+        f32x4v xa[DL], xb[DL];
+#pragma unroll
+        for (int k = 0; k < DL; ++k) {
+            xa[k] = Vb4[(int64_t)r0 * D4 + lane + 64 * k];
+            xb[k] = Vb4[(int64_t)rb * D4 + lane + 64 * k];
+        }
+#pragma unroll
+        for (int j = 0; j < REP; ++j) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < DL; ++k) {
+                const f32x4v g = dp4[j * D4 + lane + 64 * k];
+                a += xa[k].x * g.x + xa[k].y * g.y + xa[k].z * g.z + xa[k].w * g.w;
+                b += xb[k].x * g.x + xb[k].y * g.y + xb[k].z * g.z + xb[k].w * g.w;
+            }
+            a = wave_sum(a);
+            b = wave_sum(b);
+            if (lane == 0) {
+                ds[j * 40 + r0] = a;
+                if (okb) ds[j * 40 + rb] = b;
+            }
+        }
+    }
+    __syncthreads();
+    // softmax backward: ds = att * (datt - sum(att*datt)); R <= 40 < 64: one lane per region
+    if (wave < REP) {
+        const int64_t q = q0 + wave;
+        const float a = lane < R ? att[q * R + lane] : 0.f;
+        const float d = lane < R ? ds[wave * 40 + lane] : 0.f;
+        const float dot = wave_sum(a * d);
+        const float g = a * (d - dot);
+        if (lane < R) ds[wave * 40 + lane] = g;
+        const float tot = wave_sum(g);
+        if (lane == 0) part_db[q] = tot;
+    }
+    __syncthreads();
+
+    const int H4 = H / 4;
+    const int half = threadIdx.x / (BWD_THREADS / 2), tcol = threadIdx.x % (BWD_THREADS / 2);
+    const f32x4v* vb4 = reinterpret_cast<const f32x4v*>(v + (int64_t)mem * R * H);
+    const unsigned* mk4 = MASK ? reinterpret_cast<const unsigned*>(keepmask + q0 * R * H) : nullptr;
+    f32x4v* dv4 = reinterpret_cast<f32x4v*>(dv + (int64_t)mem * R * H);
+    for (int hu0 = 0; hu0 < H4; hu0 += BWD_THREADS / 2) {       // H == 1024: one pass, every thread has a column
+        const int hu = hu0 + tcol;
+        const f32x4v ww = reinterpret_cast<const f32x4v*>(w)[hu];
+        f32x4v qj[REP], S[REP];
+#pragma unroll
+        for (int j = 0; j < REP; ++j) {
+            S[j] = (f32x4v)(0.f);
+            qj[j] = reinterpret_cast<const f32x4v*>(qv + (q0 + j) * H)[hu];
+        }
+        for (int rb = half; rb < R; rb += 2 * RB) {
+            f32x4v x[RB];
+            unsigned m[RB][REP];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int r = min(rb + 2 * i, R - 1);
+                x[i] = vb4[(int64_t)r * H4 + hu];
+                if (MASK) {
+#pragma unroll
+                    for (int j = 0; j < REP; ++j) m[i][j] = mk4[((int64_t)j * R + r) * H4 + hu];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int r = rb + 2 * i;
+                if (r >= R) break;                                      // workgroup-uniform per half; no barrier inside
+                f32x4v acc = (f32x4v)(0.f);
+#pragma unroll
+                for (int j = 0; j < REP; ++j) {
+                    const float d = ds[j * 40 + r];
+                    f32x4v g = (f32x4v)(d);
+                    if (MASK) {
+                        const unsigned mm = m[i][j];
+                        g.x *= (float)(mm & 0xFFu) * inv_keep; g.y *= (float)((mm >> 8) & 0xFFu) * inv_keep;
+                        g.z *= (float)((mm >> 16) & 0xFFu) * inv_keep; g.w *= (float)(mm >> 24) * inv_keep;
+                    }
+                    S[j].x += g.x * x[i].x; S[j].y += g.y * x[i].y; S[j].z += g.z * x[i].z; S[j].w += g.w * x[i].w;
+                    acc.x += g.x * qj[j].x * ww.x; acc.y += g.y * qj[j].y * ww.y;
+                    acc.z += g.z * qj[j].z * ww.z; acc.w += g.w * qj[j].w * ww.w;
+                }
+                dv4[(int64_t)r * H4 + hu] = acc;
+            }
+        }
+        // odd-row partial sums -> LDS, the even-row thread of the same column finishes (fixed order)
+        __syncthreads();
+        if (half == 1) {
+#pragma unroll
+            for (int j = 0; j < REP; ++j) reinterpret_cast<f32x4v*>(comb + (size_t)j * H)[hu] = S[j];
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < REP; ++j) {
+                const f32x4v o = reinterpret_cast<const f32x4v*>(comb + (size_t)j * H)[hu];
+                const f32x4v t = S[j] + o;
+                reinterpret_cast<f32x4v*>(dqv + (q0 + j) * H)[hu] = t * ww;
+                reinterpret_cast<f32x4v*>(part_dw + (q0 + j) * H)[hu] = t * qj[j];
+            }
+        }
+    }
+}
+
 int g_attn_fast = 1;   // tuning / A-B switch (vqa_attn_set_fast)
 
 }  // namespace
@@ -588,6 +725,17 @@ extern "C" int vqa_attn_pool_bwd_rep(const float* dpooled, const float* v, const
     hipStream_t st = (hipStream_t)stream;
     auto lds_for = [&](int REPt) { return (size_t)(D + ((REPt * R + 3) / 4) * 4 + REPt * H) * sizeof(float); };
     VQA_REQUIRE(lds_for(rep == 1 ? 1 : rep <= 5 ? 5 : 8) <= 64 * 1024, VQA_ERR_UNSUPPORTED);
+    if (g_attn_fast && (rep == 1 || rep == 5) && D == 2048 && H == 1024 && R <= 40 && vqa_aligned16(dpooled)) {
+        const size_t l = (size_t)(rep * D + rep * 40 + rep * H) * sizeof(float);
+#define VQA_ATTN_BWD_FAST(r, mk)                                                                                       \
+    hipLaunchKernelGGL((attn_pool_bwd_fast_kernel<r, mk>), dim3(B), dim3(BWD_THREADS), l, st, dpooled, v, qv, V, att, w, \
+                       keepmask, ik, dv, dqv, part_dw, part_db, R, H)
+        if (rep == 1) { if (keepmask) VQA_ATTN_BWD_FAST(1, true); else VQA_ATTN_BWD_FAST(1, false); }
+        else { if (keepmask) VQA_ATTN_BWD_FAST(5, true); else VQA_ATTN_BWD_FAST(5, false); }
+#undef VQA_ATTN_BWD_FAST
+        VQA_CHECK_LAUNCH();
+        return VQA_OK;
+    }
     if (rep == 1)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(B), dim3(BWD_THREADS), lds_for(1), st, dpooled, v, qv, V, att, w,
                            keepmask, ik, dv, dqv, part_dw, part_db, R, H, D, rep);
