@@ -85,6 +85,27 @@ if os.environ.get("PERSIST") == "1":
         print("  forward: stepwise %.1f us   persistent %.1f us" % (tm(fwd), tm(fwd_persistent)), flush=True)
     sys.exit(0)
 
+if os.environ.get("GRAPH") == "1":
+    # does replaying the 28-kernel chain from a captured graph shorten the gaps between its dependent kernels?
+    def on_stream(fn_name, args):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(getattr(lib, fn_name)(*args, st), fn_name)
+    fa = (P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H)
+    ba = (P(dhT), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(dxp), P(dhs), T, B, H)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        on_stream("vqa_gru_seq_fwd", fa); on_stream("vqa_gru_seq_bwd", ba)
+    torch.cuda.synchronize()
+    gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gf, stream=side):
+        on_stream("vqa_gru_seq_fwd", fa)
+    with torch.cuda.graph(gb, stream=side):
+        on_stream("vqa_gru_seq_bwd", ba)
+    for rep in range(3):
+        print("forward: launches %.1f us  graph replay %.1f us | backward: launches %.1f us  graph replay %.1f us" % (
+            tm(fwd), tm(gf.replay), tm(lambda: _lib.check(lib.vqa_gru_seq_bwd(*ba, None), "bwd")), tm(gb.replay)), flush=True)
+    sys.exit(0)
+
 cfgs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "11,16,17,18").split(",")]
 best = {k: [1e9, 1e9] for k in cfgs}
 ref = None
