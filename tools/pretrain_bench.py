@@ -7,6 +7,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("VQA_HOT_LIB"):      # A/B of two builds of the library on one box (tuning only)
+    from vqa_transfer_externaldata_amd import _lib as _l0
+    _l0._LIB_PATH = os.environ["VQA_HOT_LIB"]
 from vqa_transfer_externaldata_amd import pretrain as PT  # noqa: E402
 
 B, n, R, D, H, L, W, Vq, n_ws, A = 512, 5, 36, 2048, 1024, 10, 300, 5000, 2000, 4000

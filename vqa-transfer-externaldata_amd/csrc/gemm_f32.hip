@@ -282,7 +282,11 @@ __device__ __forceinline__ float4 frag4(const float* s, int r0, int c, int lane)
 
 template <int BM, int BN, int WM, int WN, int WGK, int BK, int DEEP, bool A_KC, bool B_KC, int EPI, bool CONV = false,
           bool EDGE = false, int NT = 256, bool GATHER = false>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
+// (the 4-wave implicit-GEMM form lands on 113 + 16 registers, one allocation granule above four waves per SIMD: ask for
+// four, i.e. four co-resident workgroups per CU instead of three -- the compiler gets there without spilling, and the
+// extractor gains 1.5 %.  The same request for the 64x64 two-tile-prefetch form (121 + 16) measured 0.5 % SLOWER
+// on the pre-training step, same box, two builds: left alone.)
+__global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kernel(GemmArgs p, EpiArgs ep) {
     static_assert(!GATHER || (A_KC && DEEP == 0 && !CONV && !EDGE && EPI == EPI_PLAIN), "row-gathered A: plain NN/NT tiles");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
@@ -1392,9 +1396,10 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
         if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
         return launch_by_id(cfg, 0, 0, a, 1, st, 0);
     }
-    // 3x3: 128x64 tiles of 8 waves for the stride-1 layers up to 256 channels (256 @28x28: 1014 -> 938 us), the
-    // 64x64 / 4-wave tile for the deep narrow-M layers and the strided ones (profiles/r2_conv_tune.txt)
-    const int ccfg = g_conv_cfg >= 0 ? g_conv_cfg : (((stride == 1 && Ci <= 256) || Ci <= 64) && Ci >= 32 ? 1 : 0);
+    // 64x64 / 4-wave tiles for every implicit-GEMM layer: at four workgroups per CU (see the kernel's launch bounds)
+    // they beat the 8-wave 128x64 and 64x128 tiles in the network (profiles/r2_conv_cfg_ab.txt); in isolation on
+    // uniform random inputs the 128x64 tile wins the stride-1 layers (profiles/r2_conv_tune.txt) -- not in situ
+    const int ccfg = g_conv_cfg >= 0 ? g_conv_cfg : 0;
     // one 32-deep k tile per filter tap, or 4-channel pixels with a K that is a whole number of tiles (conv1)
     VQA_REQUIRE((Ci % 32 == 0 || (Ci == 4 && K % 32 == 0)) && vqa_aligned16(x), VQA_ERR_ALIGN);
     a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.cstride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
@@ -1405,8 +1410,6 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     a.a_bytes = (unsigned)xb;
     a.b_bytes = (unsigned)wb;
     const EpiArgs ep{};
-    // 64x64 tiles also for wide layers: more workgroups per launch beat the 64x128 tile's operand reuse
-    // (ResNet-101 @448, batch 64: 1737 -> 1803 images/s)
     switch (ccfg) {
         case 1: return launch_one<128, 64, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, true, false, 512>(a, ep, 1, st, 0);
         case 2: return launch_one<64, 128, 32, 32, 1, 32, 0, true, false, EPI_PLAIN, true, false, 512>(a, ep, 1, st, 0);
