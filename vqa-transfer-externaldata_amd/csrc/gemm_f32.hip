@@ -1384,13 +1384,14 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     a.scale = scale;
     a.relu = relu;
     if (plain) {
-        // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M.  The expansions
-        // (Co >= 2 Ci: k loop of 2..16 tiles, then an epilogue that reads the residual and writes 4x the input)
-        // amortise that epilogue better on 128x128 tiles of 8 waves once there are enough of them
-        // (tools/conv_tune.py, profiles/r2_conv_tune.txt: 256 -> 1024 @28x28: 477 -> 465 us, 64 -> 256 @112x112:
-        // 894 -> 814 us); the 256 -> 64 reduction at 112x112 likes 128x64.
+        // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M.  The block-1/2 expansions
+        // (64 -> 256, 128 -> 512: a k loop of 2..4 tiles, then an epilogue that reads the residual and writes 4x the
+        // input) amortise that epilogue better on 128x128 tiles of 8 waves: in the network 809 -> 738 us and
+        // 689 -> 658 us per launch; from 256 input channels on the 64x64 tile is faster again (456 against 467 us,
+        // 412 against 442: profiles/r2_vfeat_trace_summary.txt and its history).  The 256 -> 64 reduction at 112x112
+        // likes 128x64.
         int cfg = 3;
-        if (Co >= 256 && Co >= 2 * Ci && (int64_t)M * Co >= (1ll << 25)) cfg = 16;
+        if (Ci <= 128 && Co >= 256 && Co >= 2 * Ci && (int64_t)M * Co >= (1ll << 25)) cfg = 16;
         else if (Co <= 64 && Ci >= 256) cfg = 20;
         if (g_conv_cfg_plain >= 0) cfg = g_conv_cfg_plain;
         if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
