@@ -7,6 +7,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("VQA_HOT_LIB"):      # another build of the library (same-box A/B of compile-time choices)
+    from vqa_transfer_externaldata_amd import _lib as _l0
+    _l0._LIB_PATH = os.path.abspath(os.environ["VQA_HOT_LIB"])
 from vqa_transfer_externaldata_amd import vfeat as VF  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -21,6 +21,10 @@
 #include "vqa_common.h"
 #include <cstdlib>
 
+#ifndef VQA_GEMM_STAGGER
+#define VQA_GEMM_STAGGER 1      // 0: build without the SIMD-partner stagger of the 8-wave kernels (A/B builds)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -523,7 +527,74 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
             const unsigned stepB = (unsigned)(B_KC ? BK : BK * p.ldb) * 4u;
             const int nfull = (kend - kbeg) / BK;
             unsigned oa = stepA, ob = stepB;   // scalar byte offsets of tile t + 1
-            for (; t + 2 < nfull; t += 2) {
+            // Stagger (8-wave workgroups: waves w and w + 4 share a SIMD and, running the same program with one
+            // barrier per k tile, reach their MFMA burst, their LDS traffic and the barrier together).  Inside one
+            // barrier interval "compute tile t from one LDS buffer" and "store tile t+1 into the other" commute, so
+            // waves 4..7 run the interval as store(t+1) -> fetch(t+2) -> compute(t) while waves 0..3 keep
+            // fetch(t+1) -> compute(t) -> store(t+1): a SIMD's two waves of this workgroup alternate between the
+            // MFMA burst and the LDS/global phase instead of colliding in both.  Same barrier count on both paths;
+            // one entry fetch and one transition interval bring waves 4..7 in and out of the half-interval lead.
+            // Compiled in only where it pays and costs no occupancy: the 128x64 / 64x128 tiles of 32x32 waves with BK 32
+            // (95 -> 99 registers, still two workgroups per CU) and the 128x128 BK-16 weight-gradient tile; in the
+            // 128x128 BK-32 kernel the second loop body costs 6 registers and with them its second workgroup per CU
+            // (124 -> 130: the extractor's 1x1 layers lost 1.3 % until this was fenced off).
+            constexpr bool STAG = (NT == 512) && !GATHER && EPI == EPI_PLAIN && (VQA_GEMM_STAGGER != 0) &&
+                                  ((WM == 32 && WN == 32 && BK == 32 && BM + BN == 192) || (BM == 128 && BN == 128 && BK == 16));
+            // Long k loops only: on the roofline GEMM (64 tiles) the k loop gets 2 % shorter (552 -> 541 us, same
+            // box, two builds); on the extractor's short-k 1x1 layers (4..8 tiles) the entry fetch and the transition
+            // interval cost more than the stagger returns (2064 -> 2043 imgs/s).  profiles/r2_stagger_ab.txt
+            const bool stag_wg = STAG && nfull >= 16;                 // workgroup-uniform
+            if (stag_wg && wave >= 4) {
+                sa.load_full(rsA, oa); sb.load_full(rsB, ob);         // tile 1 into the staging registers
+                oa += stepA; ob += stepB;
+                for (; t + 3 < nfull; t += 2) {
+                    sa.store(L1); sb.store(L1 + A_FL);                // tile t + 1
+                    sa.load_full(rsA, oa); sb.load_full(rsB, ob);     // tile t + 2
+                    oa += stepA; ob += stepB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_tile(L0, L0 + A_FL);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                    sa.store(L0); sb.store(L0 + A_FL);                // tile t + 2
+                    sa.load_full(rsA, oa); sb.load_full(rsB, ob);     // tile t + 3
+                    oa += stepA; ob += stepB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_tile(L1, L1 + A_FL);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                }
+                sa.store(L1); sb.store(L1 + A_FL);                    // transition: tile t + 1 (< nfull) is in the registers
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                ++t;
+            } else if (stag_wg) {
+                for (; t + 3 < nfull; t += 2) {                       // the same trip count as the waves above
+                    sa.load_full(rsA, oa); sb.load_full(rsB, ob);
+                    oa += stepA; ob += stepB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_tile(L0, L0 + A_FL);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sa.store(L1); sb.store(L1 + A_FL);
+                    __syncthreads();
+                    sa.load_full(rsA, oa); sb.load_full(rsB, ob);
+                    oa += stepA; ob += stepB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_tile(L1, L1 + A_FL);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sa.store(L0); sb.store(L0 + A_FL);
+                    __syncthreads();
+                }
+                sa.load_full(rsA, oa); sb.load_full(rsB, ob);         // transition interval
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                sa.store(L1); sb.store(L1 + A_FL);
+                __syncthreads();
+                ++t;
+            }
+            for (; !stag_wg && t + 2 < nfull; t += 2) {
                 if (GATHER) sa.load_ptr(gsrc, (t + 1) * BK); else sa.load_full(rsA, oa);
                 sb.load_full(rsB, ob);
                 oa += stepA; ob += stepB;
@@ -599,6 +670,10 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
             const unsigned stepB = (unsigned)(B_KC ? BK : BK * p.ldb) * 4u;
             const int nfull = (kend - kbeg) / BK;
             unsigned oa = 2 * stepA, ob = 2 * stepB;   // scalar byte offsets of tile t + 2
+            // (The SIMD-partner stagger of the one-tile-prefetch loop above was tried here as well -- upper half of the
+            // waves: fetch(t+2) -> store(t+1) -> compute(t) -- and makes the recurrence SLOWER, 523 -> 556 us forward,
+            // 488 -> 539 us backward: storing tile t+1 at the top of the interval leaves its load one phase of cover
+            // instead of two, which is what this loop exists for.)
             for (; t + 3 < nfull; t += 2) {
                 sa0.load_full(rsA, oa); sb0.load_full(rsB, ob);
                 oa += stepA; ob += stepB;
