@@ -545,6 +545,8 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
             // interval cost more than the stagger returns (2064 -> 2043 imgs/s).  profiles/r2_stagger_ab.txt
             const bool stag_wg = STAG && nfull >= 16;                 // workgroup-uniform
             if (stag_wg && wave >= 4) {
+                // (a static s_setprio 1 for this second-dispatched half, the guide's companion rule, made the roofline
+                // GEMM 2 % SLOWER here: 563 -> 574 us, same box, two builds)
                 sa.load_full(rsA, oa); sb.load_full(rsB, ob);         // tile 1 into the staging registers
                 oa += stepA; ob += stepB;
                 for (; t + 3 < nfull; t += 2) {
