@@ -49,6 +49,30 @@ def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
     return z
 
 
+def pretrain_case(seed=7, B=3, n=5, R=6, D=16, H=8, L=4, W=12, Vq=20, n_ws=7, A=12):
+    """cfg-5 pre-training model (vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py) at toy size: inputs, masks, the
+    13 report scalars, attention maps, logits and every gradient (float64 torch-autograd restatement)."""
+    from oracle import pretrain_oracle as PO
+    rng = np.random.default_rng(seed)
+    p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H)
+    batch = PO.make_batch(rng, B, n, R, D, L, Vq, n_ws, A)
+    masks = PO.make_masks(rng, B, n, R, H)
+    to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
+    total, report, mid = PO.forward(to64(p), to64(batch), to64(masks), n)
+    _, _, grads, slices = PO.torch_loss_and_grads(to64(p), to64(batch), to64(masks), n)
+    z = dict(B=B, n=n, R=R, D=D, H=H, L=L, W=W, Vq=Vq, n_ws=n_ws, A=A, total_loss=np.float64(total))
+    z.update({"param/" + k: v for k, v in p.items()})
+    z.update({"batch/" + k: v for k, v in batch.items()})
+    z.update({"keep/" + k: v.astype(np.uint8) for k, v in masks.items()})
+    z.update({"report/" + k: np.float64(v) for k, v in report.items()})
+    for k in PO.KINDS:
+        for m in ("att", "bf_logit", "ws_logit"):
+            z["mid/%s/%s" % (k, m)] = np.asarray(mid[k + "/" + m])
+    z.update({"grad/" + k: np.asarray(v, np.float64) for k, v in grads.items()})
+    z["slice_sq"] = np.float64(sum(float((v ** 2).sum()) for v in slices.values()))
+    return z
+
+
 def conv_case(seed=3):
     rng = np.random.default_rng(seed)
     full = [(n, b, 1, s) for (n, b, u, s) in CO.BLOCKS_R50_B3]
@@ -67,6 +91,8 @@ def conv_case(seed=3):
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "fusion_vlmap_answer_b8.npz"), **fusion_case("vlmap_answer", 101))
     np.savez_compressed(os.path.join(HERE, "fusion_standard_b8.npz"), **fusion_case("standard", 102))
+    np.savez_compressed(os.path.join(HERE, "fusion_standard_word2vec_b4.npz"), **fusion_case("standard_word2vec", 103, B=4))
+    np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy.npz"), **pretrain_case())
     np.savez_compressed(os.path.join(HERE, "vfeat_resnet_narrow.npz"), **conv_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
