@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vqa_transfer_externaldata_amd import _lib, ops  # noqa: E402
 
+if os.environ.get("VQA_HOT_LIB"):      # another build of the library (same-box A/B of compile-time choices)
+    _lib._LIB_PATH = os.path.abspath(os.environ["VQA_HOT_LIB"])
 lib = _lib.load()
 B, R, H, D = 512, 36, 1024, 2048
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -28,7 +30,7 @@ def tm(f, n=20):
     return best
 
 
-for rep in (1, 5):
+for rep in [int(x) for x in os.environ.get("ATTN_REPS", "1,5").split(",")]:
     v = torch.relu(torch.randn(B, R, H, device="cuda", generator=g))
     qv = torch.relu(torch.randn(B * rep, H, device="cuda", generator=g))
     V = torch.relu(torch.randn(B, R, D, device="cuda", generator=g))

@@ -108,7 +108,13 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_pool_fwd_kernel(
 // (hipcc note: the loads are written on a native 4-float vector type and are UNCONDITIONAL -- row indices are clamped
 // and rows past R get weight zero.  With HIP's float4 struct a guarded `in ? load : zero` becomes four scalar loads
 // in four branches, each waited for before the next is issued.)
-constexpr int FAST_PF = 8, FAST_POOL_BATCH = 7;
+#ifndef VQA_ATTN_PF
+#define VQA_ATTN_PF 8
+#endif
+#ifndef VQA_ATTN_POOL_BATCH
+#define VQA_ATTN_POOL_BATCH 7
+#endif
+constexpr int FAST_PF = VQA_ATTN_PF, FAST_POOL_BATCH = VQA_ATTN_POOL_BATCH;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // scores of CNT rows (row0, row0 + 8, ...) of one wave: every load of the batch is issued before the first use
