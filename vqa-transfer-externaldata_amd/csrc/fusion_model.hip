@@ -307,6 +307,13 @@ extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64
     return VQA_OK;
 }
 
+namespace {
+inline bool visual_late_enabled() {       // VQA_HOT_VISUAL_LATE=0: the round-1 order (A/B)
+    static const bool v = [] { const char* e = getenv("VQA_HOT_VISUAL_LATE"); return e == nullptr || atoi(e) != 0; }();
+    return v;
+}
+}  // namespace
+
 extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_batch_t* bt,
                                   void* workspace, int64_t workspace_bytes, int want_dz, void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && bt && workspace, VQA_ERR_ARG);
@@ -322,23 +329,32 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     const bool forked = fork_side(c, sd);
     Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
     const bool fuse_gather = gather_mode(dims) == 1 && (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table);
-    // a1: V_ft = features[image_idx] (a pass of its own, or inside the GEMM below), num_V_ft = num_boxes[image_idx]
-    TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
-                            cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, cv.st));
-    // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
-    if (fuse_gather) {
-        {
-            ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
-            TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
-                                    P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
-                                    cv.st));
+    // The visual branch (a1 + a2).  With the side stream it is launched first and overlaps the recurrence; on one
+    // stream it runs AFTER the question branch, right before the attention that consumes it: V_ft (151 MB) and
+    // v_linear_v (75 MB) are then still in the 256 MB Infinity Cache when the attention kernel reads them, instead
+    // of having been pushed out by the recurrence's traffic.
+    auto visual_branch = [&]() -> int {
+        // a1: V_ft = features[image_idx] (a pass of its own, or inside the GEMM below), num_V_ft = num_boxes[image_idx]
+        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
+                                cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, cv.st));
+        // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
+        if (fuse_gather) {
+            {
+                ProbeScope ps("v_linear_v.fwd_gemm", cv.st);
+                TRY(vqa_gemm_f32_gather((int)(B * R), (int)H, (int)D, bt->table, (int)D, bt->image_idx, (int)R, dims->N_img,
+                                        P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
+                                        cv.st));
+            }
+            TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
+                                cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
+        } else {
+            TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
+                               nullptr, 1.f));
         }
-        TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
-                            cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
-    } else {
-        TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
-                           nullptr, 1.f));
-    }
+        return VQA_OK;
+    };
+    const bool visual_late = !forked && visual_late_enabled();
+    if (!visual_late) TRY(visual_branch());
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
@@ -372,6 +388,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     // a5
     TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
     if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
+    if (visual_late) TRY(visual_branch());
     // a6 + a7
     {
     ProbeScope ps("attn_pool.fwd", c.st);
