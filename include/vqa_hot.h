@@ -291,7 +291,8 @@ int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, fl
 typedef struct {
     int32_t B, R, D, H, T, W, A, Vq;
     int64_t N_img;
-    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec */
+    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec, 3 = standard_testmask (= 1 with
+                              * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268) */
     float keep_att;          /* 0.8  vlmap/modules.py:82 */
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */

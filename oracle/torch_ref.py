@@ -87,7 +87,7 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     if model_type == "standard_word2vec":
         z = z @ P[sc["glove"]].detach()
     ell = F.binary_cross_entropy_with_logits(z, tgt, reduction="none")
-    if model_type in ("vlmap_answer", "standard_word2vec"):
+    if model_type in O.TRAIN_MASKED_LOSS:
         loss = (ell * _t(answer_masks["train"], dtype)).sum(-1).mean()
     else:
         loss = ell.sum(-1).mean()

@@ -45,6 +45,23 @@ FROZEN_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWei
 TRANSFER_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc")
 
 OUTPUT_GLOVE = "reasoning/output_glove:const"
+# model_standard and its variants share one architecture (every variable trainable, fusion MLP under 'reasoning/',
+# plain 'classifier' head); standard_testmask (vqa/model_standard_testmask.py) is model_standard with the training
+# loss masked by the train-answer mask (:266-268) and an older, shorter report (:295-304)
+STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
+TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask")
+# report keys of vqa/model_standard_testmask.py:295-304 in terms of the 13 keys of the current models
+TESTMASK_REPORT = {"answer_train_loss": "answer_train_loss", "answer_report_loss": "answer_report_loss",
+                   "answer_accuracy": "answer_acc", "exist_answer_accuracy": "exist_acc",
+                   "test_answer_accuracy": "test_acc", "normal_test_answer_accuracy": "normal_test_acc",
+                   "max_exist_answer_accuracy": "max_exist_acc", "test_max_answer_accuracy": "test_max_acc",
+                   "test_max_exist_answer_accuracy": "test_max_exist_acc"}
+
+
+def testmask_report(report):
+    """the 9 report scalars of vqa/model_standard_testmask.py:295-304 from the 13-key report"""
+    return {k: report[v] for k, v in TESTMASK_REPORT.items()}
+
 
 
 def is_const(name):
@@ -69,7 +86,7 @@ def scope_names(model_type: str) -> dict:
     if model_type == "vlmap_answer":
         pre = ""
         head = "WordWeightAnswer"
-    elif model_type in ("standard", "standard_word2vec"):
+    elif model_type in STANDARD_FAMILY:
         pre = "reasoning/"
         head = "reasoning/classifier"
     else:
@@ -94,7 +111,7 @@ def scope_names(model_type: str) -> dict:
 def train_var_names(params: dict, model_type: str) -> list:
     """filter_train_vars: vqa/model_vlmap_answer.py:81-89, vqa/model_standard.py:80-84."""
     names = sorted(n for n in params.keys() if not is_const(n))
-    if model_type in ("standard", "standard_word2vec"):
+    if model_type in STANDARD_FAMILY:
         return names
     return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
 
@@ -102,7 +119,7 @@ def train_var_names(params: dict, model_type: str) -> list:
 def transfer_var_names(params: dict, model_type: str) -> list:
     """filter_transfer_vars: vqa/model_vlmap_answer.py:91-100 (standard: :86-93)."""
     names = sorted(n for n in params.keys() if not is_const(n))
-    if model_type in ("standard", "standard_word2vec"):
+    if model_type in STANDARD_FAMILY:
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
     return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
 
@@ -267,7 +284,7 @@ def loss_and_report(z, tgt, answer_masks, model_type):
     obj, attr, exist = answer_masks["obj"], answer_masks["attr"], answer_masks["exist"]
     ell = sigmoid_ce(z, tgt)
     report_loss = ell.sum(axis=1).mean()
-    if model_type in ("vlmap_answer", "standard_word2vec"):     # model_standard_word2vec.py:199-201 masks too
+    if model_type in TRAIN_MASKED_LOSS:     # model_standard_word2vec.py:199-201 and model_standard_testmask.py:266-268 mask too
         train_loss = (ell * train).sum(axis=1).mean()
     else:
         train_loss = report_loss
@@ -401,7 +418,7 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     B = z.shape[0]
     tgt = batch["answer_target"]
     dz = (sigmoid(z) - tgt) / dt(B)
-    if model_type in ("vlmap_answer", "standard_word2vec"):
+    if model_type in TRAIN_MASKED_LOSS:
         dz = dz * answer_masks["train"]
     Wh = params[sc["head"] + "/fc/weights"]
     if model_type == "standard_word2vec":

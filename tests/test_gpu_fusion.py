@@ -36,7 +36,7 @@ def grad_close(got, want, name, tol=5e-4):
     assert err <= tol * sc + 1e-9, "%s: max err %.3e vs scale %.3e" % (name, err, sc)
 
 
-@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec"])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask"])
 @pytest.mark.parametrize("cfg", [("small", SMALL, 5, 6, 7, 9), ("med", MED, 32, 36, 14, 64),
                                  ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
 def test_forward_backward_match_oracle(model_type, cfg):

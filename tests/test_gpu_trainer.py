@@ -174,3 +174,22 @@ def test_trainer_and_evaler_start_from_reference_format_files_with_cli_defaults(
     ev.eval()
     saved = pickle.load(open(ev.save_pkl, "rb"))
     assert len(saved["qid2result"]) == 40 and saved["avg_eval_report"]["answer_acc_num_point"] == 40
+
+
+def test_standard_testmask_trains_and_reports_its_nine_scalars(tmp_path):
+    """vqa/model_standard_testmask.py through the Trainer mirror: every variable trainable, loss = masked training
+    loss, `report` / log lines under the nine older key names (:295-304)."""
+    from vqa_transfer_externaldata_amd import trainer
+    c, Vq, A = _config(tmp_path, "standard_testmask")
+    t = trainer.Trainer(c, datasets=_datasets(Vq, A), image_features=_features())
+    keys = {"answer_train_loss", "answer_report_loss", "answer_accuracy", "exist_answer_accuracy", "test_answer_accuracy",
+            "normal_test_answer_accuracy", "max_exist_answer_accuracy", "test_max_answer_accuracy",
+            "test_max_exist_answer_accuracy"}
+    assert set(t.model.report) == keys
+    assert sorted(t.model.engine.train_names) == sorted(t.model.engine.shapes)         # all trainable
+    step, summary, loss0, report, dt = t.run_train_step(True)
+    assert set(report) == keys and abs(loss0 - report["answer_train_loss"]) < 1e-6
+    assert report["answer_train_loss"] <= report["answer_report_loss"]
+    t.train()                                                                          # logs / averages use the nine keys
+    _, _, loss1, vreport, _ = t.run_val_step(False, "val")
+    assert set(vreport) == keys and loss1 < loss0

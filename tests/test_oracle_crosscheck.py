@@ -20,7 +20,7 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
     return p, table, nbox, batch, am, masks
 
 
-@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec"])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -104,3 +104,25 @@ def test_train_step_matches_torch_cpu_baseline_port():
     for k in p:
         if k.split("/")[0] in O.FROZEN_TOP_SCOPES_VLMAP:
             np.testing.assert_array_equal(p[k], p_t[k])     # frozen vars never move
+
+
+def test_standard_testmask_is_standard_with_the_masked_training_loss():
+    """vqa/model_standard_testmask.py:262-268, 295-304: the network of model_standard, the training loss masked by the
+    train-answer mask (so head gradients of the test answers vanish), the report loss unmasked, nine report scalars."""
+    p, table, nbox, batch, am, masks = _case(17, "standard_testmask")
+    assert sorted(p) == sorted(_case(17, "standard")[0])                              # same variables
+    assert O.train_var_names(p, "standard_testmask") == sorted(p)                     # all trainable
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, "standard_testmask")
+    loss_s, report_s, _, mid_s, _ = O.forward(p, batch, table, nbox, am, masks, "standard")
+    np.testing.assert_array_equal(mid["logit"], mid_s["logit"])                       # same forward
+    assert report["answer_report_loss"] == report_s["answer_report_loss"] == loss_s
+    assert loss == report["answer_train_loss"] < loss_s                               # masked sum of positive terms
+    grads, _ = O.backward(p, batch, am, masks, tape, "standard_testmask")
+    test_cols = am["train"] == 0
+    assert test_cols.any() and np.all(grads["reasoning/classifier/fc/weights"][:, test_cols] == 0)
+    assert np.all(grads["reasoning/classifier/fc/biases"][test_cols] == 0)
+    r9 = O.testmask_report(report)
+    assert sorted(r9) == sorted(["answer_train_loss", "answer_report_loss", "answer_accuracy", "exist_answer_accuracy",
+                                 "test_answer_accuracy", "normal_test_answer_accuracy", "max_exist_answer_accuracy",
+                                 "test_max_answer_accuracy", "test_max_exist_answer_accuracy"])
+    assert r9["answer_accuracy"] == report["answer_acc"] and r9["test_max_exist_answer_accuracy"] == report["test_max_exist_acc"]

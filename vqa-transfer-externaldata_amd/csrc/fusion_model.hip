@@ -246,7 +246,7 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 2;
+           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 3;
 }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)

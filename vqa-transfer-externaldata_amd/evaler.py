@@ -85,7 +85,7 @@ class Evaler(object):
             self.model.set_batch(batch)      # (re)build: the constructor ran before the checkpoint was loaded
             self.model.build()
             torch.cuda.synchronize(self.model.device)
-            reports = self.model.engine.report()
+            reports = self.model.map_report(self.model.engine.report())
             outputs = {k: v.detach().cpu().numpy() for k, v in self.model.output.items()
                        if k not in ("att_score", "logit")}
             inputs = batch

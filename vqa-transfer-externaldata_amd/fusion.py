@@ -35,12 +35,17 @@ TRANSFER_TOP_SCOPES_VLMAP = ("q_linear_l", "pooled_linear_l", "joint_fc")
 _INT_TENSORS = {"num_V_ft", "pred"}
 
 
+# model_standard and its variants: one architecture, every variable trainable (vqa/model_standard.py:80-84,
+# vqa/model_standard_word2vec.py, vqa/model_standard_testmask.py:64-68)
+STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
+
+
 def scope_names(model_type):
     """logical layer -> TF variable scope (vqa/model_vlmap_answer.py:126-185,
     vqa/model_standard.py:223-275)."""
     if model_type == "vlmap_answer":
         pre, head = "", "WordWeightAnswer"
-    elif model_type in ("standard", "standard_word2vec"):
+    elif model_type in STANDARD_FAMILY:
         pre, head = "reasoning/", "reasoning/classifier"
     else:
         raise ValueError("unknown model_type %r" % (model_type,))
@@ -80,14 +85,14 @@ def variable_shapes(model_type, Vq, W, D, H, A):
 
 def filter_train_vars(names, model_type):
     """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
-    if model_type in ("standard", "standard_word2vec"):
+    if model_type in STANDARD_FAMILY:
         return list(names)
     return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
 
 
 def filter_transfer_vars(names, model_type):
     """vqa/model_vlmap_answer.py:91-100 / vqa/model_standard.py:86-93."""
-    if model_type in ("standard", "standard_word2vec"):
+    if model_type in STANDARD_FAMILY:
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
     return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
 
@@ -97,7 +102,7 @@ def _pad4(n):
 
 
 class FusionEngine:
-    MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2}
+    MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,

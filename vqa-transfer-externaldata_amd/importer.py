@@ -1,12 +1,12 @@
 """String -> Model class registry, the counterpart of vqa/importer.py:1-52.
 
-The two models on the hot path and the first variant of section 8f-4
-(standard_word2vec) are built natively; the reference's other ablation variants are listed so that
+The two models on the hot path and the first variants of section 8f-4
+(standard_word2vec, standard_testmask) are built natively; the reference's other ablation variants are listed so that
 a request for one fails with a precise message instead of an import error."""
 
-_NATIVE = ("standard", "standard_word2vec", "vlmap_answer")
+_NATIVE = ("standard", "standard_testmask", "standard_word2vec", "vlmap_answer")
 _REFERENCE_ONLY = (
-    "vqa", "standard_testmask", "vlmap_only", "vlmap_finetune", "vlmap_answer_vqa_all",
+    "vqa", "vlmap_only", "vlmap_finetune", "vlmap_answer_vqa_all",
     "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_noc", "vlmap_answer_nocarch", "vlmap_answer_adapt",
     "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise")
 
@@ -18,6 +18,8 @@ def get_model_types():
 def get_model_class(model_type="vlmap_answer"):
     if model_type == "standard":
         from .model_standard import Model
+    elif model_type == "standard_testmask":
+        from .model_standard_testmask import Model
     elif model_type == "standard_word2vec":
         from .model_standard_word2vec import Model
     elif model_type == "vlmap_answer":

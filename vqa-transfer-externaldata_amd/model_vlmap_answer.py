@@ -266,6 +266,10 @@ class Model(object):
         return db
 
     # ---------------------------------------------------------------- build = forward
+    def map_report(self, report):
+        """the step's 13 report scalars under this model's `report` keys (variants with an older report rename them)"""
+        return report
+
     def build(self):
         """build network architecture and loss (here: run it on self.batch)"""
         db = self._device_batch()
@@ -292,7 +296,7 @@ class Model(object):
         stats = eng.tensor("stats").view(B, 16)
         rep = eng.tensor("report")
         keys = [eng.lib.vqa_report_key(i).decode() for i in range(13)]
-        self.report = {k: rep[i] for i, k in enumerate(keys)}
+        self.report = self.map_report({k: rep[i] for i, k in enumerate(keys)})
         self.losses = {"answer": rep[0]}
         self.loss = rep[0]
         self.mid_result = {

@@ -169,7 +169,7 @@ class Trainer(object):
         torch.cuda.synchronize(self.model.device)
         # data parallel: statistics are reduced over the ranks, so every rank logs the global-batch report
         rep = self.model.engine.report(global_rows=self.config.global_batch if self.world > 1 else None)
-        return float(rep["answer_train_loss"]), rep
+        return float(rep["answer_train_loss"]), self.model.map_report(rep)
 
     # ------------------------------------------------------------------ steps
     def run_train_step(self, use_heavy_summary):
