@@ -73,3 +73,29 @@ def test_dataset_and_batches_from_densecap_hdf5(tmp_path):
     assert sorted(a["id"].tolist()) == [0, 1, 2, 3, 4] and a["id"].tolist() == b["id"].tolist() != [0, 1, 2, 3, 4]
     with pytest.raises(StopIteration):
         next(it)
+
+
+def test_ring_buffers_give_the_same_batches_when_consumed_in_order(tmp_path):
+    """reuse_buffers=True (the extractor's mode): same batches as the allocating mode when each one is consumed before
+    the next is drawn; the image blocks come from a ring of prefetch + 2 buffers"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    d = tmp_path / "img" / "VG_100K"
+    d.mkdir(parents=True)
+    paths, boxes = [], {}
+    for i in range(11):
+        Image.fromarray(rng.integers(0, 255, size=(40 + i, 50, 3), dtype=np.uint8)).save(str(d / ("%d.png" % i)))
+        paths.append("VG_100K/%d.png" % i)
+        boxes["VG_100K-%d.png" % i] = rng.uniform(1, 20, size=(3 + i % 4, 4)).astype(np.float32)
+    ds = DV.create_dataset(paths, str(tmp_path / "img"), None, boxes=boxes)
+    want = [{k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+            for b in IO.create(ds, 4, is_train=False, shuffle=False, num_parallel_calls=2, prefetch=2)]
+    seen = set()
+    n = 0
+    for got, w in zip(IO.create(ds, 4, is_train=False, shuffle=False, num_parallel_calls=3, prefetch=2, reuse_buffers=True), want):
+        for k in ("id", "image", "box", "normal_box", "num_box"):
+            np.testing.assert_array_equal(got[k], w[k], err_msg=k)
+        assert got["image_id"] == w["image_id"]
+        seen.add(got["image"].__array_interface__["data"][0])
+        n += 1
+    assert n == len(want) == 3 and [len(w["id"]) for w in want] == [4, 4, 3] and len(seen) <= 4
