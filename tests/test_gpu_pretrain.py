@@ -161,3 +161,51 @@ def test_checkpoint_resume_continues_the_adam_trajectory():
             continue       # analytically zero gradient (softmax shift invariance): Adam amplifies run-to-run rounding noise
         # bitwise up to the atomically scatter-added embedding gradients (order of the adds varies run to run)
         np.testing.assert_allclose(v.cpu().numpy(), want[k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_resident_feature_tables_give_the_dense_batch_results():
+    """PretrainEngine.bind_tables + batches that carry image_idx: the rows gathered on the device are the dense
+    batch's, so report, logits and gradients are bit for bit those of the dense path"""
+    from vqa_transfer_externaldata_amd import pretrain as PT
+    cfg = dict(B=6, n=5, R=36, D=64, H=32, L=5, W=12, Vq=30, n_ws=9, A=20)
+    rng = np.random.default_rng(11)
+    p = PO.init_params(rng, cfg["Vq"], cfg["n_ws"], cfg["A"], W=cfg["W"], D=cfg["D"], H=cfg["H"])
+    batch = PO.make_batch(rng, cfg["B"], cfg["n"], cfg["R"], cfg["D"], cfg["L"], cfg["Vq"], cfg["n_ws"], cfg["A"])
+    masks = {k: dev(v.astype(np.uint8)) for k, v in PO.make_masks(rng, cfg["B"], cfg["n"], cfg["R"], cfg["H"]).items()}
+    N = 17
+    idx = rng.permutation(N)[:cfg["B"]].astype(np.int64)
+    table = rng.standard_normal((N, cfg["R"], cfg["D"])).astype(np.float32)
+    spat = rng.random((N, cfg["R"], 6)).astype(np.float32)
+    nbox = rng.integers(1, cfg["R"] + 1, size=N).astype(np.int32)
+    dense = dict(batch, image_ft=table[idx], spatial_ft=spat[idx], num_boxes=nbox[idx])
+    res = {k: v for k, v in batch.items() if k not in ("image_ft", "spatial_ft", "num_boxes")}
+    res["image_idx"] = idx
+    out = []
+    for b, bind in ((dense, False), (res, True)):
+        eng = PT.PretrainEngine(n=cfg["n"], R=cfg["R"], D=cfg["D"], H=cfg["H"], W=cfg["W"], A=cfg["A"], Vq=cfg["Vq"],
+                                n_ws=cfg["n_ws"], params=p, deterministic=True)      # atomic-free embedding gradients
+        if bind:
+            eng.bind_tables(table, spat, nbox)
+        eng.forward({k: dev(v) for k, v in b.items()}, masks)
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append((eng.fetch_report(), eng.grad_flat.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+    eng = PT.PretrainEngine(n=cfg["n"], R=cfg["R"], D=cfg["D"], H=cfg["H"], W=cfg["W"], A=cfg["A"], Vq=cfg["Vq"],
+                            n_ws=cfg["n_ws"], params=p)
+    with pytest.raises(ValueError, match="bind_tables"):
+        eng.forward({k: dev(v) for k, v in res.items()}, masks)
+
+
+def test_trainer_loop_with_tables_in_hbm_and_forked_producers_in_a_fresh_process():
+    """tools/pretrain_trainer_bench.py resident-workers: the Trainer mirror with both splits' tables on the device and
+    4 forked batch producers started before the GPU is touched (a fresh process, as `python -m ...pretrain_trainer`)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pretrain_trainer_bench.py"), "resident-workers", "4",
+                        "64", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "resident-workers" in r.stdout and "images/s" in r.stdout, r.stdout

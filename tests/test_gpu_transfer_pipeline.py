@@ -22,7 +22,8 @@ def test_pretrain_export_finetune_eval(tmp_path):
 
     cfg = PTT.build_parser().parse_args(["--batch_size", "8", "--max_train_iter", "9", "--train_average_iter", "3",
                                          "--val_average_iter", "1", "--validation_step", "4", "--checkpoint_step", "4",
-                                         "--heavy_summary_step", "4", "--learning_rate", "0.002"])
+                                         "--heavy_summary_step", "4", "--learning_rate", "0.002",
+                                         "--input_workers", "0"])      # (this process already holds the GPU)
     cfg.data_cfg = ds["train"].get_config()
     cfg.vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
     cfg.answer_dict, cfg.ws_dict = data["answer_dict"], data["ws_dict"]

@@ -65,3 +65,51 @@ def test_variable_contract_matches_oracle_and_transfer_names():
     for n in F.filter_transfer_vars(sorted(vq), "vlmap_answer"):
         assert n in a and a[n] == vq[n], n
     assert a["classifier/fc/weights"] == (2048, 4000)
+
+
+def _same_batch(a, b):
+    assert sorted(a) == sorted(b)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_resident_batches_carry_indices_into_the_feature_tables():
+    """create_ops(resident=True): same sampled entries as the dense stream, `image_idx` in place of the feature
+    slices; gathering the tables by it gives the dense batch's image_ft / spatial_ft / num_boxes"""
+    mk = lambda: DV.Dataset(split="train", data=DV.synthetic_dataset(11, 50, 9, 21, R=36, D=8, max_len=7, seed=2), seed=4)
+    dense = DV.create_ops(4, mk(), is_train=True, shuffle=True, seed=9, repeat=2)
+    ds = mk()
+    res = DV.create_ops(4, ds, is_train=True, shuffle=True, seed=9, repeat=2, resident=True)
+    n = 0
+    for d, r in zip(dense, res):
+        assert "image_ft" not in r and "spatial_ft" not in r and "num_boxes" not in r and r["image_idx"].dtype == np.int64
+        np.testing.assert_array_equal(ds.image_features[r["image_idx"]], d["image_ft"])
+        np.testing.assert_array_equal(ds.spatial_features[r["image_idx"]], d["spatial_ft"])
+        np.testing.assert_array_equal(np.asarray(ds.num_boxes)[r["image_idx"]], d["num_boxes"])
+        for k in r:
+            if k != "image_idx":
+                np.testing.assert_array_equal(r[k], d[k], err_msg=k)
+        n += 1
+    assert n == 6                                         # 2 epochs x (4 + 4 + 3)
+
+
+def test_producer_thread_and_processes_deliver_the_stream_in_order():
+    # (a fresh copy per stream: the dataset shuffles its word-set lists in place, like the reference's)
+    mk = lambda: DV.Dataset(split="train", data=DV.synthetic_dataset(10, 50, 9, 21, R=36, D=8, max_len=7, seed=3), seed=5)
+    plain = list(DV.create_ops(3, mk(), is_train=True, seed=1, repeat=2, resident=True))
+    threaded = list(DV.create_ops(3, mk(), is_train=True, seed=1, repeat=2, resident=True, prefetch=2))
+    assert len(plain) == len(threaded) == 8
+    for a, b in zip(plain, threaded):
+        _same_batch(a, b)                                 # one producer thread: the very same stream
+    # forked producers: batch g comes from producer g % K, in order; same images per batch as the plain stream (the
+    # epoch orders are shared), own sampling streams; reproducible for a given K
+    runs = [list(DV.create_ops(3, mk(), is_train=True, seed=1, repeat=2, resident=True, workers=2)) for _ in range(2)]
+    assert len(runs[0]) == len(runs[1]) == 8
+    for a, b, p in zip(runs[0], runs[1], plain):
+        _same_batch(a, b)
+        np.testing.assert_array_equal(a["image_idx"], p["image_idx"])
+        np.testing.assert_array_equal(a["image_id"], p["image_id"])
+    # a single evaluation pass ends, short last batch included
+    ev = list(DV.create_ops(4, mk(), is_train=False, resident=True, workers=3))
+    assert [len(b["image_id"]) for b in ev] == [4, 4, 2]
+    np.testing.assert_array_equal(np.concatenate([b["image_id"] for b in ev]), np.asarray(mk().ids, np.int32))

@@ -11,11 +11,14 @@ model does not read them.  Files: `<data_dir>/<split>_processed.pkl`, `<split>_i
 """
 from __future__ import annotations
 
+import logging
 import os
 import pickle
 from collections import defaultdict
 
 import numpy as np
+
+log = logging.getLogger(__name__)
 
 NUM_CONFIG = {"obj_blank_fill": 5, "attr_blank_fill": 5}      # dataset_vlmap.py (n_obj_bf, n_attr_bf)
 
@@ -88,11 +91,16 @@ class Dataset(object):
             self.wordset_choice_idx[category][task][label] = 0
         return ws
 
-    def get_data(self, image_id):
+    def get_data(self, image_id, with_features=True):
+        """with_features=False (not in the reference): the row carries `image_idx` instead of its slices of the
+        feature tables -- for trainers that keep the tables in HBM and gather there (create_ops(resident=True))"""
         idx = self.image_id2idx[image_id]
-        ret = {"image_id": np.array(image_id, np.int32), "image_ft": self.image_features[idx],
-               "spatial_ft": self.spatial_features[idx], "normal_boxes": self.normal_boxes[idx],
-               "num_boxes": self.num_boxes[idx]}
+        if with_features:
+            ret = {"image_id": np.array(image_id, np.int32), "image_ft": self.image_features[idx],
+                   "spatial_ft": self.spatial_features[idx], "normal_boxes": self.normal_boxes[idx],
+                   "num_boxes": self.num_boxes[idx]}
+        else:
+            ret = {"image_id": np.array(image_id, np.int32), "image_idx": np.array(idx, np.int64)}
         entry = self.processed[image_id]
         for cat, key in (("obj", "obj_blank_fill"), ("attr", "attr_blank_fill")):
             n = NUM_CONFIG[key]
@@ -129,28 +137,123 @@ class Dataset(object):
         return len(self._ids)
 
 
-def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=True, seed=0, repeat=1000):
-    """Iterator of padded batch dicts (dataset_vlmap.create_ops, :308-353): captions are padded to the
-    longest of the batch; train repeats, eval is a single pass."""
+def _collate(rows):
+    """padded_batch of the reference: captions zero-padded to the longest of the batch, everything else stacked"""
+    out = {}
+    for k in rows[0]:
+        if k.endswith("/blanks"):
+            L = max(r[k].shape[1] for r in rows)
+            o = np.zeros((len(rows), rows[0][k].shape[0], L), rows[0][k].dtype)
+            for i, r in enumerate(rows):
+                o[i, :, :r[k].shape[1]] = r[k]
+            out[k] = o
+        else:
+            out[k] = np.stack([np.asarray(r[k]) for r in rows])
+    return out
+
+
+def _batches(batch_size, dataset, is_train, shuffle, seed, repeat, resident, part=0, parts=1):
+    """batches number part, part + parts, ... of the stream (every producer draws the same epoch orders)"""
     ids = list(dataset.ids)
     rng = np.random.RandomState(seed)
+    g = 0
+    for _ in range(repeat if is_train else 1):
+        order = list(ids)
+        if is_train and shuffle:
+            rng.shuffle(order)
+        for lo in range(0, len(order), batch_size):
+            if g % parts == part:
+                yield _collate([dataset.get_data(i, with_features=not resident) for i in order[lo:lo + batch_size]])
+            g += 1
 
-    def gen():
-        for _ in range(repeat if is_train else 1):
-            order = list(ids)
-            if is_train and shuffle:
-                rng.shuffle(order)
-            for lo in range(0, len(order), batch_size):
-                rows = [dataset.get_data(i) for i in order[lo:lo + batch_size]]
-                out = {}
-                for k in rows[0]:
-                    if k.endswith("/blanks"):
-                        L = max(r[k].shape[1] for r in rows)
-                        out[k] = np.stack([np.pad(r[k], ((0, 0), (0, L - r[k].shape[1]))) for r in rows])
-                    else:
-                        out[k] = np.stack([np.asarray(r[k]) for r in rows])
-                yield out
-    return gen()
+
+def _worker_main(q, batch_size, dataset, is_train, shuffle, seed, repeat, resident, part, parts):
+    dataset.rng = np.random.RandomState((int(seed) + 1000003 * (part + 1)) % (2 ** 31 - 1))   # own sampling stream
+    try:
+        for b in _batches(batch_size, dataset, is_train, shuffle, seed, repeat, resident, part, parts):
+            q.put(b)
+    finally:
+        q.put(None)
+
+
+def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=True, seed=0, repeat=1000,
+               resident=False, workers=0, prefetch=0):
+    """Iterator of padded batch dicts (dataset_vlmap.create_ops, :308-353): captions are padded to the
+    longest of the batch; train repeats, eval is a single pass.
+
+    Not in the reference (whose py_func map is sequential, :323-340, and was never the bottleneck of a 2018 GPU):
+    * resident: rows carry `image_idx` instead of the 295 KB feature slices (the trainer gathers from tables in HBM);
+    * workers K > 0: K forked producer processes, started HERE (call before anything initialises the GPU); producer w
+      assembles batches w, w + K, ... of the same epoch orders with its own sampling stream, the parent hands them out
+      in batch order, so a run is reproducible for a given K (the sampled entries differ from the K = 0 stream);
+    * prefetch P > 0 (workers == 0): one producer thread runs P batches ahead of the consumer."""
+    args = (batch_size, dataset, is_train, shuffle, seed, repeat, resident)
+    if workers and workers > 0:
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            # a fork now would hand the children this process's GPU file descriptors: one producer thread instead
+            log.warning("create_ops(workers=%d) after the GPU was initialised: using one producer thread", workers)
+            workers, prefetch = 0, max(2, prefetch or 0)
+    if workers and workers > 0:
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")              # the dataset (pickles, feature tables) is shared copy-on-write
+        qs = [ctx.Queue(maxsize=max(2, prefetch or 2)) for _ in range(workers)]
+        procs = [ctx.Process(target=_worker_main, args=(qs[w],) + args + (w, workers), daemon=True) for w in range(workers)]
+        for p in procs:
+            p.start()
+
+        def gen_mp():
+            try:
+                g = 0
+                while True:
+                    b = qs[g % workers].get()
+                    if b is None:
+                        return
+                    yield b
+                    g += 1
+            finally:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+        return gen_mp()
+    if prefetch and prefetch > 0:
+        import queue
+        import threading
+        q = queue.Queue(maxsize=prefetch)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for b in _batches(*args):
+                    while not stop.is_set():
+                        try:
+                            q.put(b, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+            finally:
+                while not stop.is_set():
+                    try:
+                        q.put(None, timeout=0.2)
+                        break
+                    except queue.Full:
+                        continue
+        threading.Thread(target=produce, daemon=True).start()
+
+        def gen_thread():
+            try:
+                while True:
+                    b = q.get()
+                    if b is None:
+                        return
+                    yield b
+            finally:
+                stop.set()
+        return gen_thread()
+    return _batches(*args)
 
 
 def synthetic_dataset(num_images, Vq, n_ws, A, R=36, D=2048, max_len=10, seed=0):

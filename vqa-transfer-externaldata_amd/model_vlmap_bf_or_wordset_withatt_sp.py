@@ -76,7 +76,7 @@ class Model(object):
         self.batch = batch
 
     def _device_batch(self):
-        keep = ("image_ft", "spatial_ft", "num_boxes")
+        keep = ("image_ft", "spatial_ft", "num_boxes", "image_idx")
         out = {}
         for k, v in self.batch.items():
             if k in keep or k.split("/")[-1] in ("normal_boxes", "fills", "blanks", "blanks_len", "wordsets", "num"):
@@ -85,7 +85,8 @@ class Model(object):
                 t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
                 out[k] = t.to(self.device)
         for k in ("image_ft", "spatial_ft"):
-            out[k] = out[k].float()
+            if k in out:
+                out[k] = out[k].float()
         if getattr(self.config, "sort_by_length", 1):
             host = PT.add_length_sort({k: v for k, v in self.batch.items() if k.endswith(("/blanks", "/blanks_len"))})
             out.update({k: v for k, v in host.items() if k.endswith("/sort")})
@@ -105,7 +106,10 @@ class Model(object):
                                              A=self.num_answer, Vq=len(self.vocab["vocab"]), n_ws=self.num_ws,
                                              params=self._initial_params(shapes), device=self.device)
         eng = self._engine
-        B = db["image_ft"].shape[0]
+        B = int((db["image_ft"] if "image_ft" in db else db["image_idx"]).shape[0])
+        tables = getattr(self.config, "feature_tables", None)
+        if tables is not None and getattr(eng, "_tables", None) is None:
+            eng.bind_tables(*tables)           # (image_features, spatial_features, num_boxes): gathered on the device
         masks = None if getattr(self.config, "dropout_off", False) else eng.make_keep_masks(
             B, int(getattr(self.config, "seed", 123)), self._step)
         self._step += 1

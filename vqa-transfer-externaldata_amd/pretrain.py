@@ -171,6 +171,28 @@ class PretrainEngine:
         t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def bind_tables(self, image_features, spatial_features, num_boxes):
+        """Keep the feature tables of the dataset ([N,R,D] f32, [N,R,6] f32, [N] i32) in HBM; batches may then carry
+        `image_idx` (i64 [B]) instead of image_ft / spatial_ft / num_boxes and the rows are gathered on the device
+        (`vqa_gather_features`), the cfg-5 counterpart of SURVEY row a1: no per-step np.take of 151 MB on the host and
+        no H2D copy of it.  The reference holds the whole '<split>_vfeat.hdf5' in host RAM (dataset_vlmap.py:67-72)."""
+        f = self._dev(image_features, torch.float32)
+        assert f.dim() == 3 and f.shape[1] == self.R and f.shape[2] == self.D, f.shape
+        self._tables = (f, self._dev(spatial_features, torch.float32), self._dev(np.asarray(num_boxes), torch.int32))
+        self._gathered = {}
+
+    def _gather(self, idx):
+        """image_ft / spatial_ft / num_boxes of a batch from the bound tables, into buffers owned by the engine"""
+        from . import ops
+        table, spat, nb = self._tables
+        B = int(idx.numel())
+        buf = self._gathered.get(B)
+        if buf is None:
+            buf = self._gathered[B] = {"spatial_ft": torch.empty(B, self.R, spat.shape[2], device=self.device)}
+        V, n = ops.gather_features(table, nb, idx)
+        torch.index_select(spat, 0, idx, out=buf["spatial_ft"])
+        return V, buf["spatial_ft"], n
+
     def _batch_struct(self, batch, masks):
         """C view of one batch (device tensors with the keys of vlmap_memft/datasets/dataset_vlmap.py:128-236 that
         the model reads).  Converted tensors are cached on the batch dict, so a batch that is fed again (the input
@@ -181,10 +203,18 @@ class PretrainEngine:
                 cache[key] = self._dev(batch[key], dtype)
             return cache[key]
         keep = [cache, masks]
-        bs = _lib.PtBatch(image_ft=get("image_ft", torch.float32).data_ptr(),
-                          spatial_ft=get("spatial_ft", torch.float32).data_ptr(),
-                          num_boxes=get("num_boxes", torch.int32).data_ptr())
-        B = cache["image_ft"].shape[0]
+        if "image_idx" in batch and "image_ft" not in batch:
+            if getattr(self, "_tables", None) is None:
+                raise ValueError("batch carries image_idx but no feature tables are bound (PretrainEngine.bind_tables)")
+            V, sp, nb = self._gather(get("image_idx", torch.int64))
+            keep.append((V, sp, nb))
+            bs = _lib.PtBatch(image_ft=V.data_ptr(), spatial_ft=sp.data_ptr(), num_boxes=nb.data_ptr())
+            B = V.shape[0]
+        else:
+            bs = _lib.PtBatch(image_ft=get("image_ft", torch.float32).data_ptr(),
+                              spatial_ft=get("spatial_ft", torch.float32).data_ptr(),
+                              num_boxes=get("num_boxes", torch.int32).data_ptr())
+            B = cache["image_ft"].shape[0]
         L = None
         for ki, k in enumerate(KINDS):
             pre = k + "_blank_fill/"

@@ -37,10 +37,31 @@ class Trainer(object):
         os.makedirs(self.train_dir, exist_ok=True)
         log.infov("Train Dir: %s", self.train_dir)
         self.batch_size = config.batch_size
-        self._iters = {"train": dataset_vlmap.create_ops(self.batch_size, dataset["train"], is_train=True,
-                                                         scope="train_ops", shuffle=True, seed=config.seed),
-                       "val": dataset_vlmap.create_ops(self.batch_size, dataset["val"], is_train=True,
-                                                       scope="val_ops", shuffle=False, seed=config.seed)}
+        # Input side (not in the reference, whose sequential py_func pipeline fed a 2018 GPU): the feature tables of
+        # both splits stay in HBM and batches carry image indices (features_on_device), batches are assembled by
+        # forked producer processes (input_workers) or one producer thread (input_prefetch) while the GPU runs the
+        # step.  Producers are started here, before anything has initialised the GPU.
+        resident = bool(getattr(config, "features_on_device", 1))
+        workers = int(getattr(config, "input_workers", 0) or 0)
+        prefetch = int(getattr(config, "input_prefetch", 2) or 0)
+        mk = lambda split, shuffle, name: dataset_vlmap.create_ops(
+            self.batch_size, dataset[split], is_train=True, scope=name, shuffle=shuffle, seed=config.seed,
+            resident=resident, workers=workers, prefetch=prefetch)
+        self._iters = {"train": mk("train", True, "train_ops"), "val": mk("val", False, "val_ops")}
+        if resident:
+            tr, va = dataset["train"], dataset["val"]
+            n_train = int(np.asarray(tr.image_features).shape[0])
+            same = va.image_features is tr.image_features
+            cat = (lambda a, b: a if same else np.concatenate([np.asarray(a), np.asarray(b)], 0))
+            config.feature_tables = (cat(tr.image_features, va.image_features),
+                                     cat(tr.spatial_features, va.spatial_features),
+                                     cat(np.asarray(tr.num_boxes), np.asarray(va.num_boxes)))
+            if not same:       # the validation split's rows follow the training split's in the device tables
+                def offset(it):
+                    for b in it:
+                        b["image_idx"] = b["image_idx"] + n_train
+                        yield b
+                self._iters["val"] = offset(self._iters["val"])
         self._pending = next(self._iters["train"])
         self.model = self.get_model_class(config.model_type)(self._pending, config, is_train=True)
         self.global_step = 0
@@ -167,6 +188,11 @@ def build_parser():
     parser.add_argument("--batch_size", type=int, default=512, help=" ")
     parser.add_argument("--model_type", type=str, default="vlmap_bf_or_wordset_withatt_sp", help=" ",
                         choices=MODEL_TYPES)
+    # not in the reference: how the input side keeps up with a 18 ms step
+    parser.add_argument("--features_on_device", type=int, default=1,
+                        help="keep both splits' feature tables in HBM, batches carry image indices")
+    parser.add_argument("--input_workers", type=int, default=4, help="forked batch producers (0: in-process)")
+    parser.add_argument("--input_prefetch", type=int, default=2, help="batches assembled ahead of the step")
     return parser
 
 
