@@ -30,25 +30,35 @@ def _collate(ids, items, images=None):
 
 
 def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=True, seed=123, num_parallel_calls=8,
-           prefetch=10, repeat=1000, reuse_buffers=False):
+           prefetch=10, repeat=1000, reuse_buffers=False, pinned=False):
     """reuse_buffers (not in the reference): the image blocks of the batches come from a ring of `prefetch + 2`
     preallocated [B,H,W,3] buffers, so a batch's `image` is only valid until the second next batch is requested (its
     slot is refilled then) -- for consumers that upload each batch before asking for the next (the extractor).
     Fresh memory of that size (336 MB per batch of 96) is page-faulted in at well under 1 GB/s in these VMs, which
     otherwise dominates the loader: 54 -> 496 images/s on 8 cores together with the direct write of the pixels into
-    the batch block (tools/vfeat_input_bench.py)."""
+    the batch block (tools/vfeat_input_bench.py).  pinned: the ring is page-locked memory (needs the GPU runtime)."""
     ids = list(dataset.ids)
     if is_train and shuffle:
         np.random.RandomState(seed).shuffle(ids)
     chunks = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
 
+    ring_keepalive = []
     direct = bool(getattr(dataset, "supports_image_out", False))
     shape = (int(getattr(dataset, "height", 0)), int(getattr(dataset, "width", 0)), 3)
-    ring = [np.empty((batch_size,) + shape, np.float32) for _ in range(max(1, prefetch) + 2)] \
-        if (direct and reuse_buffers) else []
+    ring = []
+    if direct and reuse_buffers:
+        n_ring = max(1, prefetch) + 2
+        if pinned:      # page-locked blocks: the consumer's .to(device, non_blocking=True) is an asynchronous DMA
+            import torch
+            keep = [torch.empty((batch_size,) + shape, dtype=torch.float32, pin_memory=True) for _ in range(n_ring)]
+            ring = [t.numpy() for t in keep]
+            ring_keepalive.extend(keep)
+        else:
+            ring = [np.empty((batch_size,) + shape, np.float32) for _ in range(n_ring)]
     slot = [0]
 
     def gen():
+        _ = ring_keepalive          # the pinned tensors live as long as the generator
         with ThreadPoolExecutor(max_workers=max(1, num_parallel_calls)) as pool:
             for _ in range(repeat if is_train else 1):
                 pending = collections.deque()

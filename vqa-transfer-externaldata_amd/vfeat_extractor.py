@@ -81,7 +81,8 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device="cuda:0"):
     model = get_model_class(config.model_type)(params, blocks, device=device)
     batches = input_ops_vfeat.create(dataset, config.batch_size, is_train=False, scope="batch_ops", shuffle=False,
                                      num_parallel_calls=int(getattr(config, "num_parallel_calls", 8) or 8),
-                                     prefetch=3, reuse_buffers=True)      # each batch is uploaded before the next is drawn
+                                     prefetch=3, reuse_buffers=True,       # each batch is uploaded before the next is drawn
+                                     pinned=torch.cuda.is_available())
     ex = vfeat.Extractor(model, image_info["image_id2idx"], dataset.get_config().max_roi_num,
                          config.pretrained_param_path)
     out = ex.extract(device_batches(batches, device), config.save_path)
