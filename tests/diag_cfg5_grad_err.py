@@ -2,7 +2,7 @@
 float32 CPU autograd run of the same model makes against the same f64 numbers."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pretrain_oracle as PO
 from tests.test_gpu_pretrain import _setup
 cfg = dict(B=512, n=5, R=36, D=2048, H=1024, L=10, W=300, Vq=5000, n_ws=2000, A=4000)

@@ -123,7 +123,7 @@ def test_full_size_cfg5_bs512_matches_oracle_f64():
         # At this size (3e7 ReLU gates per head) float32 and float64 disagree on a handful of gates whose
         # pre-activation is ~0; each flip shifts one column's gradient and everything upstream of it by ~1e-3 of
         # the tensor norm.  A plain float32 torch-CPU autograd run shows the same deviations from float64
-        # (tools/dbg/cfg5_grad_err.py: 1e-3 .. 1.6e-2 of max-abs, 1e-3 norm-wise), so the bar here is norm-wise.
+        # (tests/diag_cfg5_grad_err.py: 1e-3 .. 1.6e-2 of max-abs, 1e-3 norm-wise), so the bar here is norm-wise.
         g = eng.grads[name].cpu().numpy().astype(np.float64)
         sc = max(np.abs(grads[name]).max(), 1e-12)
         fro = np.linalg.norm(g - grads[name]) / max(np.linalg.norm(grads[name]), 1e-30)
