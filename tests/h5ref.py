@@ -59,7 +59,13 @@ class H5:
         self.T = {np.dtype("<f4"): (g("H5T_IEEE_F32LE_g"), g("H5T_NATIVE_FLOAT_g")),
                   np.dtype("<f8"): (g("H5T_IEEE_F64LE_g"), g("H5T_NATIVE_DOUBLE_g")),
                   np.dtype("<i4"): (g("H5T_STD_I32LE_g"), g("H5T_NATIVE_INT32_g")),
-                  np.dtype("<i8"): (g("H5T_STD_I64LE_g"), g("H5T_NATIVE_INT64_g"))}
+                  np.dtype("<i8"): (g("H5T_STD_I64LE_g"), g("H5T_NATIVE_INT64_g")),
+                  np.dtype("i1"): (g("H5T_STD_I8LE_g"), g("H5T_NATIVE_INT8_g")),
+                  np.dtype("u1"): (g("H5T_STD_U8LE_g"), g("H5T_NATIVE_UINT8_g")),
+                  np.dtype("<i2"): (g("H5T_STD_I16LE_g"), g("H5T_NATIVE_INT16_g")),
+                  np.dtype("<u2"): (g("H5T_STD_U16LE_g"), g("H5T_NATIVE_UINT16_g")),
+                  np.dtype("<u4"): (g("H5T_STD_U32LE_g"), g("H5T_NATIVE_UINT32_g")),
+                  np.dtype("<u8"): (g("H5T_STD_U64LE_g"), g("H5T_NATIVE_UINT64_g"))}
         self.C_S1 = g("H5T_C_S1_g")
         self.P_DATASET_CREATE = g("H5P_CLS_DATASET_CREATE_ID_g")
         lib.H5Eset_auto2(0, None, None)            # no error-stack printing; return codes are checked below

@@ -259,3 +259,51 @@ def test_extractor_and_export_write_the_reference_layout(tmp_path):
     assert sorted(got) == ["class_biases", "class_weights", "l_answer_word", "l_word", "v_word"]
     np.testing.assert_array_equal(got["class_weights"], sd["classifier/fc/weights"])
     assert MV.load_word_weight_dir(d)["class_biases"].shape == (7,)
+
+
+def _random_tree(rng, depth=0):
+    dts = [np.float32, np.float64, np.int32, np.int64, np.uint8, np.int8, np.int16, np.uint16, np.uint32]
+    tree = {}
+    for i in range(int(rng.integers(1, 6))):
+        name = "n%d_%s" % (i, "".join(rng.choice(list("abcXYZ_09"), size=int(rng.integers(1, 9)))))
+        kind = rng.integers(0, 10)
+        if kind < 2 and depth < 3:
+            tree[name] = _random_tree(rng, depth + 1)
+        elif kind == 2:
+            tree[name] = "".join(rng.choice(list("abc /-_.0123"), size=int(rng.integers(1, 30))))
+        else:
+            dt = dts[int(rng.integers(0, len(dts)))]
+            shape = tuple(int(x) for x in rng.integers(0, 7, size=int(rng.integers(0, 4))))
+            a = rng.integers(-100, 100, size=shape) if np.issubdtype(dt, np.integer) else rng.standard_normal(shape) * 10
+            if np.issubdtype(dt, np.unsignedinteger):
+                a = np.abs(a)
+            tree[name] = np.asarray(a).astype(dt)
+    return tree
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_trees_round_trip_and_are_read_by_libhdf5(tmp_path, seed):
+    """seeded random trees (nested groups, 9 dtypes, 0-d to 3-d shapes with empty axes, strings): our writer ->
+    our reader value for value and dtype for dtype; every numeric dataset is also read back by the real libhdf5"""
+    rng = np.random.default_rng(1000 + seed)
+    tree = _random_tree(rng)
+    p = str(tmp_path / "r.hdf5")
+    H.write(p, tree)
+    with H.File(p) as f:
+        _check_tree(f, tree)
+
+        def walk(t, pre=""):
+            for k, v in t.items():
+                if isinstance(v, dict):
+                    yield from walk(v, pre + k + "/")
+                elif not isinstance(v, str):
+                    yield pre + k, v
+        for name, want in walk(tree):
+            assert np.asarray(f[name]).dtype == want.dtype, name
+    h5 = h5ref.H5() if h5ref.load() is not None else None
+    if h5 is not None:
+        for name, want in walk(tree):
+            if want.size == 0:
+                continue
+            got = h5.read(p, name, want.dtype.newbyteorder("<").str)
+            np.testing.assert_array_equal(got, want, err_msg=name)
