@@ -37,7 +37,8 @@ with tempfile.TemporaryDirectory() as d:
     ds = DV.create_dataset(paths, d, None, is_train=False, boxes=boxes)
     for mode, kw in (("fresh pageable batches", dict(reuse_buffers=False)),
                      ("ring of pageable blocks", dict(reuse_buffers=True)),
-                     ("ring of pinned blocks", dict(reuse_buffers=True, pinned=True))):
+                     ("ring of pinned blocks", dict(reuse_buffers=True, pinned=True)),
+                     ("pinned ring, byte pixels", dict(reuse_buffers=True, pinned=True, image_dtype=np.uint8))):
         ex = VF.Extractor(model, id2idx, ds.get_config().max_roi_num)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

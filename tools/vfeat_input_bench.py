@@ -28,10 +28,13 @@ with tempfile.TemporaryDirectory() as d:
         boxes[p.replace("/", "-")] = b
     ds = DV.create_dataset(paths, d, None, is_train=False, boxes=boxes)
     for w in workers:
-        t0 = time.perf_counter()
-        cnt = 0
-        for b in IO.create(ds, 96, is_train=False, shuffle=False, num_parallel_calls=w, prefetch=3, reuse_buffers=True):
-            cnt += len(b["id"])
-        dt = time.perf_counter() - t0
-        print("%d workers: %d images (640x480 JPEG -> %s) in %.2f s = %.0f imgs/s on %d host cores" % (
-            w, cnt, "x".join(str(x) for x in b["image"].shape[1:]), dt, cnt / dt, os.cpu_count()), flush=True)
+        for dt_img in (np.float32, np.uint8):
+            t0 = time.perf_counter()
+            cnt = 0
+            for b in IO.create(ds, 96, is_train=False, shuffle=False, num_parallel_calls=w, prefetch=3, reuse_buffers=True,
+                               image_dtype=dt_img):
+                cnt += len(b["id"])
+            dt = time.perf_counter() - t0
+            print("%d workers, %s pixels: %d images (640x480 JPEG -> %s) in %.2f s = %.0f imgs/s on %d host cores" % (
+                w, np.dtype(dt_img).name, cnt, "x".join(str(x) for x in b["image"].shape[1:]), dt, cnt / dt, os.cpu_count()),
+                flush=True)

@@ -30,13 +30,16 @@ def _collate(ids, items, images=None):
 
 
 def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=True, seed=123, num_parallel_calls=8,
-           prefetch=10, repeat=1000, reuse_buffers=False, pinned=False):
+           prefetch=10, repeat=1000, reuse_buffers=False, pinned=False, image_dtype=np.float32):
     """reuse_buffers (not in the reference): the image blocks of the batches come from a ring of `prefetch + 2`
     preallocated [B,H,W,3] buffers, so a batch's `image` is only valid until the second next batch is requested (its
     slot is refilled then) -- for consumers that upload each batch before asking for the next (the extractor).
     Fresh memory of that size (336 MB per batch of 96) is page-faulted in at well under 1 GB/s in these VMs, which
     otherwise dominates the loader: 54 -> 496 images/s on 8 cores together with the direct write of the pixels into
-    the batch block (tools/vfeat_input_bench.py).  pinned: the ring is page-locked memory (needs the GPU runtime)."""
+    the batch block (tools/vfeat_input_bench.py).  pinned: the ring is page-locked memory (needs the GPU runtime).
+    image_dtype=np.uint8 (with a dataset that writes into the block): the pixels stay bytes on the host -- a quarter of
+    the upload, and no uint8 -> float32 conversion under the GIL in the loader threads; the consumer converts on the
+    device (vfeat_extractor.device_batches does).  The reference's batches are float32 (input_ops_vfeat.py:40-51)."""
     ids = list(dataset.ids)
     if is_train and shuffle:
         np.random.RandomState(seed).shuffle(ids)
@@ -50,11 +53,12 @@ def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=Tru
         n_ring = max(1, prefetch) + 2
         if pinned:      # page-locked blocks: the consumer's .to(device, non_blocking=True) is an asynchronous DMA
             import torch
-            keep = [torch.empty((batch_size,) + shape, dtype=torch.float32, pin_memory=True) for _ in range(n_ring)]
+            tdt = torch.uint8 if np.dtype(image_dtype) == np.uint8 else torch.float32
+            keep = [torch.empty((batch_size,) + shape, dtype=tdt, pin_memory=True) for _ in range(n_ring)]
             ring = [t.numpy() for t in keep]
             ring_keepalive.extend(keep)
         else:
-            ring = [np.empty((batch_size,) + shape, np.float32) for _ in range(n_ring)]
+            ring = [np.empty((batch_size,) + shape, image_dtype) for _ in range(n_ring)]
     slot = [0]
 
     def gen():
@@ -73,7 +77,7 @@ def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=Tru
                             images = ring[slot[0] % len(ring)][:len(c)]
                             slot[0] += 1
                         else:
-                            images = np.empty((len(c),) + shape, np.float32)
+                            images = np.empty((len(c),) + shape, image_dtype)
                         pending.append((c, [pool.submit(dataset.get_data, i, images[j]) for j, i in enumerate(c)], images))
                     else:
                         pending.append((c, [pool.submit(dataset.get_data, i) for i in c], None))

@@ -45,6 +45,8 @@ def device_batches(batches, device):
     for b in batches:
         out = dict(b)
         out["image"] = torch.from_numpy(b["image"]).to(device, non_blocking=True)
+        if out["image"].dtype != torch.float32:          # byte pixels from the loader: converted here, on the device
+            out["image"] = out["image"].float()
         out["normal_box"] = torch.from_numpy(b["normal_box"]).to(device, non_blocking=True)
         yield out
 
@@ -82,7 +84,7 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device="cuda:0"):
     batches = input_ops_vfeat.create(dataset, config.batch_size, is_train=False, scope="batch_ops", shuffle=False,
                                      num_parallel_calls=int(getattr(config, "num_parallel_calls", 8) or 8),
                                      prefetch=3, reuse_buffers=True,       # each batch is uploaded before the next is drawn
-                                     pinned=torch.cuda.is_available())
+                                     pinned=torch.cuda.is_available(), image_dtype=np.uint8)
     ex = vfeat.Extractor(model, image_info["image_id2idx"], dataset.get_config().max_roi_num,
                          config.pretrained_param_path)
     out = ex.extract(device_batches(batches, device), config.save_path)
