@@ -76,3 +76,40 @@ def test_shard_bounds_cover_and_balance():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vqa_transfer_externaldata_amd import dp
+    flat = torch.arange(40, dtype=torch.float32) * (rank + 1)            # rank r contributes (r + 1) * [0..39]
+    red = dp.BucketedAllReduce(timing=True)
+    # three buckets started one after the other (views of one flat buffer, as FusionEngine.backward hands them over),
+    # one finish(): every bucket is summed in place, nothing is left pending
+    for lo, hi in ((0, 7), (7, 25), (25, 40)):
+        red.start(flat[lo:hi])
+    red.finish()
+    assert red._works == []
+    red.start(flat[0:0])                                                 # an empty bucket is legal
+    red.finish()
+    ms = red.exposed_ms()
+    if rank == 0:
+        out.put((flat.numpy(), len(ms)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_sums_every_bucket_in_place():
+    """dp.BucketedAllReduce (the reducer FusionEngine.backward drives phase by phase) on CPU tensors over gloo: async
+    all-reduces of views of one flat buffer, finish() waits for all of them"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got, n_timed = q.get(timeout=120)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    np.testing.assert_array_equal(got, np.arange(40, dtype=np.float32) * 3)
+    assert n_timed == 0                                                  # no GPU events on the CPU path
