@@ -113,3 +113,37 @@ def test_producer_thread_and_processes_deliver_the_stream_in_order():
     ev = list(DV.create_ops(4, mk(), is_train=False, resident=True, workers=3))
     assert [len(b["image_id"]) for b in ev] == [4, 4, 2]
     np.testing.assert_array_equal(np.concatenate([b["image_id"] for b in ev]), np.asarray(mk().ids, np.int32))
+
+
+def test_export_word_weights_command_line(tmp_path):
+    """vlmap_memft/export_word_weights.py as a command: --checkpoint <run>/model-N -> <run>/word_weights_model-N/ with
+    weights.hdf5 + vocab.pkl + answer_dict.pkl read from --data_dir; refuses to overwrite; checks --class_feat_dim"""
+    import pickle
+    import torch
+    from vqa_transfer_externaldata_amd import export_word_weights as EW, hdf5_io, model_vlmap_answer as MV
+    H2, A, Vq = 16, 7, 11
+    sd = {k: torch.full(s, float(i)) for i, (k, s) in enumerate(PT.variable_shapes(Vq, 5, A, 8, 16, H2 // 2).items())}
+    run = tmp_path / "vlmap_run"
+    data = tmp_path / "data"
+    run.mkdir(); data.mkdir()
+    torch.save(sd, str(run / "model-12"))
+    vocab = {"vocab": ["w%d" % i for i in range(Vq)]}
+    adict = {"vocab": ["a%d" % i for i in range(A)], "dict": {"a%d" % i: i for i in range(A)}}
+    pickle.dump(vocab, open(str(data / "vocab.pkl"), "wb"), protocol=2)
+    pickle.dump(adict, open(str(data / "answer_dict.pkl"), "wb"), protocol=2)
+    c = EW.build_parser().parse_args(["--checkpoint", str(run / "model-12"), "--data_dir", str(data),
+                                      "--class_feat_dim", str(H2)])
+    d = EW.run(c)
+    assert d == str(run / "word_weights_model-12")
+    got = hdf5_io.load_tree(str(run / "word_weights_model-12" / "weights.hdf5"))
+    assert sorted(got) == ["class_biases", "class_weights", "l_answer_word", "l_word", "v_word"]
+    np.testing.assert_array_equal(got["class_weights"], sd["classifier/fc/weights"].numpy())
+    assert pickle.load(open(str(run / "word_weights_model-12" / "answer_dict.pkl"), "rb")) == adict
+    assert MV.load_word_weight_dir(d)["class_biases"].shape == (A,)
+    with pytest.raises(ValueError, match="Do not overwrite"):
+        EW.run(EW.build_parser().parse_args(["--checkpoint", str(run / "model-12"), "--data_dir", str(data),
+                                             "--class_feat_dim", str(H2)]))
+    torch.save(sd, str(run / "model-13"))
+    with pytest.raises(ValueError, match="class_feat_dim"):
+        EW.run(EW.build_parser().parse_args(["--checkpoint", str(run / "model-13"), "--data_dir", str(data)]))
+    assert EW.build_parser().parse_args(["--checkpoint", "x"]).class_feat_dim == 2048
