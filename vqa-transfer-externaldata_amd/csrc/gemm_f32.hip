@@ -1102,6 +1102,16 @@ int g_gru_cfg = -1;
 // Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
 // (2560 rows, T 10: forward 1637 us with 64x64 BK 64, 1550 with BK 32 -- profiles/r2_gru_tune_b2560.txt)
 inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 12 : rows > 256 ? 18 : 16); }
+// The H-wide candidate kernel of a tall batch takes 32x64 tiles: at 2560 rows x 1024 columns the 64x64 tile gives 640
+// tiles (2.5 per CU, a half-empty last round), 32x64 gives 1280 (5 per CU): forward recurrence 1548 -> 1489 us at
+// 2560 rows, T 10.  VQA_HOT_GRU_NARROW_CFG overrides (tuning; -1 = the same config as the gate kernel).
+inline int gru_narrow_override() {
+    static const int v = [] { const char* e = getenv("VQA_HOT_GRU_NARROW_CFG"); return e ? atoi(e) : 9; }();
+    return v;
+}
+inline int gru_cfg_fwd_cand(int rows) {
+    return (g_gru_cfg < 0 && rows >= 2048 && gru_narrow_override() >= 0) ? gru_narrow_override() : gru_cfg_fwd(rows);
+}
 inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 256 ? 18 : 16); }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
@@ -1294,7 +1304,7 @@ extern "C" int vqa_gru_seq_fwd_rows(float* xp, const float* Wg_h, const float* W
         ec.H = H; ec.t = t; ec.len = len + row0; ec.h_prev = hp; ec.i0 = u + t * BH + o; ec.o0 = c + t * BH + o;
         ec.o1 = hs + (t + 1) * BH + o;
         GemmArgs ac = make_args(rows, H, H, rh + t * BH + o, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
-        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(rows), ac, ec, st);
+        rc = launch_gru<EPI_CAND>(gru_cfg_fwd_cand(rows), ac, ec, st);
         if (rc != VQA_OK) return rc;
     }
     return VQA_OK;
@@ -1331,7 +1341,7 @@ extern "C" int vqa_gru_seq_fwd_live(float* xp, const float* Wg_h, const float* W
         ec.H = H; ec.t = t; ec.len = len; ec.h_prev = hp; ec.i0 = u + t * BH; ec.o0 = c + t * BH;
         ec.o1 = hs + (t + 1) * BH;
         GemmArgs ac = make_args(rows, H, H, rh + t * BH, H, Wc_h, H, nullptr, 0, nullptr, xpt + 2 * H, 3 * H);
-        rc = launch_gru<EPI_CAND>(gru_cfg_fwd(rows), ac, ec, st);
+        rc = launch_gru<EPI_CAND>(gru_cfg_fwd_cand(rows), ac, ec, st);
         if (rc != VQA_OK) return rc;
     }
     return vqa_gru_fill_finished(hs, rh, len, T, B, H, stream);
