@@ -88,6 +88,11 @@ struct Layout {
         e.push_back({name, total, n});
         total += ((n * 4 + 255) / 256) * 256;
     }
+    // a named view of `cnt` floats inside an existing entry (the four heads' tensors are slices of stacked blocks)
+    void alias(const std::string& name, const std::string& base, int64_t off_floats, int64_t cnt) {
+        const Entry* b = find(base);
+        e.push_back({name, b->off + off_floats * 4, cnt});
+    }
     const Entry* find(const std::string& name) const {
         for (const auto& x : e)
             if (x.name == name) return &x;
@@ -103,37 +108,51 @@ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 Layout make_layout(const vqa_pretrain_dims_t& d) {
     Layout L;
     const int64_t B = d.B, n = d.n, R = d.R, D = d.D, H = d.H, W = d.W, A = d.A, T = d.L, Bn = B * n;
+    // The four heads (ln = 2 t + k: obj/bf, attr/bf, obj/ws, attr/ws) share pooled_linear_l, q_linear_l, joint_fc and the
+    // classifier, so their rows are stacked and every shared FC is ONE GEMM over 4 Bn (2 Bn for pooled_linear_l) rows:
+    // M = 2560 leaves the last round of tiles half empty (1260 tiles of 128x64 on 512 workgroup slots = 2.46 rounds),
+    // M = 10240 does not (9.84).  The per-head names below are views into the stacked blocks.
+    L.add("S/pooled", 2 * Bn * D); L.add("S/vl_pre", 2 * Bn * H); L.add("S/lft", 4 * Bn * H);
+    L.add("S/vl", 4 * Bn * H); L.add("S/ll_pre", 4 * Bn * H); L.add("S/ll", 4 * Bn * H); L.add("S/jin", 4 * Bn * H);
+    L.add("S/j_pre", 4 * Bn * 2 * H); L.add("S/j", 4 * Bn * 2 * H);
+    L.add("S/z", 4 * Bn * A); L.add("S/dz", 4 * Bn * A); L.add("S/stats", 4 * Bn * 4);
     for (int k = 0; k < 2; ++k) {
         const std::string p = std::string(KIND[k]) + "/";
         L.add(p + "key6", Bn * 6);
         L.add(p + "v_pre", B * R * H); L.add(p + "v", B * R * H); L.add(p + "v_mean", B); L.add(p + "v_rstd", B);
         L.add(p + "qv_pre", Bn * H); L.add(p + "qv", Bn * H); L.add(p + "qv_mean", B); L.add(p + "qv_rstd", B);
-        L.add(p + "att", Bn * R); L.add(p + "pooled", Bn * D); L.add(p + "vl_pre", Bn * H);
+        L.add(p + "att", Bn * R);
+        L.alias(p + "pooled", "S/pooled", k * Bn * D, Bn * D); L.alias(p + "vl_pre", "S/vl_pre", k * Bn * H, Bn * H);
         L.add(p + "valid", Bn); L.add(p + "inv_valid", 4);
         L.add(p + "blanks_s", Bn * T); L.add(p + "lens_s", Bn);
         L.add(p + "x_tm", T * Bn * W); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
         L.add(p + "gru_r", T * Bn * H); L.add(p + "gru_u", T * Bn * H); L.add(p + "gru_c", T * Bn * H);
         L.add(p + "gru_rh", T * Bn * H);
-        L.add(p + "bf_state", Bn * H);
+        L.alias(p + "bf_state", "S/lft", k * Bn * H, Bn * H);
         L.add(p + "wse", Bn * W); L.add(p + "ws", Bn * W);
-        L.add(p + "wf_pre", Bn * H); L.add(p + "wf", Bn * H); L.add(p + "wf_mean", B); L.add(p + "wf_rstd", B);
+        L.add(p + "wf_pre", Bn * H); L.alias(p + "wf", "S/lft", (2 + k) * Bn * H, Bn * H);
+        L.add(p + "wf_mean", B); L.add(p + "wf_rstd", B);
         for (int t = 0; t < 2; ++t) {
             const std::string q = p + HEAD[t] + "/";
-            L.add(q + "vl", Bn * H); L.add(q + "vl_mean", B); L.add(q + "vl_rstd", B);
-            L.add(q + "ll_pre", Bn * H); L.add(q + "ll", Bn * H); L.add(q + "ll_mean", B); L.add(q + "ll_rstd", B);
-            L.add(q + "jin", Bn * H);
-            L.add(q + "j_pre", Bn * 2 * H); L.add(q + "j", Bn * 2 * H); L.add(q + "j_mean", B); L.add(q + "j_rstd", B);
-            L.add(q + "z", Bn * A); L.add(q + "dz", Bn * A); L.add(q + "stats", Bn * 4);
+            const int64_t ln = 2 * t + k;
+            L.alias(q + "vl", "S/vl", ln * Bn * H, Bn * H); L.add(q + "vl_mean", B); L.add(q + "vl_rstd", B);
+            L.alias(q + "ll_pre", "S/ll_pre", ln * Bn * H, Bn * H); L.alias(q + "ll", "S/ll", ln * Bn * H, Bn * H);
+            L.add(q + "ll_mean", B); L.add(q + "ll_rstd", B);
+            L.alias(q + "jin", "S/jin", ln * Bn * H, Bn * H);
+            L.alias(q + "j_pre", "S/j_pre", ln * Bn * 2 * H, Bn * 2 * H); L.alias(q + "j", "S/j", ln * Bn * 2 * H, Bn * 2 * H);
+            L.add(q + "j_mean", B); L.add(q + "j_rstd", B);
+            L.alias(q + "z", "S/z", ln * Bn * A, Bn * A); L.alias(q + "dz", "S/dz", ln * Bn * A, Bn * A);
+            L.alias(q + "stats", "S/stats", ln * Bn * 4, Bn * 4);
         }
     }
     L.add("report", 16);
     // backward scratch, shared by the two categories
-    L.add("d_j", Bn * 2 * H); L.add("d_jpre", Bn * 2 * H); L.add("d_jin", Bn * H);
-    L.add("d_vl", Bn * H); L.add("d_ll", Bn * H); L.add("d_vlpre", Bn * H); L.add("d_vlpre0", Bn * H); L.add("d_llpre", Bn * H);
-    L.add("d_pooled", Bn * D);
-    L.add("d_state", Bn * H); L.add("d_state_s", Bn * H); L.add("d_hscratch", Bn * H);
+    L.add("d_j", 4 * Bn * 2 * H); L.add("d_jpre", 4 * Bn * 2 * H); L.add("d_jin", 4 * Bn * H);
+    L.add("d_vl", 4 * Bn * H); L.add("d_ll", 4 * Bn * H); L.add("d_vlpre", 4 * Bn * H); L.add("d_llpre", 4 * Bn * H);
+    L.add("d_lft", 4 * Bn * H); L.add("d_pooled", 2 * Bn * D);
+    L.add("d_state_s", Bn * H); L.add("d_hscratch", Bn * H);
     L.add("dxp", T * Bn * 3 * H); L.add("dx", T * Bn * W);
-    L.add("d_wf", Bn * H); L.add("d_wfpre", Bn * H); L.add("d_ws", Bn * W); L.add("d_wse", Bn * W);
+    L.add("d_wfpre", Bn * H); L.add("d_ws", Bn * W); L.add("d_wse", Bn * W);
     L.add("d_v", B * R * H); L.add("d_vpre", B * R * H); L.add("d_qv", Bn * H); L.add("d_qvpre", Bn * H);
     L.add("part_a", B * 2 * H); L.add("part_b", B * 2 * H); L.add("part_c", B * 2 * H);
     L.add("part_dw", Bn * H); L.add("part_db", Bn);
@@ -145,7 +164,10 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
         gw = max64(gw, vqa_gemm_workspace_floats(tA, tB, (int)M, (int)N, (int)K, 0));
     };
     g(0, 0, B * R, H, 6); g(0, 0, Bn, H, 6); g(0, 0, Bn, H, D); g(0, 0, Bn, H, H); g(0, 0, Bn, 2 * H, H);
-    g(0, 0, Bn, A, 2 * H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
+    g(0, 0, Bn, A, 2 * H);
+    g(0, 0, 2 * Bn, H, D); g(0, 0, 4 * Bn, H, H); g(0, 0, 4 * Bn, 2 * H, H); g(0, 0, 4 * Bn, A, 2 * H);      // stacked heads
+    g(1, 0, 2 * H, A, 4 * Bn); g(0, 1, 4 * Bn, 2 * H, A); g(1, 0, H, 2 * H, 4 * Bn); g(0, 1, 4 * Bn, H, 2 * H);
+    g(1, 0, D, H, 2 * Bn); g(0, 1, 2 * Bn, D, H); g(1, 0, H, H, 4 * Bn); g(0, 1, 4 * Bn, H, H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
     g(1, 0, 2 * H, A, Bn); g(0, 1, Bn, 2 * H, A); g(1, 0, H, 2 * H, Bn); g(0, 1, Bn, H, 2 * H); g(1, 0, D, H, Bn);
     g(0, 1, Bn, D, H); g(1, 0, H, H, Bn); g(0, 1, Bn, H, H); g(1, 0, W, H, Bn); g(0, 1, Bn, W, H);
     g(1, 0, W, 2 * H, T * Bn); g(1, 0, H, 2 * H, T * Bn); g(1, 0, W, H, T * Bn); g(1, 0, H, H, T * Bn);
@@ -154,6 +176,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     int64_t cw = 4;
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)(2 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)Bn, (int)A));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)(4 * Bn), (int)A));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * Bn), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)Bn, (int)H));
     L.add("colsum_ws", 3 * cw);
@@ -243,6 +266,16 @@ int ln_bwd(const Ctx& c, Acc& acc, const float* dy, int64_t M, int64_t N, const 
     return acc.colsum3(c.f("part_a"), c.f("part_b"), c.f("part_c"), G, N, g.gamma[ln], g.beta[ln], g.b);
 }
 
+// the same on pointers (slices of the stacked head blocks)
+int ln_bwd_p(const Ctx& c, Acc& acc, const float* dy, int64_t M, int64_t N, const vqa_pt_fc_t& p, const vqa_pt_fc_t& g, int ln,
+             int rows, int act, const float* pre, const float* mean, const float* rstd, const uint8_t* keep, float keep_prob,
+             float* d_pre) {
+    const int64_t G = M / rows;
+    TRY(vqa_ln_act_bwd(dy, pre, mean, rstd, p.gamma[ln], p.beta[ln], keep, keep_prob, d_pre, c.f("part_a"), c.f("part_b"),
+                       c.f("part_c"), (int)G, rows, (int)N, act, c.st));
+    return acc.colsum3(c.f("part_a"), c.f("part_b"), c.f("part_c"), G, N, g.gamma[ln], g.beta[ln], g.b);
+}
+
 // backward of the FC half: dW (+)= x^T d_pre, optional dx = d_pre * W^T
 int fc_bwd(const Ctx& c, Acc& acc, const std::string& d_pre, const float* x, int64_t M, int64_t K, int64_t N,
            const vqa_pt_fc_t& p, const vqa_pt_fc_t& g, float* dx) {
@@ -327,30 +360,6 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
                            (int)B, (int)n);
         VQA_CHECK_LAUNCH();
 
-        auto head = [&](int t, const float* l_ft, const uint8_t* jmask) -> int {
-            const std::string q = p + HEAD[t] + "/";
-            const int ln = (t == 0) ? k : 2 + k;
-            // pooled_linear_l: both heads of a kind apply the SAME FC to the same pooled features (only the LayerNorm
-            // parameters differ, modules.fc_layer's scope per head), so the product is computed once per kind
-            if (t == 0)
-                TRY(c.gemm(0, 0, Bn, H, D, c.f(p + "pooled"), (int)D, P->pooled_linear_l.w, (int)H, c.f(p + "vl_pre"), (int)H,
-                           P->pooled_linear_l.b));
-            TRY(vqa_ln_act_fwd(c.f(p + "vl_pre"), P->pooled_linear_l.gamma[ln], P->pooled_linear_l.beta[ln], nullptr, 1.f,
-                               c.f(q + "vl"), c.f(q + "vl_mean"), c.f(q + "vl_rstd"), (int)B, (int)n, (int)H, 0, c.st));
-            TRY(fc_ln_fwd(c, l_ft, Bn, H, H, P->q_linear_l, ln, (int)n, 0, q + "ll_pre", q + "ll", q + "ll_mean",
-                          q + "ll_rstd", nullptr, 1.f));
-            TRY(vqa_mul(c.f(q + "vl"), c.f(q + "ll"), c.f(q + "jin"), Bn * H, c.st));
-            TRY(fc_ln_fwd(c, c.f(q + "jin"), Bn, H, 2 * H, P->joint_fc, ln, (int)n, 0, q + "j_pre", q + "j", q + "j_mean",
-                          q + "j_rstd", jmask, dims->keep_joint));
-            TRY(c.gemm(0, 0, Bn, A, 2 * H, c.f(q + "j"), (int)(2 * H), P->classifier.w, (int)A, c.f(q + "z"), (int)A,
-                       P->classifier.b));
-            TRY(vqa_softmax_ce_fwd(c.f(q + "z"), kb.fills, c.f(p + "valid"), 5, c.f(p + "inv_valid"), c.f(q + "stats"),
-                                   want_dz ? c.f(q + "dz") : nullptr, (int)Bn, (int)A, c.st));
-            ra.stats[2 * k + t] = c.f(q + "stats");
-            ra.inv[2 * k + t] = c.f(p + "inv_valid");
-            return VQA_OK;
-        };
-
         // ---- build_*_blank_fill: captions in length order when the host sorted them (live prefix recurrence)
         TRY(gather_rows(kb.blanks, kb.perm, c.i32(p + "blanks_s"), Bn, T, c.st));
         TRY(gather_rows(kb.blanks_len, kb.perm, c.i32(p + "lens_s"), Bn, 1, c.st));
@@ -369,13 +378,52 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
             TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
                                 c.f(p + "gru_c"), c.f(p + "gru_rh"), (int)T, (int)Bn, (int)H, c.st));
         TRY(gather_rows(hs + T * Bn * H, kb.inv, c.f(p + "bf_state"), Bn, H, c.st));      // back to caption order
-        TRY(head(0, c.f(p + "bf_state"), kb.keep_bf_joint));
         // ---- build_*_wordset
         TRY(vqa_embed_fwd(P->wordset_map, kb.wordsets, c.f(p + "wse"), (int)Bn, 1, (int)W, dims->n_ws, c.st));
         TRY(vqa_tanh_fwd(c.f(p + "wse"), c.f(p + "ws"), Bn * W, c.st));
         TRY(fc_ln_fwd(c, c.f(p + "ws"), Bn, W, H, P->wordset_ft, k, (int)n, 1, p + "wf_pre", p + "wf", p + "wf_mean",
                       p + "wf_rstd", nullptr, 1.f));
-        TRY(head(1, c.f(p + "wf"), kb.keep_ws_joint));
+    }
+    // ---- the four heads, stacked (ln = 2 t + k; see make_layout): every shared FC is one GEMM, LayerNorm (its own
+    // gamma / beta per head) and the loss run per slice
+    {
+        const int64_t SH = Bn * H, SJ = Bn * 2 * H, SA = Bn * A;
+        auto hname = [&](int ln) { return std::string(KIND[ln & 1]) + "/" + HEAD[ln >> 1] + "/"; };
+        // pooled_linear_l: both heads of a category apply the SAME FC to the same pooled features, so the product is
+        // computed once per category (2 Bn rows)
+        TRY(c.gemm(0, 0, 2 * Bn, H, D, c.f("S/pooled"), (int)D, P->pooled_linear_l.w, (int)H, c.f("S/vl_pre"), (int)H,
+                   P->pooled_linear_l.b));
+        TRY(c.gemm(0, 0, 4 * Bn, H, H, c.f("S/lft"), (int)H, P->q_linear_l.w, (int)H, c.f("S/ll_pre"), (int)H, P->q_linear_l.b));
+        for (int ln = 0; ln < 4; ++ln) {
+            const std::string q = hname(ln);
+            TRY(vqa_ln_act_fwd(c.f("S/vl_pre") + (ln & 1) * SH, P->pooled_linear_l.gamma[ln], P->pooled_linear_l.beta[ln],
+                               nullptr, 1.f, c.f("S/vl") + ln * SH, c.f(q + "vl_mean"), c.f(q + "vl_rstd"), (int)B, (int)n,
+                               (int)H, 0, c.st));
+            TRY(vqa_ln_act_fwd(c.f("S/ll_pre") + ln * SH, P->q_linear_l.gamma[ln], P->q_linear_l.beta[ln], nullptr, 1.f,
+                               c.f("S/ll") + ln * SH, c.f(q + "ll_mean"), c.f(q + "ll_rstd"), (int)B, (int)n, (int)H, 0, c.st));
+        }
+        TRY(vqa_mul(c.f("S/vl"), c.f("S/ll"), c.f("S/jin"), 4 * SH, c.st));
+        TRY(c.gemm(0, 0, 4 * Bn, 2 * H, H, c.f("S/jin"), (int)H, P->joint_fc.w, (int)(2 * H), c.f("S/j_pre"), (int)(2 * H),
+                   P->joint_fc.b));
+        for (int ln = 0; ln < 4; ++ln) {
+            const std::string q = hname(ln);
+            const vqa_pretrain_kind_t& kb = bt->kind[ln & 1];
+            const uint8_t* jmask = (ln >> 1) == 0 ? kb.keep_bf_joint : kb.keep_ws_joint;
+            TRY(vqa_ln_act_fwd(c.f("S/j_pre") + ln * SJ, P->joint_fc.gamma[ln], P->joint_fc.beta[ln], jmask, dims->keep_joint,
+                               c.f("S/j") + ln * SJ, c.f(q + "j_mean"), c.f(q + "j_rstd"), (int)B, (int)n, (int)(2 * H), 0,
+                               c.st));
+        }
+        TRY(c.gemm(0, 0, 4 * Bn, A, 2 * H, c.f("S/j"), (int)(2 * H), P->classifier.w, (int)A, c.f("S/z"), (int)A,
+                   P->classifier.b));
+        for (int ln = 0; ln < 4; ++ln) {
+            const int k = ln & 1, t = ln >> 1;
+            const std::string p = std::string(KIND[k]) + "/";
+            TRY(vqa_softmax_ce_fwd(c.f("S/z") + ln * SA, bt->kind[k].fills, c.f(p + "valid"), 5, c.f(p + "inv_valid"),
+                                   c.f("S/stats") + ln * Bn * 4, want_dz ? c.f("S/dz") + ln * SA : nullptr, (int)Bn, (int)A,
+                                   c.st));
+            ra.stats[2 * k + t] = c.f("S/stats") + ln * Bn * 4;
+            ra.inv[2 * k + t] = c.f(p + "inv_valid");
+        }
     }
     hipLaunchKernelGGL(pretrain_report_kernel, dim3(1), dim3(256), 0, c.st, ra, c.f("report"));
     VQA_CHECK_LAUNCH();
@@ -401,32 +449,45 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         sq_prev = c.f("sq");
         return VQA_OK;
     };
+    // ---- the four heads, stacked (ln = 2 t + k): every shared FC's dW and dx is one GEMM over the 4 Bn rows
+    {
+        const int64_t SH = Bn * H, SJ = Bn * 2 * H;
+        auto hname = [&](int ln) { return std::string(KIND[ln & 1]) + "/" + HEAD[ln >> 1] + "/"; };
+        TRY(acc.weight(G->classifier.w, c.f("S/j"), (int)(2 * H), c.f("S/dz"), (int)A, 2 * H, A, 4 * Bn));
+        TRY(acc.colsum(c.f("S/dz"), 4 * Bn, A, (int)A, G->classifier.b));
+        TRY(c.gemm(0, 1, 4 * Bn, 2 * H, A, c.f("S/dz"), (int)A, P->classifier.w, (int)A, c.f("d_j"), (int)(2 * H)));
+        for (int ln = 0; ln < 4; ++ln) {
+            const std::string q = hname(ln);
+            const vqa_pretrain_kind_t& kb = bt->kind[ln & 1];
+            const uint8_t* jmask = (ln >> 1) == 0 ? kb.keep_bf_joint : kb.keep_ws_joint;
+            TRY(ln_bwd_p(c, acc, c.f("d_j") + ln * SJ, Bn, 2 * H, P->joint_fc, G->joint_fc, ln, (int)n, 0,
+                         c.f("S/j_pre") + ln * SJ, c.f(q + "j_mean"), c.f(q + "j_rstd"), jmask, dims->keep_joint,
+                         c.f("d_jpre") + ln * SJ));
+        }
+        TRY(fc_bwd(c, acc, "d_jpre", c.f("S/jin"), 4 * Bn, H, 2 * H, P->joint_fc, G->joint_fc, c.f("d_jin")));
+        TRY(vqa_mul_bwd(c.f("d_jin"), c.f("S/vl"), c.f("S/ll"), c.f("d_vl"), c.f("d_ll"), 4 * SH, c.st));
+        for (int ln = 0; ln < 4; ++ln) {
+            const std::string q = hname(ln);
+            TRY(ln_bwd_p(c, acc, c.f("d_vl") + ln * SH, Bn, H, P->pooled_linear_l, G->pooled_linear_l, ln, (int)n, 0,
+                         c.f("S/vl_pre") + (ln & 1) * SH, c.f(q + "vl_mean"), c.f(q + "vl_rstd"), nullptr, 1.f,
+                         c.f("d_vlpre") + ln * SH));
+            TRY(ln_bwd_p(c, acc, c.f("d_ll") + ln * SH, Bn, H, P->q_linear_l, G->q_linear_l, ln, (int)n, 0,
+                         c.f("S/ll_pre") + ln * SH, c.f(q + "ll_mean"), c.f(q + "ll_rstd"), nullptr, 1.f,
+                         c.f("d_llpre") + ln * SH));
+        }
+        // pooled_linear_l's product is shared by the two heads of a category: their d_pre (slices k and 2 + k) meet
+        // before ONE dW and ONE dx GEMM over the 2 Bn pooled rows
+        TRY(vqa_add_inplace(c.f("d_vlpre"), c.f("d_vlpre") + 2 * SH, 2 * SH, c.st));
+        TRY(acc.weight(G->pooled_linear_l.w, c.f("S/pooled"), (int)D, c.f("d_vlpre"), (int)H, D, H, 2 * Bn));
+        TRY(c.gemm(0, 1, 2 * Bn, D, H, c.f("d_vlpre"), (int)H, P->pooled_linear_l.w, (int)H, c.f("d_pooled"), (int)D));
+        TRY(fc_bwd(c, acc, "d_llpre", c.f("S/lft"), 4 * Bn, H, H, P->q_linear_l, G->q_linear_l, c.f("d_lft")));
+    }
     for (int k = 0; k < 2; ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         const std::string p = std::string(KIND[k]) + "/";
-        auto head_bwd = [&](int t, const float* l_ft, const uint8_t* jmask, float* d_lft) -> int {
-            const std::string q = p + HEAD[t] + "/";
-            const int ln = (t == 0) ? k : 2 + k;
-            TRY(acc.weight(G->classifier.w, c.f(q + "j"), (int)(2 * H), c.f(q + "dz"), (int)A, 2 * H, A, Bn));
-            TRY(acc.colsum(c.f(q + "dz"), Bn, A, (int)A, G->classifier.b));
-            TRY(c.gemm(0, 1, Bn, 2 * H, A, c.f(q + "dz"), (int)A, P->classifier.w, (int)A, c.f("d_j"), (int)(2 * H)));
-            TRY(fc_ln_bwd(c, acc, c.f("d_j"), c.f(q + "jin"), Bn, H, 2 * H, P->joint_fc, G->joint_fc, ln, (int)n, 0,
-                          q + "j_pre", q + "j_mean", q + "j_rstd", jmask, dims->keep_joint, "d_jpre", c.f("d_jin")));
-            TRY(vqa_mul_bwd(c.f("d_jin"), c.f(q + "vl"), c.f(q + "ll"), c.f("d_vl"), c.f("d_ll"), Bn * H, c.st));
-            // the shared product's gradient: the two heads' d_pre meet before ONE dW and ONE dx GEMM per kind
-            TRY(ln_bwd(c, acc, c.f("d_vl"), Bn, H, P->pooled_linear_l, G->pooled_linear_l, ln, (int)n, 0, p + "vl_pre",
-                       q + "vl_mean", q + "vl_rstd", nullptr, 1.f, t == 0 ? "d_vlpre0" : "d_vlpre"));
-            if (t == 1) {
-                TRY(vqa_add_inplace(c.f("d_vlpre"), c.f("d_vlpre0"), Bn * H, c.st));
-                TRY(fc_bwd(c, acc, "d_vlpre", c.f(p + "pooled"), Bn, D, H, P->pooled_linear_l, G->pooled_linear_l,
-                           c.f("d_pooled")));
-            }
-            return fc_ln_bwd(c, acc, c.f("d_ll"), l_ft, Bn, H, H, P->q_linear_l, G->q_linear_l, ln, (int)n, 0, q + "ll_pre",
-                             q + "ll_mean", q + "ll_rstd", nullptr, 1.f, "d_llpre", d_lft);
-        };
+        const float* d_pooled = c.f("d_pooled") + k * Bn * D;
         // ---- blank fill -> GRU -> L_GloVe
-        TRY(head_bwd(0, c.f(p + "bf_state"), kb.keep_bf_joint, c.f("d_state")));
-        TRY(gather_rows(c.f("d_state"), kb.perm, c.f("d_state_s"), Bn, H, c.st));          // into the sorted order
+        TRY(gather_rows(c.f("d_lft") + k * Bn * H, kb.perm, c.f("d_state_s"), Bn, H, c.st));   // into the sorted order
         const float* Wg_h = P->gru_wg + W * 2 * H;
         const float* Wc_h = P->gru_wc + W * H;
         float* dxp = c.f("dxp");
@@ -452,15 +513,14 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
                                   dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
         TRY(add_slice_sq(dx, T * Bn * W));
         // ---- word set -> wordset_ft -> tanh -> wordset_map
-        TRY(head_bwd(1, c.f(p + "wf"), kb.keep_ws_joint, c.f("d_wf")));
-        TRY(fc_ln_bwd(c, acc, c.f("d_wf"), c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, k, (int)n, 1, p + "wf_pre",
+        TRY(fc_ln_bwd(c, acc, c.f("d_lft") + (2 + k) * Bn * H, c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, k, (int)n, 1, p + "wf_pre",
                       p + "wf_mean", p + "wf_rstd", nullptr, 1.f, "d_wfpre", c.f("d_ws")));
         TRY(vqa_tanh_bwd(c.f("d_ws"), c.f(p + "ws"), c.f("d_wse"), Bn * W, c.st));
         TRY(vqa_embed_bwd_len_det(c.f("d_wse"), kb.wordsets, nullptr, G->wordset_map, (int)Bn, 1, (int)W, dims->n_ws,
                                   (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
         TRY(add_slice_sq(c.f("d_wse"), Bn * W));
         // ---- spatial attention
-        TRY(vqa_attn_pool_bwd_rep(c.f("d_pooled"), c.f(p + "v"), c.f(p + "qv"), bt->image_ft, c.f(p + "att"),
+        TRY(vqa_attn_pool_bwd_rep(d_pooled, c.f(p + "v"), c.f(p + "qv"), bt->image_ft, c.f(p + "att"),
                                   P->spat_att_score.w, kb.keep_att, dims->keep_att, c.f("d_v"), c.f("d_qv"),
                                   c.f("part_dw"), c.f("part_db"), (int)B, (int)n, (int)R, (int)H, (int)D, c.st));
         TRY(acc.colsum(c.f("part_dw"), Bn, H, (int)H, G->spat_att_score.w));
