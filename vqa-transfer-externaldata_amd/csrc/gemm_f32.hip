@@ -1101,7 +1101,13 @@ int g_conv_cfg_plain = -1;
 int g_gru_cfg = -1;
 // Tall batches (the pre-training model runs 2560 rows per step) fill the chip with plain 4-wave tiles.
 // (2560 rows, T 10: forward 1637 us with 64x64 BK 64, 1550 with BK 32 -- profiles/r2_gru_tune_b2560.txt)
-inline int gru_cfg_fwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 12 : rows > 256 ? 18 : 16); }
+// Between 512 and 2048 rows (the live prefix of the pre-training model's 2560-row recurrence passes through all of
+// them) one 16-wave workgroup per CU is no longer the best form: 32x64 / 4-wave tiles forward (768 rows: 693 -> 565 us,
+// 1536 rows: 1072 -> 961 us per 10 steps) and 64x32 tiles of 8 waves backward (632 -> 559, 995 -> 869);
+// profiles/r2_gru_tune_rows.txt.
+inline int gru_cfg_fwd(int rows) {
+    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 12 : rows > 512 ? 9 : rows > 256 ? 18 : 16);
+}
 // The H-wide candidate kernel of a tall batch takes 32x64 tiles: at 2560 rows x 1024 columns the 64x64 tile gives 640
 // tiles (2.5 per CU, a half-empty last round), 32x64 gives 1280 (5 per CU): forward recurrence 1548 -> 1489 us at
 // 2560 rows, T 10.  VQA_HOT_GRU_NARROW_CFG overrides (tuning; -1 = the same config as the gate kernel).
@@ -1112,7 +1118,9 @@ inline int gru_narrow_override() {
 inline int gru_cfg_fwd_cand(int rows) {
     return (g_gru_cfg < 0 && rows >= 2048 && gru_narrow_override() >= 0) ? gru_narrow_override() : gru_cfg_fwd(rows);
 }
-inline int gru_cfg_bwd(int rows) { return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 256 ? 18 : 16); }
+inline int gru_cfg_bwd(int rows) {
+    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 512 ? 17 : rows > 256 ? 18 : 16);
+}
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
 //  * dW-type (reduction over the batch rows, K huge, M x N small): 128x128 tiles, BK 16, EIGHT waves
