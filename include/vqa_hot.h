@@ -141,6 +141,12 @@ int64_t vqa_colsum_workspace_floats(int M, int N);
  * fc_layer, vlmap/modules.py:630-650); workspace >= 3 * vqa_colsum_workspace_floats(M, N). */
 int vqa_colsum3(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0, float* out1,
                 float* out2, float* workspace, int64_t workspace_floats, void* stream);
+/* the same with accumulation: out (+)= column sums.  vqa_colsum_acc: accumulate != 0 adds; vqa_colsum3_acc: bit i of
+ * acc_mask adds into out_i.  (Gradients of variables shared by several call sites: the cfg-5 model's heads.) */
+int vqa_colsum_acc(const float* X, int M, int N, int ldx, float* out, int accumulate, float* workspace,
+                   int64_t workspace_floats, void* stream);
+int vqa_colsum3_acc(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0, float* out1,
+                    float* out2, int acc_mask, float* workspace, int64_t workspace_floats, void* stream);
 /* z = a * b elementwise (pooled_linear_l * l_linear_l, vqa/model_vlmap_answer.py:177) */
 int vqa_mul(const float* a, const float* b, float* z, int64_t n, void* stream);
 /* da = dz*b ; db = dz*a */

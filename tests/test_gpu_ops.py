@@ -323,6 +323,32 @@ def test_colsum_and_sumsq_and_mask():
         assert torch.equal(view, m1[:n])
 
 
+@pytest.mark.parametrize("M,N", [(7, 40), (512, 1024), (25600, 300), (3, 5)])
+def test_colsum_accumulating_forms(M, N):
+    """vqa_colsum_acc / vqa_colsum3_acc: out (+)= column sums, chosen per output; one- and two-pass reductions"""
+    import ctypes as C
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N)
+    Xs = [dev(rng.standard_normal((M, N)).astype(np.float32)) for _ in range(3)]
+    base = [dev(rng.standard_normal(N).astype(np.float32)) for _ in range(3)]
+    P = lambda t: C.c_void_p(t.data_ptr())
+    wsn = 3 * int(lib.vqa_colsum_workspace_floats(M, N)) + 4
+    ws = torch.empty(wsn, device="cuda")
+    plain = [ops.colsum(x) for x in Xs]
+    for mask in (0, 5, 7, 2):
+        outs = [b.clone() for b in base]
+        _lib.check(lib.vqa_colsum3_acc(P(Xs[0]), P(Xs[1]), P(Xs[2]), M, N, N, P(outs[0]), P(outs[1]), P(outs[2]), mask,
+                                       P(ws), wsn, None), "vqa_colsum3_acc")
+        for i in range(3):
+            want = plain[i] + base[i] if (mask >> i) & 1 else plain[i]
+            assert torch.equal(outs[i], want), (mask, i)
+    for acc in (0, 1):
+        out = base[0].clone()
+        _lib.check(lib.vqa_colsum_acc(P(Xs[0]), M, N, N, P(out), acc, P(ws), wsn, None), "vqa_colsum_acc")
+        assert torch.equal(out, plain[0] + base[0] if acc else plain[0])
+
+
 def test_errors_are_reported_not_swallowed():
     from vqa_transfer_externaldata_amd import VqaHotError
     a = torch.zeros(4, 4, device="cuda")

@@ -118,6 +118,8 @@ SIGNATURES = {
     "vqa_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
     "vqa_colsum_workspace_floats": (_L, [_I, _I]),
     "vqa_colsum3": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
+    "vqa_colsum_acc": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "vqa_colsum3_acc": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P]),
     "vqa_mul": (_I, [_P, _P, _P, _L, _P]),
     "vqa_mul_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "vqa_add_inplace": (_I, [_P, _P, _L, _P]),

@@ -234,25 +234,18 @@ struct Acc {
         const bool first = touched.insert(gw).second;
         return c.gemm(1, 0, K, N, M, x, ldx, dpre, ldp, gw, (int)N, nullptr, first ? nullptr : gw, (int)N);
     }
-    // three column sums (d_gamma, d_beta, d_bias partials [G, N]) into their gradients
+    // three column sums (d_gamma, d_beta, d_bias partials [G, N]) into their gradients: first touch overwrites, later
+    // ones add inside the reduction's last pass (no temporaries, no add kernels)
     int colsum3(const float* p0, const float* p1, const float* p2, int64_t G, int64_t N, float* g0, float* g1, float* g2) {
-        const bool f0 = touched.count(g0) == 0, f1 = touched.count(g1) == 0, f2 = touched.count(g2) == 0;
-        float* o0 = f0 ? g0 : c.f("vec_a");
-        float* o1 = f1 ? g1 : c.f("vec_b");
-        float* o2 = f2 ? g2 : c.f("vec_c");
-        TRY(vqa_colsum3(p0, p1, p2, (int)G, (int)N, (int)N, o0, o1, o2, c.f("colsum_ws"), c.count("colsum_ws"), c.st));
-        if (!f0) TRY(vqa_add_inplace(g0, o0, N, c.st));
-        if (!f1) TRY(vqa_add_inplace(g1, o1, N, c.st));
-        if (!f2) TRY(vqa_add_inplace(g2, o2, N, c.st));
+        const int mask = (touched.count(g0) ? 1 : 0) | (touched.count(g1) ? 2 : 0) | (touched.count(g2) ? 4 : 0);
+        TRY(vqa_colsum3_acc(p0, p1, p2, (int)G, (int)N, (int)N, g0, g1, g2, mask, c.f("colsum_ws"), c.count("colsum_ws"),
+                            c.st));
         touched.insert(g0); touched.insert(g1); touched.insert(g2);
         return VQA_OK;
     }
     int colsum(const float* X, int64_t M, int64_t N, int ldx, float* grad) {
         const bool first = touched.insert(grad).second;
-        float* o = first ? grad : c.f("vec_a");
-        TRY(vqa_colsum(X, (int)M, (int)N, ldx, o, c.f("colsum_ws"), c.count("colsum_ws"), c.st));
-        if (!first) TRY(vqa_add_inplace(grad, o, N, c.st));
-        return VQA_OK;
+        return vqa_colsum_acc(X, (int)M, (int)N, ldx, grad, first ? 0 : 1, c.f("colsum_ws"), c.count("colsum_ws"), c.st);
     }
 };
 

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gru_zero_finished_kernel(float* __restric
 // ------------------------------------------------------------------ column sums
 // partial[y][n] = sum over the rows of chunk y.  Block = 64 columns x 4 row lanes.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                     float* __restrict__ out, int rows_per_chunk) {
+                                                     float* __restrict__ out, int rows_per_chunk, int accumulate = 0) {
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
@@ -259,12 +259,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         for (int m = m0 + ry; m < m1; m += 4) s += X[(int64_t)m * ldx + col];
     red[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && col < N) out[(int64_t)blockIdx.y * N + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+    if (ry == 0 && col < N) {
+        const float v = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        float* o = out + (int64_t)blockIdx.y * N + col;
+        *o = accumulate ? *o + v : v;           // accumulate: single-chunk / final pass only (one writer per column)
+    }
 }
 
 // three equally shaped matrices per launch (blockIdx.z): the (d_gamma, d_beta, d_bias) partials of one
 // LayerNorm block -- these reductions are launch-latency bound, so batching them is the whole gain
-struct Colsum3 { const float* X[3]; float* out[3]; };
+struct Colsum3 { const float* X[3]; float* out[3]; int acc[3]; };
 __global__ __launch_bounds__(256) void colsum3_kernel(Colsum3 a, int M, int N, int ldx, int64_t out_stride_rows,
                                                       int rows_per_chunk) {
     __shared__ float red[4][64];
@@ -278,8 +282,11 @@ __global__ __launch_bounds__(256) void colsum3_kernel(Colsum3 a, int M, int N, i
         for (int m = m0 + ry; m < m1; m += 4) s += X[(int64_t)m * ldx + col];
     red[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && col < N)
-        out[(int64_t)blockIdx.y * out_stride_rows + col] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+    if (ry == 0 && col < N) {
+        const float v = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        float* o = out + (int64_t)blockIdx.y * out_stride_rows + col;
+        *o = a.acc[blockIdx.z] ? *o + v : v;
+    }
 }
 
 // ------------------------------------------------------------------ dropout keep-mask
@@ -507,34 +514,47 @@ extern "C" int64_t vqa_colsum_workspace_floats(int M, int N) {
     const int ch = colsum_chunks(M);
     return ch > 1 ? (int64_t)ch * N : 0;
 }
-extern "C" int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
-                          int64_t workspace_floats, void* stream) {
+extern "C" int vqa_colsum_acc(const float* X, int M, int N, int ldx, float* out, int accumulate, float* workspace,
+                              int64_t workspace_floats, void* stream) {
     VQA_REQUIRE(X && out && M >= 0 && N > 0 && ldx >= N, VQA_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const int ch = colsum_chunks(std::max(M, 1));
     const int gx = (N + 63) / 64;
+    const int acc = accumulate ? 1 : 0;
     if (ch == 1 || workspace == nullptr) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, X, M, N, ldx, out, std::max(M, 1));
+        hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, X, M, N, ldx, out, std::max(M, 1), acc);
         VQA_CHECK_LAUNCH();
         return VQA_OK;
     }
     VQA_REQUIRE(workspace_floats >= (int64_t)ch * N, VQA_ERR_WORKSPACE);
     const int rpc = (int)cdiv(M, ch);
     const int ch2 = (int)cdiv(M, rpc);
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, ch2), dim3(256), 0, st, X, M, N, ldx, workspace, rpc);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, ch2), dim3(256), 0, st, X, M, N, ldx, workspace, rpc, 0);
     VQA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, ch2, N, N, out, ch2);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, ch2, N, N, out, ch2, acc);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
 
+extern "C" int vqa_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+                          int64_t workspace_floats, void* stream) {
+    return vqa_colsum_acc(X, M, N, ldx, out, 0, workspace, workspace_floats, stream);
+}
+
 extern "C" int vqa_colsum3(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0,
                            float* out1, float* out2, float* workspace, int64_t workspace_floats, void* stream) {
+    return vqa_colsum3_acc(X0, X1, X2, M, N, ldx, out0, out1, out2, 0, workspace, workspace_floats, stream);
+}
+
+extern "C" int vqa_colsum3_acc(const float* X0, const float* X1, const float* X2, int M, int N, int ldx, float* out0,
+                               float* out1, float* out2, int acc_mask, float* workspace, int64_t workspace_floats,
+                               void* stream) {
     VQA_REQUIRE(X0 && X1 && X2 && out0 && out1 && out2 && M >= 0 && N > 0 && ldx >= N, VQA_ERR_ARG);
     hipStream_t st = (hipStream_t)stream;
     const int ch = colsum_chunks(std::max(M, 1));
     const int gx = (N + 63) / 64;
-    Colsum3 a{{X0, X1, X2}, {out0, out1, out2}};
+    const int a0 = acc_mask & 1, a1 = (acc_mask >> 1) & 1, a2 = (acc_mask >> 2) & 1;
+    Colsum3 a{{X0, X1, X2}, {out0, out1, out2}, {a0, a1, a2}};
     if (ch == 1) {
         hipLaunchKernelGGL(colsum3_kernel, dim3(gx, 1, 3), dim3(256), 0, st, a, M, N, ldx, (int64_t)N, std::max(M, 1));
         VQA_CHECK_LAUNCH();
@@ -544,10 +564,10 @@ extern "C" int vqa_colsum3(const float* X0, const float* X1, const float* X2, in
     const int rpc = (int)cdiv(M, ch);
     const int ch2 = (int)cdiv(M, rpc);
     const int64_t zs = (int64_t)ch * N;
-    Colsum3 p1{{X0, X1, X2}, {workspace, workspace + zs, workspace + 2 * zs}};
+    Colsum3 p1{{X0, X1, X2}, {workspace, workspace + zs, workspace + 2 * zs}, {0, 0, 0}};
     hipLaunchKernelGGL(colsum3_kernel, dim3(gx, ch2, 3), dim3(256), 0, st, p1, M, N, ldx, (int64_t)N, rpc);
     VQA_CHECK_LAUNCH();
-    Colsum3 p2{{workspace, workspace + zs, workspace + 2 * zs}, {out0, out1, out2}};
+    Colsum3 p2{{workspace, workspace + zs, workspace + 2 * zs}, {out0, out1, out2}, {a0, a1, a2}};
     hipLaunchKernelGGL(colsum3_kernel, dim3(gx, 1, 3), dim3(256), 0, st, p2, ch2, N, N, (int64_t)N, ch2);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
