@@ -310,6 +310,10 @@ def test_colsum_and_sumsq_and_mask():
     m2 = ops.dropout_mask(1 << 20, 123, 0, 0.8, "cuda")
     m3 = ops.dropout_mask(1 << 19, 123, 1 << 19, 0.8, "cuda")
     assert torch.equal(m1, m2) and torch.equal(m1[1 << 19:], m3)                  # counter based
+    for off in (1, 2, 3, 5, 4096 + 7):                                            # ... at any offset, not only aligned ones
+        assert torch.equal(ops.dropout_mask(1000, 123, off, 0.8, "cuda"), m1[off:off + 1000]), off
+    assert float(ops.dropout_mask(1 << 16, 9, 0, 1.0, "cuda").float().min()) == 1.0
+    assert float(ops.dropout_mask(1 << 16, 9, 0, 0.5, "cuda").float().mean()) == pytest.approx(0.5, abs=1e-2)
     assert abs(float(m1.float().mean()) - 0.8) < 5e-3
     # ragged length and an unaligned destination give the same stream of bits as the 16-byte-store form
     big = torch.zeros((1 << 12) + 64, dtype=torch.uint8, device="cuda")

@@ -34,11 +34,11 @@ if os.environ.get("VQA_LN_FAST") or os.environ.get("VQA_GRU_CFG") or os.environ.
     if os.environ.get("VQA_ATTN_FAST"):
         _l.vqa_attn_set_fast(int(os.environ["VQA_ATTN_FAST"]))
 for i in range(3):
-    eng.train_step(db, eng.make_keep_masks(B, 1, i), 1e-3)
+    eng.train_step(db, eng.make_keep_masks(B, int(os.environ.get("MASK_SEED", "1")), i), 1e-3)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
-    eng.train_step(db, eng.make_keep_masks(B, 1, 3 + i), 1e-3)
+    eng.train_step(db, eng.make_keep_masks(B, int(os.environ.get("MASK_SEED", "1")), 3 + i), 1e-3)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 rep = eng.fetch_report()
