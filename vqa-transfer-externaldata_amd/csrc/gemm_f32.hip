@@ -1105,8 +1105,13 @@ int g_gru_cfg = -1;
 // them) one 16-wave workgroup per CU is no longer the best form: 32x64 / 4-wave tiles forward (768 rows: 693 -> 565 us,
 // 1536 rows: 1072 -> 961 us per 10 steps) and 64x32 tiles of 8 waves backward (632 -> 559, 995 -> 869);
 // profiles/r2_gru_tune_rows.txt.
+inline int env_cfg(const char* name, int dflt) {      // tuning overrides, read once
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 inline int gru_cfg_fwd(int rows) {
-    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 12 : rows > 512 ? 9 : rows > 256 ? 18 : 16);
+    static const int mid = env_cfg("VQA_HOT_GRU_MID_FWD", 9), tall = env_cfg("VQA_HOT_GRU_TALL_FWD", 12);
+    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? tall : rows > 512 ? mid : rows > 256 ? 18 : 16);
 }
 // The H-wide candidate kernel of a tall batch takes 32x64 tiles: at 2560 rows x 1024 columns the 64x64 tile gives 640
 // tiles (2.5 per CU, a half-empty last round), 32x64 gives 1280 (5 per CU): forward recurrence 1548 -> 1489 us at
@@ -1119,7 +1124,8 @@ inline int gru_cfg_fwd_cand(int rows) {
     return (g_gru_cfg < 0 && rows >= 2048 && gru_narrow_override() >= 0) ? gru_narrow_override() : gru_cfg_fwd(rows);
 }
 inline int gru_cfg_bwd(int rows) {
-    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? 13 : rows > 512 ? 17 : rows > 256 ? 18 : 16);
+    static const int mid = env_cfg("VQA_HOT_GRU_MID_BWD", 17), tall = env_cfg("VQA_HOT_GRU_TALL_BWD", 13);
+    return g_gru_cfg >= 0 ? g_gru_cfg : (rows >= 2048 ? tall : rows > 512 ? mid : rows > 256 ? 18 : 16);
 }
 
 // Tile / split-k choice from the gemm_tune sweep on MI355X (tools/gemm_tune.py, profiles/):
