@@ -147,3 +147,12 @@ def test_export_word_weights_command_line(tmp_path):
     with pytest.raises(ValueError, match="class_feat_dim"):
         EW.run(EW.build_parser().parse_args(["--checkpoint", str(run / "model-13"), "--data_dir", str(data)]))
     assert EW.build_parser().parse_args(["--checkpoint", "x"]).class_feat_dim == 2048
+
+
+def test_a_failing_producer_raises_in_the_consumer():
+    ds = DV.Dataset(split="train", data=DV.synthetic_dataset(6, 50, 9, 21, R=36, D=8, max_len=7, seed=3), seed=5)
+    del ds.processed[ds.ids[4]]                                   # the second batch cannot be assembled
+    it = DV.create_ops(3, ds, is_train=False, resident=True, workers=1)
+    assert len(next(it)["image_id"]) == 3
+    with pytest.raises(RuntimeError, match="batch producer 0 failed"):
+        next(it)

@@ -172,6 +172,9 @@ def _worker_main(q, batch_size, dataset, is_train, shuffle, seed, repeat, reside
     try:
         for b in _batches(batch_size, dataset, is_train, shuffle, seed, repeat, resident, part, parts):
             q.put(b)
+    except BaseException:                 # hand the failure to the consumer instead of ending the stream silently
+        import traceback
+        q.put(("__producer_error__", traceback.format_exc()))
     finally:
         q.put(None)
 
@@ -210,6 +213,8 @@ def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=
                     b = qs[g % workers].get()
                     if b is None:
                         return
+                    if isinstance(b, tuple) and b and b[0] == "__producer_error__":
+                        raise RuntimeError("batch producer %d failed:\n%s" % (g % workers, b[1]))
                     yield b
                     g += 1
             finally:
