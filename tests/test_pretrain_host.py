@@ -156,3 +156,7 @@ def test_a_failing_producer_raises_in_the_consumer():
     assert len(next(it)["image_id"]) == 3
     with pytest.raises(RuntimeError, match="batch producer 0 failed"):
         next(it)
+    it = DV.create_ops(3, ds, is_train=False, resident=True, prefetch=2)
+    assert len(next(it)["image_id"]) == 3
+    with pytest.raises(RuntimeError, match="producer thread failed"):
+        next(it)

@@ -228,17 +228,23 @@ def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=
         q = queue.Queue(maxsize=prefetch)
         stop = threading.Event()
 
+        def offer(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return
+                except queue.Full:
+                    continue
+
         def produce():
             try:
                 for b in _batches(*args):
-                    while not stop.is_set():
-                        try:
-                            q.put(b, timeout=0.2)
-                            break
-                        except queue.Full:
-                            continue
+                    offer(b)
                     if stop.is_set():
                         return
+            except BaseException:
+                import traceback
+                offer(("__producer_error__", traceback.format_exc()))
             finally:
                 while not stop.is_set():
                     try:
@@ -254,6 +260,8 @@ def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=
                     b = q.get()
                     if b is None:
                         return
+                    if isinstance(b, tuple) and b and b[0] == "__producer_error__":
+                        raise RuntimeError("batch producer thread failed:\n%s" % b[1])
                     yield b
             finally:
                 stop.set()
