@@ -327,6 +327,18 @@ def test_colsum_and_sumsq_and_mask():
         assert torch.equal(view, m1[:n])
 
 
+@pytest.mark.parametrize("M,N", [(5, 8), (700, 1024), (25600, 3072), (129, 260)])
+def test_colsum_16_byte_form_equals_the_scalar_form(M, N):
+    """N, ldx multiples of 4 take the 16-byte kernels: bit for bit the scalar kernels' result (same per-column order),
+    here against the scalar path taken by an N - 1 wide view of the same matrix"""
+    rng = np.random.default_rng(M + N)
+    X = dev(rng.standard_normal((M, N)).astype(np.float32))
+    v4 = ops.colsum(X)                                   # 16-byte form
+    sc = ops.colsum(X[:, :N - 1])                        # N - 1 columns, row stride N: scalar form
+    assert torch.equal(v4[:N - 1], sc)
+    close(v4, X.double().sum(0).cpu().numpy(), 1e-4, 1e-3 * max(1.0, np.sqrt(M) / 10))
+
+
 @pytest.mark.parametrize("M,N", [(7, 40), (512, 1024), (25600, 300), (3, 5)])
 def test_colsum_accumulating_forms(M, N):
     """vqa_colsum_acc / vqa_colsum3_acc: out (+)= column sums, chosen per output; one- and two-pass reductions"""
