@@ -51,6 +51,7 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("mean_v", B); L.add("rstd_v", B);
     L.add("x_tm", T * B * W);
     L.add("xp", T * B * 3 * H);
+    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", W * 3 * H);
     L.add("hs", (T + 1) * B * H);
     L.add("gru_r", T * B * H); L.add("gru_u", T * B * H); L.add("gru_c", T * B * H); L.add("gru_rh", T * B * H);
     L.add("pre_qv", B * H); L.add("q_linear_v", B * H); L.add("mean_qv", B); L.add("rstd_qv", B);
@@ -91,6 +92,7 @@ Layout make_layout(const vqa_dims_t& d) {
     g(1, 0, D, H, B); g(1, 0, H, H, B); g(0, 1, B, H, H); g(1, 0, D, H, B * R); g(1, 0, W, 2 * H, T * B);
     g(1, 0, H, 2 * H, T * B); g(1, 0, W, H, T * B); g(1, 0, H, H, T * B); g(0, 1, T * B, W, 2 * H);
     g(0, 1, T * B, W, H);                                                         // backward
+    g(0, 0, T * B, 3 * H, W); g(0, 1, T * B, W, 3 * H); g(1, 0, W, 3 * H, T * B);  // packed x-projection
     g(0, 0, B, W, 2 * H); g(0, 0, B, A, W); g(0, 1, B, W, A); g(1, 0, 2 * H, W, B); g(0, 1, B, 2 * H, W);  // word2vec head
     L.add("gemm_ws", max64(gw, 4));
     L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
@@ -314,6 +316,43 @@ inline bool visual_late_enabled() {       // VQA_HOT_VISUAL_LATE=0: the round-1 
 }
 }  // namespace
 
+namespace {
+// The x rows (first W) of the two GRU kernels -- gates [W+H, 2H], candidate [W+H, H] -- side by side as one [W, 3H]
+// matrix (+ the two biases as one [3H] vector), so that the input projection of all steps, its gradient dx and the
+// x-part of the weight gradient are ONE GEMM each against the [T*B, 3H] projection block instead of two with
+// K (or N) = 300: three launches and an accumulate pass less per step.  Repacked every step (the weights move).
+__global__ __launch_bounds__(256) void pack_wx_kernel(const float* __restrict__ wg, const float* __restrict__ wc,
+                                                      const float* __restrict__ bg, const float* __restrict__ bc,
+                                                      float* __restrict__ wx, float* __restrict__ bx, int W, int H) {
+    const int H3 = 3 * H;
+    const int64_t n = (int64_t)W * H3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n + H3; i += (int64_t)gridDim.x * 256) {
+        if (i < n) {
+            const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
+            wx[i] = col < 2 * H ? wg[(int64_t)r * 2 * H + col] : wc[(int64_t)r * H + (col - 2 * H)];
+        } else {
+            const int col = (int)(i - n);
+            bx[col] = col < 2 * H ? bg[col] : bc[col - 2 * H];
+        }
+    }
+}
+// gradient of the packed matrix back into the x rows of the two kernels' gradients
+__global__ __launch_bounds__(256) void unpack_dwx_kernel(const float* __restrict__ dwx, float* __restrict__ gwg,
+                                                         float* __restrict__ gwc, int W, int H) {
+    const int H3 = 3 * H;
+    const int64_t n = (int64_t)W * H3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
+        if (col < 2 * H) gwg[(int64_t)r * 2 * H + col] = dwx[i];
+        else gwc[(int64_t)r * H + (col - 2 * H)] = dwx[i];
+    }
+}
+inline bool xcat_enabled() {       // VQA_HOT_XCAT=0: the two-GEMM form (A/B)
+    static const bool v = [] { const char* e = getenv("VQA_HOT_XCAT"); return e == nullptr || atoi(e) != 0; }();
+    return v;
+}
+}  // namespace
+
 extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P, const vqa_batch_t* bt,
                                   void* workspace, int64_t workspace_bytes, int want_dz, void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && bt && workspace, VQA_ERR_ARG);
@@ -360,8 +399,16 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
     // a4: GRU.  Input projections of all steps as two big GEMMs ...
     float* xp = c.f("xp");
-    TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
-    TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+    if (xcat_enabled()) {
+        const int64_t n = W * 3 * H + 3 * H;
+        hipLaunchKernelGGL(pack_wx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, c.st,
+                           P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H);
+        VQA_CHECK_LAUNCH();
+        TRY(gemm(c, 0, 0, T * B, 3 * H, W, c.f("x_tm"), (int)W, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H), c.f("bx_cat")));
+    } else {
+        TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
+        TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+    }
     float* hs = c.f("hs");
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
     const float* Wg_h = P->gru_wg + W * 2 * H;
@@ -528,8 +575,12 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }
     // embedding: un-aggregated slices dx [T,B,W], then scatter-add
     float* dx = c.f("dx_embed");
-    TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
-    TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+    if (xcat_enabled()) {       // wx_cat was packed by the forward of this step (the weights have not moved since)
+        TRY(gemm(c, 0, 1, T * B, W, 3 * H, dxp, (int)(3 * H), c.f("wx_cat"), (int)(3 * H), dx, (int)W));
+    } else {
+        TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
+        TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+    }
     if (G->embed != nullptr)
         TRY(vqa_embed_bwd_len_det(dx, bt->q_intseq, bt->q_intseq_len, G->embed, (int)B, (int)T, (int)W, dims->Vq,
                                   (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
@@ -538,12 +589,21 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }   // phase 2
 
     if ((phases & 4) && G->gru_wg != nullptr) {
-        TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
+        if (xcat_enabled()) {   // x rows of BOTH kernels' gradients (the candidate's bucket is reduced after phase 4)
+            TRY(gemm(c, 1, 0, W, 3 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), c.f("dwx_cat"), (int)(3 * H)));
+            const int64_t n = W * 3 * H;
+            hipLaunchKernelGGL(unpack_dwx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
+                               c.st, c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H);
+            VQA_CHECK_LAUNCH();
+        } else {
+            TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
+        }
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
         TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
     }   // phase 3: gates
     if ((phases & 8) && G->gru_wg != nullptr) {
-        TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)W, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
+        if (!xcat_enabled())
+            TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)W, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
         TRY(gemm(c, 1, 0, H, H, T * B, c.f("gru_rh"), (int)H, dxp + 2 * H, (int)(3 * H), G->gru_wc + W * H, (int)H));
         TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
     }   // phase 4: candidate
