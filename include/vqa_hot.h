@@ -51,6 +51,13 @@ int vqa_gather_features(const float* table, const int32_t* nbox_table, const int
  * q i32[B,T] (batch-major, zero padded) -> x [T,B,W] TIME-major (the GRU
  * consumes one contiguous [B,W] slab per step). */
 int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, void* stream);
+/* The x rows (first W) of the two GRU kernels -- gates [W+H, 2H] and candidate [W+H, H] of tf.contrib.rnn.GRUCell
+ * (vlmap/modules.py:124-140) -- side by side as one [W, 3H] matrix, the two biases as one [3H] vector: the input
+ * projection of all time steps, its gradient and the x-part weight gradient are then one GEMM each.
+ * vqa_gru_unpack_dwx writes the gradient of the packed matrix into the x rows of the two kernels' gradients. */
+int vqa_gru_pack_wx(const float* wg, const float* wc, const float* bg, const float* bc, float* wx, float* bx, int W, int H,
+                    void* stream);
+int vqa_gru_unpack_dwx(const float* dwx, float* gwg, float* gwc, int W, int H, void* stream);
 /* backward: dE[q[b,t],:] += dx[t,b,:] (dE must be zeroed by the caller);
  * the IndexedSlices gradient of the gather.  Float atomics by default (order of the adds, hence the last bit,
  * varies run to run -- as in the reference); after vqa_set_deterministic(1) an atomic-free, run-to-run bitwise

@@ -80,6 +80,8 @@ SIGNATURES = {
     "vqa_hot_error_string": (C.c_char_p, [_I]),
     "vqa_gather_features": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_gru_pack_wx": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vqa_gru_unpack_dwx": (_I, [_P, _P, _P, _I, _I, _P]),
     "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len_det": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -317,36 +317,6 @@ inline bool visual_late_enabled() {       // VQA_HOT_VISUAL_LATE=0: the round-1 
 }  // namespace
 
 namespace {
-// The x rows (first W) of the two GRU kernels -- gates [W+H, 2H], candidate [W+H, H] -- side by side as one [W, 3H]
-// matrix (+ the two biases as one [3H] vector), so that the input projection of all steps, its gradient dx and the
-// x-part of the weight gradient are ONE GEMM each against the [T*B, 3H] projection block instead of two with
-// K (or N) = 300: three launches and an accumulate pass less per step.  Repacked every step (the weights move).
-__global__ __launch_bounds__(256) void pack_wx_kernel(const float* __restrict__ wg, const float* __restrict__ wc,
-                                                      const float* __restrict__ bg, const float* __restrict__ bc,
-                                                      float* __restrict__ wx, float* __restrict__ bx, int W, int H) {
-    const int H3 = 3 * H;
-    const int64_t n = (int64_t)W * H3;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n + H3; i += (int64_t)gridDim.x * 256) {
-        if (i < n) {
-            const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
-            wx[i] = col < 2 * H ? wg[(int64_t)r * 2 * H + col] : wc[(int64_t)r * H + (col - 2 * H)];
-        } else {
-            const int col = (int)(i - n);
-            bx[col] = col < 2 * H ? bg[col] : bc[col - 2 * H];
-        }
-    }
-}
-// gradient of the packed matrix back into the x rows of the two kernels' gradients
-__global__ __launch_bounds__(256) void unpack_dwx_kernel(const float* __restrict__ dwx, float* __restrict__ gwg,
-                                                         float* __restrict__ gwc, int W, int H) {
-    const int H3 = 3 * H;
-    const int64_t n = (int64_t)W * H3;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
-        if (col < 2 * H) gwg[(int64_t)r * 2 * H + col] = dwx[i];
-        else gwc[(int64_t)r * H + (col - 2 * H)] = dwx[i];
-    }
-}
 inline bool xcat_enabled() {       // VQA_HOT_XCAT=0: the two-GEMM form (A/B)
     static const bool v = [] { const char* e = getenv("VQA_HOT_XCAT"); return e == nullptr || atoi(e) != 0; }();
     return v;
@@ -400,10 +370,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     // a4: GRU.  Input projections of all steps as two big GEMMs ...
     float* xp = c.f("xp");
     if (xcat_enabled()) {
-        const int64_t n = W * 3 * H + 3 * H;
-        hipLaunchKernelGGL(pack_wx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, c.st,
-                           P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H);
-        VQA_CHECK_LAUNCH();
+        TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
         TRY(gemm(c, 0, 0, T * B, 3 * H, W, c.f("x_tm"), (int)W, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H), c.f("bx_cat")));
     } else {
         TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
@@ -591,10 +558,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     if ((phases & 4) && G->gru_wg != nullptr) {
         if (xcat_enabled()) {   // x rows of BOTH kernels' gradients (the candidate's bucket is reduced after phase 4)
             TRY(gemm(c, 1, 0, W, 3 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), c.f("dwx_cat"), (int)(3 * H)));
-            const int64_t n = W * 3 * H;
-            hipLaunchKernelGGL(unpack_dwx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
-                               c.st, c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H);
-            VQA_CHECK_LAUNCH();
+            TRY(vqa_gru_unpack_dwx(c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H, c.st));
         } else {
             TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
         }

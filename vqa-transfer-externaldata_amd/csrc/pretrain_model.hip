@@ -145,6 +145,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
             L.alias(q + "stats", "S/stats", ln * Bn * 4, Bn * 4);
         }
     }
+    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", W * 3 * H);      // packed x rows of the GRU kernels
     L.add("report", 16);
     // backward scratch, shared by the two categories
     L.add("d_j", 4 * Bn * 2 * H); L.add("d_jpre", 4 * Bn * 2 * H); L.add("d_jin", 4 * Bn * H);
@@ -165,6 +166,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     };
     g(0, 0, B * R, H, 6); g(0, 0, Bn, H, 6); g(0, 0, Bn, H, D); g(0, 0, Bn, H, H); g(0, 0, Bn, 2 * H, H);
     g(0, 0, Bn, A, 2 * H);
+    g(0, 0, T * Bn, 3 * H, W); g(0, 1, T * Bn, W, 3 * H); g(1, 0, W, 3 * H, T * Bn);      // packed x-projection
     g(0, 0, 2 * Bn, H, D); g(0, 0, 4 * Bn, H, H); g(0, 0, 4 * Bn, 2 * H, H); g(0, 0, 4 * Bn, A, 2 * H);      // stacked heads
     g(1, 0, 2 * H, A, 4 * Bn); g(0, 1, 4 * Bn, 2 * H, A); g(1, 0, H, 2 * H, 4 * Bn); g(0, 1, 4 * Bn, H, 2 * H);
     g(1, 0, D, H, 2 * Bn); g(0, 1, 2 * Bn, D, H); g(1, 0, H, H, 4 * Bn); g(0, 1, 4 * Bn, H, H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
@@ -332,6 +334,8 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     VQA_REQUIRE(bt->image_ft && bt->spatial_ft && bt->num_boxes, VQA_ERR_ARG);
     ReportArgs ra{};
     ra.rows = (int)Bn;
+    // the x rows of the two GRU kernels side by side (vqa_gru_pack_wx): one projection GEMM per category
+    TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
     for (int k = 0; k < 2; ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         VQA_REQUIRE(kb.normal_boxes && kb.fills && kb.blanks && kb.blanks_len && kb.wordsets && kb.num, VQA_ERR_ARG);
@@ -358,8 +362,8 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         TRY(gather_rows(kb.blanks_len, kb.perm, c.i32(p + "lens_s"), Bn, 1, c.st));
         TRY(vqa_embed_fwd(P->l_glove, c.i32(p + "blanks_s"), c.f(p + "x_tm"), (int)Bn, (int)T, (int)W, dims->Vq, c.st));
         float* xp = c.f(p + "xp");
-        TRY(c.gemm(0, 0, T * Bn, 2 * H, W, c.f(p + "x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
-        TRY(c.gemm(0, 0, T * Bn, H, W, c.f(p + "x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+        TRY(c.gemm(0, 0, T * Bn, 3 * H, W, c.f(p + "x_tm"), (int)W, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H),
+                   c.f("bx_cat")));
         float* hs = c.f(p + "hs");
         if (hipMemsetAsync(hs, 0, (size_t)Bn * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
         const float* Wg_h = P->gru_wg + W * 2 * H;
@@ -493,15 +497,15 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
             TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
                                 c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H, c.st));
         const int ld3 = (int)(3 * H);
-        TRY(acc.weight(G->gru_wg, c.f(p + "x_tm"), (int)W, dxp, ld3, W, 2 * H, T * Bn));
+        // x rows of both kernels' gradients as one GEMM into the packed [W, 3H] block (summed over the categories
+        // there, unpacked once after the loop); the h rows as before
+        TRY(acc.weight(c.f("dwx_cat"), c.f(p + "x_tm"), (int)W, dxp, ld3, W, 3 * H, T * Bn));
         TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * Bn));
-        TRY(acc.weight(G->gru_wc, c.f(p + "x_tm"), (int)W, dxp + 2 * H, ld3, W, H, T * Bn));
         TRY(acc.weight(G->gru_wc + W * H, c.f(p + "gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * Bn));
         TRY(acc.colsum(dxp, T * Bn, 2 * H, ld3, G->gru_bg));
         TRY(acc.colsum(dxp + 2 * H, T * Bn, H, ld3, G->gru_bc));
         float* dx = c.f("dx");
-        TRY(c.gemm(0, 1, T * Bn, W, 2 * H, dxp, ld3, P->gru_wg, (int)(2 * H), dx, (int)W));
-        TRY(c.gemm(0, 1, T * Bn, W, H, dxp + 2 * H, ld3, P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
+        TRY(c.gemm(0, 1, T * Bn, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));   // packed by the forward
         TRY(vqa_embed_bwd_len_det(dx, c.i32(p + "blanks_s"), c.i32(p + "lens_s"), G->l_glove, (int)Bn, (int)T, (int)W,
                                   dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
         TRY(add_slice_sq(dx, T * Bn * W));
@@ -523,6 +527,7 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, k, (int)n, 0,
                       p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
     }
+    TRY(vqa_gru_unpack_dwx(c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H, c.st));
     if (slice_sq != nullptr && sq_prev != nullptr)
         if (hipMemcpyAsync(slice_sq, sq_prev, sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
             return VQA_ERR_LAUNCH;

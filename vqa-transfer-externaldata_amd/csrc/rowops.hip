@@ -395,7 +395,56 @@ __global__ __launch_bounds__(256) void dropout_mask_bytes_kernel(uint8_t* __rest
         out[i] = (uint8_t)keep_bit(key, offset + (uint64_t)i, thr);
 }
 
+// The x rows (first W) of the two GRU kernels -- gates [W+H, 2H], candidate [W+H, H] -- side by side as one [W, 3H]
+// matrix (+ the two biases as one [3H] vector), so that the input projection of all steps, its gradient dx and the
+// x-part of the weight gradient are ONE GEMM each against the [T*B, 3H] projection block instead of two with
+// K (or N) = 300: three launches and an accumulate pass less per step.  Repacked every step (the weights move).
+__global__ __launch_bounds__(256) void pack_wx_kernel(const float* __restrict__ wg, const float* __restrict__ wc,
+                                                      const float* __restrict__ bg, const float* __restrict__ bc,
+                                                      float* __restrict__ wx, float* __restrict__ bx, int W, int H) {
+    const int H3 = 3 * H;
+    const int64_t n = (int64_t)W * H3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n + H3; i += (int64_t)gridDim.x * 256) {
+        if (i < n) {
+            const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
+            wx[i] = col < 2 * H ? wg[(int64_t)r * 2 * H + col] : wc[(int64_t)r * H + (col - 2 * H)];
+        } else {
+            const int col = (int)(i - n);
+            bx[col] = col < 2 * H ? bg[col] : bc[col - 2 * H];
+        }
+    }
+}
+// gradient of the packed matrix back into the x rows of the two kernels' gradients
+__global__ __launch_bounds__(256) void unpack_dwx_kernel(const float* __restrict__ dwx, float* __restrict__ gwg,
+                                                         float* __restrict__ gwc, int W, int H) {
+    const int H3 = 3 * H;
+    const int64_t n = (int64_t)W * H3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
+        if (col < 2 * H) gwg[(int64_t)r * 2 * H + col] = dwx[i];
+        else gwc[(int64_t)r * H + (col - 2 * H)] = dwx[i];
+    }
+}
 }  // namespace
+
+extern "C" int vqa_gru_pack_wx(const float* wg, const float* wc, const float* bg, const float* bc, float* wx, float* bx, int W,
+                               int H, void* stream) {
+    VQA_REQUIRE(wg && wc && bg && bc && wx && bx && W > 0 && H > 0, VQA_ERR_ARG);
+    const int64_t n = (int64_t)W * 3 * H + 3 * H;
+    hipLaunchKernelGGL(pack_wx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, wg, wc, bg, bc, wx, bx, W, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gru_unpack_dwx(const float* dwx, float* gwg, float* gwc, int W, int H, void* stream) {
+    VQA_REQUIRE(dwx && gwg && gwc && W > 0 && H > 0, VQA_ERR_ARG);
+    const int64_t n = (int64_t)W * 3 * H;
+    hipLaunchKernelGGL(unpack_dwx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, dwx, gwg, gwc, W, H);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
 
 extern "C" int vqa_gather_features(const float* table, const int32_t* nbox_table, const int64_t* idx, float* V,
                                    int32_t* nb, int B, int R, int D, int64_t N, void* stream) {
