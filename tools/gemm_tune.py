@@ -30,6 +30,7 @@ SHAPES = [
     ("dWg_h", "tn", 1024, 2048, 7168),
     ("dWc_h", "tn", 1024, 1024, 7168),
     ("dWg_x", "tn", 300, 2048, 7168),
+    ("xp_cat", "nn", 7168, 3072, 300), ("dx_cat", "nt", 7168, 300, 3072), ("dWx_cat", "tn", 300, 3072, 7168),   # packed x rows
 ]
 
 if os.environ.get("TUNE_SET") == "pretrain":      # cfg-5 pre-training step: 2560 rows per category
