@@ -57,3 +57,15 @@ def test_flops_and_peak_constants():
     assert bench.F32_MFMA_PEAK_TFLOPS == pytest.approx(157.3)
     cfg = bench.CFG
     assert (cfg["B"], cfg["R"], cfg["D"], cfg["H"], cfg["T"], cfg["A"]) == (512, 36, 2048, 1024, 14, 3000)
+
+
+def test_tools_and_entry_points_compile():
+    """every script under tools/ (some are driven by tests and by the profile recipes) and the two root entry points
+    are at least syntactically valid python"""
+    import glob
+    import py_compile
+    paths = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tools", "dbg", "*.py")))
+    paths += [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(paths) > 15
+    for p in paths:
+        py_compile.compile(p, doraise=True, cfile=os.devnull)
