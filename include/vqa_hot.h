@@ -58,6 +58,12 @@ int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int B, int T, i
 int vqa_gru_pack_wx(const float* wg, const float* wc, const float* bg, const float* bc, float* wx, float* bx, int W, int H,
                     void* stream);
 int vqa_gru_unpack_dwx(const float* dwx, float* gwg, float* gwc, int W, int H, void* stream);
+/* vqa_embed_fwd with a row stride ldx >= W: columns W .. ldx-1 of every row are 1, 0, 0, ... -- the constant input whose
+ * weight row is the bias.  The x-part weight-gradient GEMM over ldx rows (x_tm^T [ldx, T*B] x dxp [T*B, 3H]) then has
+ * the bias gradients (the column sums of dxp) in its row W: vqa_gru_unpack_dwx_bias writes that row into the gradients
+ * of the two biases, the rows above it into the x rows of the two kernels' gradients. */
+int vqa_embed_fwd_ld(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, int ldx, void* stream);
+int vqa_gru_unpack_dwx_bias(const float* dwx, float* gwg, float* gwc, float* gbg, float* gbc, int W, int H, void* stream);
 /* backward: dE[q[b,t],:] += dx[t,b,:] (dE must be zeroed by the caller);
  * the IndexedSlices gradient of the gather.  Float atomics by default (order of the adds, hence the last bit,
  * varies run to run -- as in the reference); after vqa_set_deterministic(1) an atomic-free, run-to-run bitwise

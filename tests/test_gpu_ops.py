@@ -387,6 +387,39 @@ def test_gru_pack_and_unpack_of_the_input_rows():
     assert bool((gwg[W:] == 7.0).all()) and bool((gwc[W:] == 9.0).all())               # the h rows are not touched
 
 
+def test_constant_column_of_the_inputs_yields_the_bias_gradient():
+    """vqa_embed_fwd_ld / vqa_gru_unpack_dwx_bias: the time-major inputs carry a constant 1 in column W (zeros up to the
+    row stride), so X^T dXP holds the x rows of both kernels' gradients in rows 0..W-1 and the two bias gradients
+    (column sums of dXP) in row W -- rnn GRUCell's bias gradients of vqa/model_vlmap_answer.py:97-105"""
+    import ctypes as C
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    B, T, W, H, Vq = 5, 3, 12, 8, 20
+    Wp = ((W + 1 + 3) // 4) * 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    E = torch.randn(Vq, W, device="cuda", generator=g)
+    q = torch.randint(0, Vq, (B, T), device="cuda", generator=g, dtype=torch.int32)
+    x = torch.full((T, B, Wp), 5.0, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(lib.vqa_embed_fwd_ld(P(E), P(q), P(x), B, T, W, Vq, Wp, None), "embed_ld")
+    assert torch.equal(x[:, :, :W], ops.embed_fwd(E, q))
+    assert bool((x[:, :, W] == 1).all()) and bool((x[:, :, W + 1:] == 0).all())
+    dxp = torch.randn(T * B, 3 * H, device="cuda", generator=g)
+    dwx = ops.gemm(x.view(T * B, Wp), dxp, transA=True)
+    gwg, gwc = torch.full((W + H, 2 * H), 7.0, device="cuda"), torch.full((W + H, H), 9.0, device="cuda")
+    gbg, gbc = torch.empty(2 * H, device="cuda"), torch.empty(H, device="cuda")
+    _lib.check(lib.vqa_gru_unpack_dwx_bias(P(dwx), P(gwg), P(gwc), P(gbg), P(gbc), W, H, None), "unpack_bias")
+    ref = x.view(T * B, Wp)[:, :W].double().t() @ dxp.double()
+    assert (gwg[:W].double() - ref[:, :2 * H]).abs().max() < 1e-4 and (gwc[:W].double() - ref[:, 2 * H:]).abs().max() < 1e-4
+    cs = dxp.double().sum(0)
+    assert (gbg.double() - cs[:2 * H]).abs().max() < 1e-4 and (gbc.double() - cs[2 * H:]).abs().max() < 1e-4
+    assert bool((gwg[W:] == 7.0).all()) and bool((gwc[W:] == 9.0).all())
+    with pytest.raises(_lib.VqaHotError if hasattr(_lib, "VqaHotError") else Exception):
+        _lib.check(lib.vqa_gru_unpack_dwx_bias(P(dwx), P(gwg), P(gwc), P(gbg), None, W, H, None), "unpack_bias")
+    with pytest.raises(Exception):
+        _lib.check(lib.vqa_embed_fwd_ld(P(E), P(q), P(x), B, T, W, Vq, W - 1, None), "embed_ld")
+
+
 def test_errors_are_reported_not_swallowed():
     from vqa_transfer_externaldata_amd import VqaHotError
     a = torch.zeros(4, 4, device="cuda")

@@ -82,6 +82,8 @@ SIGNATURES = {
     "vqa_embed_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_gru_pack_wx": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vqa_gru_unpack_dwx": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vqa_embed_fwd_ld": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vqa_gru_unpack_dwx_bias": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "vqa_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_embed_bwd_len_det": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

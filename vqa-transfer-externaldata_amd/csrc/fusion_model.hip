@@ -49,9 +49,10 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("pre_v", B * R * H);
     L.add("v_linear_v", B * R * H);
     L.add("mean_v", B); L.add("rstd_v", B);
-    L.add("x_tm", T * B * W);
+    const int64_t Wp = ((W + 1 + 3) / 4) * 4;      // row stride of x_tm: W inputs + the constant 1 (+ zero padding to 16 B)
+    L.add("x_tm", T * B * Wp);
     L.add("xp", T * B * 3 * H);
-    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", W * 3 * H);
+    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", Wp * 3 * H);
     L.add("hs", (T + 1) * B * H);
     L.add("gru_r", T * B * H); L.add("gru_u", T * B * H); L.add("gru_c", T * B * H); L.add("gru_rh", T * B * H);
     L.add("pre_qv", B * H); L.add("q_linear_v", B * H); L.add("mean_qv", B); L.add("rstd_qv", B);
@@ -93,6 +94,7 @@ Layout make_layout(const vqa_dims_t& d) {
     g(1, 0, H, 2 * H, T * B); g(1, 0, W, H, T * B); g(1, 0, H, H, T * B); g(0, 1, T * B, W, 2 * H);
     g(0, 1, T * B, W, H);                                                         // backward
     g(0, 0, T * B, 3 * H, W); g(0, 1, T * B, W, 3 * H); g(1, 0, W, 3 * H, T * B);  // packed x-projection
+    g(1, 0, Wp, 3 * H, T * B);
     g(0, 0, B, W, 2 * H); g(0, 0, B, A, W); g(0, 1, B, W, A); g(1, 0, 2 * H, W, B); g(0, 1, B, 2 * H, W);  // word2vec head
     L.add("gemm_ws", max64(gw, 4));
     L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
@@ -366,15 +368,18 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     if (!visual_late) TRY(visual_branch());
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     // a3: embedding lookup, time-major
-    TRY(vqa_embed_fwd(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, c.st));
+    // x_tm rows carry the constant 1 after the W inputs (vqa_embed_fwd_ld): the x-part weight-gradient GEMM then also
+    // delivers the bias gradients, and the two passes over dxp that summed its columns are gone
+    const int64_t Wp = ((W + 1 + 3) / 4) * 4;
+    TRY(vqa_embed_fwd_ld(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, (int)Wp, c.st));
     // a4: GRU.  Input projections of all steps as two big GEMMs ...
     float* xp = c.f("xp");
     if (xcat_enabled()) {
         TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
-        TRY(gemm(c, 0, 0, T * B, 3 * H, W, c.f("x_tm"), (int)W, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H), c.f("bx_cat")));
+        TRY(gemm(c, 0, 0, T * B, 3 * H, W, c.f("x_tm"), (int)Wp, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H), c.f("bx_cat")));
     } else {
-        TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)W, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
-        TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)W, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+        TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)Wp, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
+        TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)Wp, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
     }
     float* hs = c.f("hs");
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
@@ -459,6 +464,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
     ProbeScope ps_all("backward", c.st);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
+    const int64_t Wp = ((W + 1 + 3) / 4) * 4;      // row stride of x_tm (make_layout)
     const float* hs = c.f("hs");
     const float* h = hs + T * B * H;
     float* dh = c.f("d_h0");
@@ -557,19 +563,21 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
 
     if ((phases & 4) && G->gru_wg != nullptr) {
         if (xcat_enabled()) {   // x rows of BOTH kernels' gradients (the candidate's bucket is reduced after phase 4)
-            TRY(gemm(c, 1, 0, W, 3 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), c.f("dwx_cat"), (int)(3 * H)));
-            TRY(vqa_gru_unpack_dwx(c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H, c.st));
+            // rows 0..W-1: x rows of both kernels' gradients; row W (the constant input): both bias gradients
+            TRY(gemm(c, 1, 0, Wp, 3 * H, T * B, c.f("x_tm"), (int)Wp, dxp, (int)(3 * H), c.f("dwx_cat"), (int)(3 * H)));
+            TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
         } else {
-            TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)W, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
+            TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)Wp, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
+            TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
         }
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
-        TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
     }   // phase 3: gates
     if ((phases & 8) && G->gru_wg != nullptr) {
-        if (!xcat_enabled())
-            TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)W, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
+        if (!xcat_enabled()) {
+            TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)Wp, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
+            TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
+        }
         TRY(gemm(c, 1, 0, H, H, T * B, c.f("gru_rh"), (int)H, dxp + 2 * H, (int)(3 * H), G->gru_wc + W * H, (int)H));
-        TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
     }   // phase 4: candidate
     return VQA_OK;
 }

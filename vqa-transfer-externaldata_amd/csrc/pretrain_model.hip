@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256) void pretrain_report_kernel(ReportArgs a, floa
     if (threadIdx.x == 0) report[12] = ((loss[0] + loss[1]) + loss[2]) + loss[3];
 }
 
+// row stride of the time-major GRU inputs: W word-vector columns, the constant 1 (its row of the x-part weight gradient
+// is the bias gradient), zero padding to 16 bytes
+inline int64_t x_stride(int64_t W) { return ((W + 1 + 3) / 4) * 4; }
+
 // ---------------------------------------------------------------- workspace layout
 struct Entry { std::string name; int64_t off, n; };
 struct Layout {
@@ -125,7 +129,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
         L.alias(p + "pooled", "S/pooled", k * Bn * D, Bn * D); L.alias(p + "vl_pre", "S/vl_pre", k * Bn * H, Bn * H);
         L.add(p + "valid", Bn); L.add(p + "inv_valid", 4);
         L.add(p + "blanks_s", Bn * T); L.add(p + "lens_s", Bn);
-        L.add(p + "x_tm", T * Bn * W); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
+        L.add(p + "x_tm", T * Bn * x_stride(W)); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
         L.add(p + "gru_r", T * Bn * H); L.add(p + "gru_u", T * Bn * H); L.add(p + "gru_c", T * Bn * H);
         L.add(p + "gru_rh", T * Bn * H);
         L.alias(p + "bf_state", "S/lft", k * Bn * H, Bn * H);
@@ -145,7 +149,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
             L.alias(q + "stats", "S/stats", ln * Bn * 4, Bn * 4);
         }
     }
-    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", W * 3 * H);      // packed x rows of the GRU kernels
+    L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", x_stride(W) * 3 * H);      // packed x rows of the GRU kernels
     L.add("report", 16);
     // backward scratch, shared by the two categories
     L.add("d_j", 4 * Bn * 2 * H); L.add("d_jpre", 4 * Bn * 2 * H); L.add("d_jin", 4 * Bn * H);
@@ -166,7 +170,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     };
     g(0, 0, B * R, H, 6); g(0, 0, Bn, H, 6); g(0, 0, Bn, H, D); g(0, 0, Bn, H, H); g(0, 0, Bn, 2 * H, H);
     g(0, 0, Bn, A, 2 * H);
-    g(0, 0, T * Bn, 3 * H, W); g(0, 1, T * Bn, W, 3 * H); g(1, 0, W, 3 * H, T * Bn);      // packed x-projection
+    g(0, 0, T * Bn, 3 * H, W); g(0, 1, T * Bn, W, 3 * H); g(1, 0, x_stride(W), 3 * H, T * Bn);      // packed x-projection
     g(0, 0, 2 * Bn, H, D); g(0, 0, 4 * Bn, H, H); g(0, 0, 4 * Bn, 2 * H, H); g(0, 0, 4 * Bn, A, 2 * H);      // stacked heads
     g(1, 0, 2 * H, A, 4 * Bn); g(0, 1, 4 * Bn, 2 * H, A); g(1, 0, H, 2 * H, 4 * Bn); g(0, 1, 4 * Bn, H, 2 * H);
     g(1, 0, D, H, 2 * Bn); g(0, 1, 2 * Bn, D, H); g(1, 0, H, H, 4 * Bn); g(0, 1, 4 * Bn, H, H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
@@ -360,9 +364,10 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         // ---- build_*_blank_fill: captions in length order when the host sorted them (live prefix recurrence)
         TRY(gather_rows(kb.blanks, kb.perm, c.i32(p + "blanks_s"), Bn, T, c.st));
         TRY(gather_rows(kb.blanks_len, kb.perm, c.i32(p + "lens_s"), Bn, 1, c.st));
-        TRY(vqa_embed_fwd(P->l_glove, c.i32(p + "blanks_s"), c.f(p + "x_tm"), (int)Bn, (int)T, (int)W, dims->Vq, c.st));
+        TRY(vqa_embed_fwd_ld(P->l_glove, c.i32(p + "blanks_s"), c.f(p + "x_tm"), (int)Bn, (int)T, (int)W, dims->Vq,
+                             (int)x_stride(W), c.st));
         float* xp = c.f(p + "xp");
-        TRY(c.gemm(0, 0, T * Bn, 3 * H, W, c.f(p + "x_tm"), (int)W, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H),
+        TRY(c.gemm(0, 0, T * Bn, 3 * H, W, c.f(p + "x_tm"), (int)x_stride(W), c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H),
                    c.f("bx_cat")));
         float* hs = c.f(p + "hs");
         if (hipMemsetAsync(hs, 0, (size_t)Bn * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
@@ -497,13 +502,13 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
             TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
                                 c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H, c.st));
         const int ld3 = (int)(3 * H);
-        // x rows of both kernels' gradients as one GEMM into the packed [W, 3H] block (summed over the categories
-        // there, unpacked once after the loop); the h rows as before
-        TRY(acc.weight(c.f("dwx_cat"), c.f(p + "x_tm"), (int)W, dxp, ld3, W, 3 * H, T * Bn));
+        // x rows of both kernels' gradients as one GEMM into the packed [Wp, 3H] block (summed over the categories
+        // there, unpacked once after the loop); x_tm carries the constant 1 in column W, so row W of the block is the
+        // two bias gradients and dxp is not read again for them.  The h rows as before
+        const int64_t Wp = x_stride(W);
+        TRY(acc.weight(c.f("dwx_cat"), c.f(p + "x_tm"), (int)Wp, dxp, ld3, Wp, 3 * H, T * Bn));
         TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * Bn));
         TRY(acc.weight(G->gru_wc + W * H, c.f(p + "gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * Bn));
-        TRY(acc.colsum(dxp, T * Bn, 2 * H, ld3, G->gru_bg));
-        TRY(acc.colsum(dxp + 2 * H, T * Bn, H, ld3, G->gru_bc));
         float* dx = c.f("dx");
         TRY(c.gemm(0, 1, T * Bn, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));   // packed by the forward
         TRY(vqa_embed_bwd_len_det(dx, c.i32(p + "blanks_s"), c.i32(p + "lens_s"), G->l_glove, (int)Bn, (int)T, (int)W,
@@ -527,7 +532,7 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, k, (int)n, 0,
                       p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
     }
-    TRY(vqa_gru_unpack_dwx(c.f("dwx_cat"), G->gru_wg, G->gru_wc, (int)W, (int)H, c.st));
+    TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
     if (slice_sq != nullptr && sq_prev != nullptr)
         if (hipMemcpyAsync(slice_sq, sq_prev, sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
             return VQA_ERR_LAUNCH;

@@ -36,16 +36,17 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float* __res
 
 // ------------------------------------------------------------------ a3
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float* __restrict__ E, const int32_t* __restrict__ q,
-                                                        float* __restrict__ x, int B, int T, int W, int Vq) {
-    // one wave per token; x is time-major [T,B,W]
+                                                        float* __restrict__ x, int B, int T, int W, int Vq, int ldx) {
+    // one wave per token; x is time-major [T,B,ldx]; columns W .. ldx-1 (if any) are 1, 0, 0, ...: the constant input
+    // whose "weight" row is the bias, so the x-part weight-gradient GEMM also delivers the bias gradient
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= B * T) return;
     const int t = tok / B, b = tok % B;
     int id = q[b * T + t];
     id = min(max(id, 0), Vq - 1);
     const float* s = E + (int64_t)id * W;
-    float* d = x + (int64_t)tok * W;
-    for (int i = threadIdx.x & 63; i < W; i += 64) d[i] = s[i];
+    float* d = x + (int64_t)tok * ldx;
+    for (int i = threadIdx.x & 63; i < ldx; i += 64) d[i] = i < W ? s[i] : (i == W ? 1.f : 0.f);
 }
 
 // Deterministic mode (vqa_set_deterministic): scatter-add of the embedding gradient WITHOUT atomics -- one wave
@@ -416,13 +417,19 @@ __global__ __launch_bounds__(256) void pack_wx_kernel(const float* __restrict__ 
 }
 // gradient of the packed matrix back into the x rows of the two kernels' gradients
 __global__ __launch_bounds__(256) void unpack_dwx_kernel(const float* __restrict__ dwx, float* __restrict__ gwg,
-                                                         float* __restrict__ gwc, int W, int H) {
+                                                         float* __restrict__ gwc, float* __restrict__ gbg,
+                                                         float* __restrict__ gbc, int W, int H) {
     const int H3 = 3 * H;
-    const int64_t n = (int64_t)W * H3;
+    const int64_t n = (int64_t)(W + (gbg != nullptr ? 1 : 0)) * H3;      // row W (if asked for): the bias gradients
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / H3), col = (int)(i - (int64_t)r * H3);
-        if (col < 2 * H) gwg[(int64_t)r * 2 * H + col] = dwx[i];
-        else gwc[(int64_t)r * H + (col - 2 * H)] = dwx[i];
+        if (r < W) {
+            if (col < 2 * H) gwg[(int64_t)r * 2 * H + col] = dwx[i];
+            else gwc[(int64_t)r * H + (col - 2 * H)] = dwx[i];
+        } else {
+            if (col < 2 * H) gbg[col] = dwx[i];
+            else gbc[col - 2 * H] = dwx[i];
+        }
     }
 }
 }  // namespace
@@ -438,10 +445,15 @@ extern "C" int vqa_gru_pack_wx(const float* wg, const float* wc, const float* bg
 }
 
 extern "C" int vqa_gru_unpack_dwx(const float* dwx, float* gwg, float* gwc, int W, int H, void* stream) {
-    VQA_REQUIRE(dwx && gwg && gwc && W > 0 && H > 0, VQA_ERR_ARG);
-    const int64_t n = (int64_t)W * 3 * H;
+    return vqa_gru_unpack_dwx_bias(dwx, gwg, gwc, nullptr, nullptr, W, H, stream);
+}
+
+extern "C" int vqa_gru_unpack_dwx_bias(const float* dwx, float* gwg, float* gwc, float* gbg, float* gbc, int W, int H,
+                                       void* stream) {
+    VQA_REQUIRE(dwx && gwg && gwc && W > 0 && H > 0 && (gbg == nullptr) == (gbc == nullptr), VQA_ERR_ARG);
+    const int64_t n = (int64_t)(W + 1) * 3 * H;
     hipLaunchKernelGGL(unpack_dwx_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0,
-                       (hipStream_t)stream, dwx, gwg, gwc, W, H);
+                       (hipStream_t)stream, dwx, gwg, gwc, gbg, gbc, W, H);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -465,7 +477,16 @@ extern "C" int vqa_embed_fwd(const float* E, const int32_t* q, float* x_tm, int 
     VQA_REQUIRE(E && q && x_tm && B >= 0 && T >= 0 && W > 0 && Vq > 0, VQA_ERR_ARG);
     if (B * T == 0) return VQA_OK;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, E, q, x_tm, B, T,
-                       W, Vq);
+                       W, Vq, W);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+extern "C" int vqa_embed_fwd_ld(const float* E, const int32_t* q, float* x_tm, int B, int T, int W, int Vq, int ldx,
+                                void* stream) {
+    VQA_REQUIRE(E && q && x_tm && B >= 0 && T >= 0 && W > 0 && Vq > 0 && ldx >= W, VQA_ERR_ARG);
+    if (B * T == 0) return VQA_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, E, q, x_tm, B, T,
+                       W, Vq, ldx);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
