@@ -282,6 +282,9 @@ int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, c
  * (inv_valid_sum is a DEVICE scalar = 1/sum(valid); dz may be NULL). */
 int vqa_softmax_ce_fwd(const float* z, const int32_t* label, const float* valid, int topk,
                        const float* inv_valid_sum, float* stats, float* dz, int rows, int A, void* stream);
+/* tuning / A-B switch: 1 (default) = rows of A <= 4096 (A % 4 == 0, 16-byte aligned) are held in registers and read
+ * once, 0 = the three-pass kernel for every A */
+int vqa_softmax_set_fast(int on);
 /* report[13] in the order of vqa_report_key(i): means over B + guarded ratios. */
 int vqa_report_reduce(const float* stats, int B, float* report, void* stream);
 #define VQA_REPORT_COUNT 13

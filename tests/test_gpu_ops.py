@@ -420,6 +420,54 @@ def test_constant_column_of_the_inputs_yields_the_bias_gradient():
         _lib.check(lib.vqa_embed_fwd_ld(P(E), P(q), P(x), B, T, W, Vq, W - 1, None), "embed_ld")
 
 
+@pytest.mark.parametrize("rows,A", [(7, 12), (33, 4000), (5, 4096), (9, 1000), (4, 1028), (6, 3001), (3, 4100), (2, 8192)])
+def test_softmax_ce_rows_match_f64_and_both_kernels_agree(rows, A):
+    """vqa_softmax_ce_fwd (n_way_classification_loss, vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:675-706):
+    {ce, top-1, top-k, valid} per row and dz against float64; the register-resident kernel (A <= 4096, A % 4 == 0) and
+    the three-pass kernel agree exactly on the integer outputs and to rounding on the rest.  Ties: tf.nn.top_k /
+    argmax order equal logits by index."""
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(rows * 7919 + A)
+    z = (rng.standard_normal((rows, A)) * 3).astype(np.float32)
+    label = rng.integers(0, A, size=rows).astype(np.int32)
+    z[0, :] = 1.5                                          # all equal: argmax 0, the label's rank is its index
+    label[0] = 3
+    if rows > 2:
+        z[1, label[1]] = z[1].max() + 1                    # a clear top-1 hit
+        z[2, [5, A - 1]] = z[2].max() + 2                  # tie for the maximum: index 5 wins
+        label[2] = A - 1
+    valid = (rng.random(rows) < 0.7).astype(np.float32)
+    valid[0] = 1
+    inv = np.array([1.0 / valid.sum()], np.float32)
+    topk = 5
+    outs = []
+    try:
+        for fast in (1, 0):
+            lib.vqa_softmax_set_fast(fast)
+            st, dz = ops.softmax_ce(dev(z), dev(label), dev(valid), dev(inv), topk=topk)
+            outs.append((st.cpu().numpy(), dz.cpu().numpy()))
+    finally:
+        lib.vqa_softmax_set_fast(1)
+    z64 = z.astype(np.float64)
+    mx = z64.max(1, keepdims=True)
+    lse = mx[:, 0] + np.log(np.exp(z64 - mx).sum(1))
+    ar = np.arange(rows)
+    zl = z64[ar, label]
+    ce = (lse - zl) * valid
+    top1 = (z64.argmax(1) == label) * valid
+    rank = ((z64 > zl[:, None]) | ((z64 == zl[:, None]) & (np.arange(A)[None, :] < label[:, None]))).sum(1)
+    tk = (rank < topk) * valid
+    onehot = np.zeros((rows, A)); onehot[ar, label] = 1
+    dz_ref = (np.exp(z64 - lse[:, None]) - onehot) * (valid * inv[0])[:, None]
+    for st, dz in outs:
+        assert np.abs(st[:, 0] - ce).max() < 2e-5 * max(1, np.abs(ce).max())
+        assert np.array_equal(st[:, 1], top1) and np.array_equal(st[:, 2], tk) and np.array_equal(st[:, 3], valid)
+        assert np.abs(dz - dz_ref).max() < 3e-6
+    assert np.array_equal(outs[0][0][:, 1:], outs[1][0][:, 1:])
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-6 and np.abs(outs[0][0][:, 0] - outs[1][0][:, 0]).max() < 1e-5
+
+
 def test_errors_are_reported_not_swallowed():
     from vqa_transfer_externaldata_amd import VqaHotError
     a = torch.zeros(4, 4, device="cuda")

@@ -24,7 +24,7 @@ eng = PT.PretrainEngine(n=n, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=n_ws, params=p
 db = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
 db.update(sort_info)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-if os.environ.get("VQA_LN_FAST") or os.environ.get("VQA_GRU_CFG") or os.environ.get("VQA_ATTN_FAST"):   # A/B switches
+if any(os.environ.get(k) for k in ("VQA_LN_FAST", "VQA_GRU_CFG", "VQA_ATTN_FAST", "VQA_SOFTMAX_FAST")):   # A/B switches
     from vqa_transfer_externaldata_amd import _lib
     _l = _lib.load()
     if os.environ.get("VQA_LN_FAST"):
@@ -33,6 +33,8 @@ if os.environ.get("VQA_LN_FAST") or os.environ.get("VQA_GRU_CFG") or os.environ.
         _lib.check(_l.vqa_gemm_set_gru_config(int(os.environ["VQA_GRU_CFG"])), "gru cfg")
     if os.environ.get("VQA_ATTN_FAST"):
         _l.vqa_attn_set_fast(int(os.environ["VQA_ATTN_FAST"]))
+    if os.environ.get("VQA_SOFTMAX_FAST"):
+        _l.vqa_softmax_set_fast(int(os.environ["VQA_SOFTMAX_FAST"]))
 for i in range(3):
     eng.train_step(db, eng.make_keep_masks(B, int(os.environ.get("MASK_SEED", "1")), i), 1e-3)
 torch.cuda.synchronize()

@@ -119,6 +119,7 @@ SIGNATURES = {
     "vqa_tanh_fwd": (_I, [_P, _P, _L, _P]),
     "vqa_tanh_bwd": (_I, [_P, _P, _P, _L, _P]),
     "vqa_softmax_ce_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "vqa_softmax_set_fast": (_I, [_I]),
     "vqa_colsum": (_I, [_P, _I, _I, _I, _P, _P, _L, _P]),
     "vqa_colsum_workspace_floats": (_L, [_I, _I]),
     "vqa_colsum3": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _P]),

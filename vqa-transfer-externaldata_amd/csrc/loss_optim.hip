@@ -198,6 +198,86 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
 }
 
+// The same with the row held in registers (A <= 4096, A % 4 == 0, 16-byte aligned rows): thread t owns the float4s
+// t, t+256, ... (NV of them), so the logits are read ONCE with 16-byte loads, all of a thread's loads in flight
+// together, instead of three dependent scalar passes over the row, and dz leaves as 16-byte stores.  Same arithmetic per
+// element as softmax_ce_kernel (exp(z - lse) for dz); only the order of the sum of exponentials differs.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_ce_reg_kernel(const float* __restrict__ z, const int32_t* __restrict__ label,
+                                                             const float* __restrict__ valid, int topk,
+                                                             const float* __restrict__ inv_valid_sum,
+                                                             float* __restrict__ stats, float* __restrict__ dz, int A) {
+    __shared__ float red[16];
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int A4 = A >> 2;
+    const float4* zb = reinterpret_cast<const float4*>(z + (int64_t)b * A);
+    float x[NV][4];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const float4 v = i < A4 ? zb[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
+    }
+    const int lab = label[b];
+    const float zl = z[(int64_t)b * A + min(max(lab, 0), A - 1)];
+    float mx = -INFINITY;
+    ArgMax am{-INFINITY, 0x7fffffff};
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = 4 * (threadIdx.x + 256 * k) + j;      // padding (a >= A) holds -inf: never a maximum, never ranked
+            const float v = x[k][j];
+            mx = fmaxf(mx, v);
+            if (v > am.v) { am.v = v; am.i = a; }
+            rank += (v > zl || (v == zl && a < lab)) ? 1 : 0;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax other{__shfl_xor(am.v, o, 64), __shfl_xor(am.i, o, 64)};
+        am = argmax_combine(am, other);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) { redv[wave] = am.v; redi[wave] = am.i; red[8 + wave] = mx; }
+    const float frank = block_sum((float)rank, red);
+    mx = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+    ArgMax best{redv[0], redi[0]};
+    for (int k = 1; k < 4; ++k) best = argmax_combine(best, ArgMax{redv[k], redi[k]});
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += expf(x[k][j] - mx);     // exp(-inf) = 0 for the padding
+    se = block_sum(se, red);
+    const float lse = mx + logf(se);
+    const float vm = valid[b];
+    if (dz != nullptr) {
+        const float sc = vm * inv_valid_sum[0];
+        float4* db = reinterpret_cast<float4*>(dz + (int64_t)b * A);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < A4) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (expf(x[k][j] - lse) - (4 * i + j == lab ? 1.f : 0.f)) * sc;
+                db[i] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        float* s = stats + (int64_t)b * 4;
+        s[0] = (lse - zl) * vm;
+        s[1] = (best.i == lab ? 1.f : 0.f) * vm;
+        s[2] = (frank < (float)topk ? 1.f : 0.f) * vm;
+        s[3] = vm;
+    }
+}
+int g_softmax_reg = 1;   // A/B switch (vqa_softmax_set_fast)
+
 // ------------------------------------------------------------------ optimiser
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
                                                             float* __restrict__ partial) {
@@ -291,9 +371,23 @@ extern "C" int vqa_softmax_ce_fwd(const float* z, const int32_t* label, const fl
     VQA_REQUIRE(z && label && valid && stats && rows >= 0 && A > 0 && topk > 0, VQA_ERR_ARG);
     VQA_REQUIRE(dz == nullptr || inv_valid_sum != nullptr, VQA_ERR_ARG);
     if (rows == 0) return VQA_OK;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, z, label, valid, topk,
-                       inv_valid_sum, stats, dz, A);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_softmax_reg && A % 4 == 0 && A <= 4096 && vqa_aligned16(z) && (dz == nullptr || vqa_aligned16(dz))) {
+        switch ((A / 4 + 255) / 256) {
+        case 1: hipLaunchKernelGGL(softmax_ce_reg_kernel<1>, dim3(rows), dim3(256), 0, st, z, label, valid, topk, inv_valid_sum, stats, dz, A); break;
+        case 2: hipLaunchKernelGGL(softmax_ce_reg_kernel<2>, dim3(rows), dim3(256), 0, st, z, label, valid, topk, inv_valid_sum, stats, dz, A); break;
+        case 3: hipLaunchKernelGGL(softmax_ce_reg_kernel<3>, dim3(rows), dim3(256), 0, st, z, label, valid, topk, inv_valid_sum, stats, dz, A); break;
+        default: hipLaunchKernelGGL(softmax_ce_reg_kernel<4>, dim3(rows), dim3(256), 0, st, z, label, valid, topk, inv_valid_sum, stats, dz, A); break;
+        }
+    } else {
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3(rows), dim3(256), 0, st, z, label, valid, topk, inv_valid_sum, stats, dz, A);
+    }
     VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_softmax_set_fast(int on) {
+    g_softmax_reg = on ? 1 : 0;
     return VQA_OK;
 }
 
