@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VQA_HOT_ABI_VERSION 2
+#define VQA_HOT_ABI_VERSION 3
 
 enum {
     VQA_OK = 0,
@@ -409,9 +409,6 @@ typedef struct {                            /* one blank-fill category (vlmap_me
     const int32_t *fills, *blanks, *blanks_len, *wordsets;   /* [B,n], [B,n,L] zero padded, [B,n], [B,n] */
     const int32_t* num;                     /* [B] valid entries per image */
     const uint8_t *keep_att, *keep_bf_joint, *keep_ws_joint;  /* [B*n,R,H], [B*n,2H], [B*n,2H] 0/1 or NULL */
-    /* captions ordered by length, longest first (all three NULL = as given): perm / inv device int32 [B*n],
-     * live_rows HOST int[L] = #captions longer than t -- the recurrence then runs on the live prefix only */
-    const int32_t *perm, *inv, *live_rows;
 } vqa_pretrain_kind_t;
 
 typedef struct {
@@ -419,6 +416,11 @@ typedef struct {
     const float* spatial_ft;                /* [B,R,6] */
     const int32_t* num_boxes;               /* [B] */
     vqa_pretrain_kind_t kind[2];            /* 0 = object, 1 = attribute */
+    /* The blank-fill captions of both categories are encoded as ONE batch of 2*B*n rows (L_GloVe and the GRU are shared):
+     * row v < B*n is object caption v, row v >= B*n attribute caption v - B*n.  Optionally ordered by length, longest
+     * first (all three NULL = as given): perm / inv device int32 [2*B*n] (sorted position -> row, row -> sorted
+     * position), live_rows HOST int[L] = #captions longer than t -- the recurrence then runs on the live prefix only */
+    const int32_t *perm, *inv, *live_rows;
 } vqa_pretrain_batch_t;
 
 int64_t vqa_pretrain_workspace_bytes(const vqa_pretrain_dims_t* dims);

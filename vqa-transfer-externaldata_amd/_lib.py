@@ -65,11 +65,12 @@ class PtParams(C.Structure):
 
 class PtKind(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("normal_boxes", "fills", "blanks", "blanks_len", "wordsets", "num", "keep_att",
-                                          "keep_bf_joint", "keep_ws_joint", "perm", "inv", "live_rows")]
+                                          "keep_bf_joint", "keep_ws_joint")]
 
 
 class PtBatch(C.Structure):
-    _fields_ = [("image_ft", C.c_void_p), ("spatial_ft", C.c_void_p), ("num_boxes", C.c_void_p), ("kind", PtKind * 2)]
+    _fields_ = [("image_ft", C.c_void_p), ("spatial_ft", C.c_void_p), ("num_boxes", C.c_void_p), ("kind", PtKind * 2),
+                ("perm", C.c_void_p), ("inv", C.c_void_p), ("live_rows", C.c_void_p)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -168,7 +169,7 @@ SIGNATURES = {
                                  _P, _P]),
 }
 
-ABI_VERSION = 2      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
+ABI_VERSION = 3      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
 
 _lib = None
 

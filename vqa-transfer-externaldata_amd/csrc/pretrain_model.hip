@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __rest
     }
 }
 
+// out[i, :] = (in0 ++ in1)[index[i], :]: rows 0..rows0-1 of the virtual concatenation live in in0, the rest in in1
+// (the captions of the two categories arrive as two arrays and are encoded as ONE batch)
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const uint32_t* __restrict__ in0, const uint32_t* __restrict__ in1,
+                                                           const int32_t* __restrict__ index, uint32_t* __restrict__ out,
+                                                           int rows, int cols, int rows0) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        int s = index ? index[r] : r;
+        s = min(max(s, 0), rows - 1);
+        out[i] = s < rows0 ? in0[(int64_t)s * cols + c] : in1[(int64_t)(s - rows0) * cols + c];
+    }
+}
+
 // report[3 h + j] = sum_rows stats_h[:, j] * inv_valid_h (j = loss, top-1, top-k), report[12] = sum of the 4 losses
 struct ReportArgs { const float* stats[4]; const float* inv[4]; int rows; };
 __global__ __launch_bounds__(256) void pretrain_report_kernel(ReportArgs a, float* __restrict__ report) {
@@ -128,10 +142,6 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
         L.add(p + "att", Bn * R);
         L.alias(p + "pooled", "S/pooled", k * Bn * D, Bn * D); L.alias(p + "vl_pre", "S/vl_pre", k * Bn * H, Bn * H);
         L.add(p + "valid", Bn); L.add(p + "inv_valid", 4);
-        L.add(p + "blanks_s", Bn * T); L.add(p + "lens_s", Bn);
-        L.add(p + "x_tm", T * Bn * x_stride(W)); L.add(p + "xp", T * Bn * 3 * H); L.add(p + "hs", (T + 1) * Bn * H);
-        L.add(p + "gru_r", T * Bn * H); L.add(p + "gru_u", T * Bn * H); L.add(p + "gru_c", T * Bn * H);
-        L.add(p + "gru_rh", T * Bn * H);
         L.alias(p + "bf_state", "S/lft", k * Bn * H, Bn * H);
         L.add(p + "wse", Bn * W); L.add(p + "ws", Bn * W);
         L.add(p + "wf_pre", Bn * H); L.alias(p + "wf", "S/lft", (2 + k) * Bn * H, Bn * H);
@@ -149,14 +159,20 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
             L.alias(q + "stats", "S/stats", ln * Bn * 4, Bn * 4);
         }
     }
+    // blank-fill captions of BOTH categories as one batch of 2 Bn rows (object rows first), time-major: the GRU weights are
+    // shared, so one recurrence over 5120 rows replaces two over 2560 (half the step launches, tiles that fill the chip)
+    L.add("J/blanks_s", 2 * Bn * T); L.add("J/lens_s", 2 * Bn);
+    L.add("J/x_tm", T * 2 * Bn * x_stride(W)); L.add("J/xp", T * 2 * Bn * 3 * H); L.add("J/hs", (T + 1) * 2 * Bn * H);
+    L.add("J/gru_r", T * 2 * Bn * H); L.add("J/gru_u", T * 2 * Bn * H); L.add("J/gru_c", T * 2 * Bn * H);
+    L.add("J/gru_rh", T * 2 * Bn * H);
     L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", x_stride(W) * 3 * H);      // packed x rows of the GRU kernels
     L.add("report", 16);
     // backward scratch, shared by the two categories
     L.add("d_j", 4 * Bn * 2 * H); L.add("d_jpre", 4 * Bn * 2 * H); L.add("d_jin", 4 * Bn * H);
     L.add("d_vl", 4 * Bn * H); L.add("d_ll", 4 * Bn * H); L.add("d_vlpre", 4 * Bn * H); L.add("d_llpre", 4 * Bn * H);
     L.add("d_lft", 4 * Bn * H); L.add("d_pooled", 2 * Bn * D);
-    L.add("d_state_s", Bn * H); L.add("d_hscratch", Bn * H);
-    L.add("dxp", T * Bn * 3 * H); L.add("dx", T * Bn * W);
+    L.add("d_state_s", 2 * Bn * H); L.add("d_hscratch", 2 * Bn * H);
+    L.add("dxp", T * 2 * Bn * 3 * H); L.add("dx", T * 2 * Bn * W);
     L.add("d_wfpre", Bn * H); L.add("d_ws", Bn * W); L.add("d_wse", Bn * W);
     L.add("d_v", B * R * H); L.add("d_vpre", B * R * H); L.add("d_qv", Bn * H); L.add("d_qvpre", Bn * H);
     L.add("part_a", B * 2 * H); L.add("part_b", B * 2 * H); L.add("part_c", B * 2 * H);
@@ -170,7 +186,8 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     };
     g(0, 0, B * R, H, 6); g(0, 0, Bn, H, 6); g(0, 0, Bn, H, D); g(0, 0, Bn, H, H); g(0, 0, Bn, 2 * H, H);
     g(0, 0, Bn, A, 2 * H);
-    g(0, 0, T * Bn, 3 * H, W); g(0, 1, T * Bn, W, 3 * H); g(1, 0, x_stride(W), 3 * H, T * Bn);      // packed x-projection
+    g(0, 0, 2 * T * Bn, 3 * H, W); g(0, 1, 2 * T * Bn, W, 3 * H); g(1, 0, x_stride(W), 3 * H, 2 * T * Bn);      // packed x-projection
+    g(1, 0, H, 2 * H, 2 * T * Bn); g(1, 0, H, H, 2 * T * Bn);
     g(0, 0, 2 * Bn, H, D); g(0, 0, 4 * Bn, H, H); g(0, 0, 4 * Bn, 2 * H, H); g(0, 0, 4 * Bn, A, 2 * H);      // stacked heads
     g(1, 0, 2 * H, A, 4 * Bn); g(0, 1, 4 * Bn, 2 * H, A); g(1, 0, H, 2 * H, 4 * Bn); g(0, 1, 4 * Bn, H, 2 * H);
     g(1, 0, D, H, 2 * Bn); g(0, 1, 2 * Bn, D, H); g(1, 0, H, H, 4 * Bn); g(0, 1, 4 * Bn, H, H); g(0, 0, T * Bn, 2 * H, W); g(0, 0, T * Bn, H, W); g(0, 0, Bn, H, W);
@@ -186,7 +203,7 @@ Layout make_layout(const vqa_pretrain_dims_t& d) {
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * Bn), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)Bn, (int)H));
     L.add("colsum_ws", 3 * cw);
-    L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * Bn * W), 4));
+    L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(2 * T * Bn * W), 4));
     return L;
 }
 
@@ -300,6 +317,16 @@ int gather_rows(const void* in, const int32_t* index, void* out, int64_t rows, i
     return VQA_OK;
 }
 
+int gather_rows2(const void* in0, const void* in1, const int32_t* index, void* out, int64_t rows, int64_t cols,
+                 int64_t rows0, hipStream_t st) {
+    if (rows * cols == 0) return VQA_OK;
+    const int grid = (int)std::min<int64_t>((rows * cols + 255) / 256, 4096);
+    hipLaunchKernelGGL(gather_rows2_kernel, dim3(grid), dim3(256), 0, st, static_cast<const uint32_t*>(in0),
+                       static_cast<const uint32_t*>(in1), index, static_cast<uint32_t*>(out), (int)rows, (int)cols, (int)rows0);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
 const char* const REPORT_KEYS[13] = {
     "obj_blank_fill_loss", "obj_blank_fill_acc", "obj_blank_fill_top_5_acc", "obj_wordset_loss", "obj_wordset_acc",
     "obj_wordset_top_5_acc", "attr_blank_fill_loss", "attr_blank_fill_acc", "attr_blank_fill_top_5_acc",
@@ -336,6 +363,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     const int64_t B = dims->B, n = dims->n, R = dims->R, D = dims->D, H = dims->H, W = dims->W, A = dims->A, T = dims->L;
     const int64_t Bn = B * n;
     VQA_REQUIRE(bt->image_ft && bt->spatial_ft && bt->num_boxes, VQA_ERR_ARG);
+    VQA_REQUIRE((bt->perm == nullptr) == (bt->inv == nullptr) && (bt->perm == nullptr) == (bt->live_rows == nullptr), VQA_ERR_ARG);
     ReportArgs ra{};
     ra.rows = (int)Bn;
     // the x rows of the two GRU kernels side by side (vqa_gru_pack_wx): one projection GEMM per category
@@ -343,8 +371,6 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     for (int k = 0; k < 2; ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         VQA_REQUIRE(kb.normal_boxes && kb.fills && kb.blanks && kb.blanks_len && kb.wordsets && kb.num, VQA_ERR_ARG);
-        VQA_REQUIRE((kb.perm == nullptr) == (kb.inv == nullptr) && (kb.perm == nullptr) == (kb.live_rows == nullptr),
-                    VQA_ERR_ARG);
         const std::string p = std::string(KIND[k]) + "/";
         // ---- build_*_V_ft: spatial attention over the regions
         hipLaunchKernelGGL(box6_kernel, dim3((unsigned)((Bn + 255) / 256)), dim3(256), 0, c.st, kb.normal_boxes,
@@ -361,30 +387,35 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
                            (int)B, (int)n);
         VQA_CHECK_LAUNCH();
 
-        // ---- build_*_blank_fill: captions in length order when the host sorted them (live prefix recurrence)
-        TRY(gather_rows(kb.blanks, kb.perm, c.i32(p + "blanks_s"), Bn, T, c.st));
-        TRY(gather_rows(kb.blanks_len, kb.perm, c.i32(p + "lens_s"), Bn, 1, c.st));
-        TRY(vqa_embed_fwd_ld(P->l_glove, c.i32(p + "blanks_s"), c.f(p + "x_tm"), (int)Bn, (int)T, (int)W, dims->Vq,
-                             (int)x_stride(W), c.st));
-        float* xp = c.f(p + "xp");
-        TRY(c.gemm(0, 0, T * Bn, 3 * H, W, c.f(p + "x_tm"), (int)x_stride(W), c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H),
-                   c.f("bx_cat")));
-        float* hs = c.f(p + "hs");
-        if (hipMemsetAsync(hs, 0, (size_t)Bn * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
-        const float* Wg_h = P->gru_wg + W * 2 * H;
-        const float* Wc_h = P->gru_wc + W * H;
-        if (kb.live_rows != nullptr)
-            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, c.i32(p + "lens_s"), kb.live_rows, hs, c.f(p + "gru_r"),
-                                     c.f(p + "gru_u"), c.f(p + "gru_c"), c.f(p + "gru_rh"), (int)T, (int)Bn, (int)H, c.st));
-        else
-            TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
-                                c.f(p + "gru_c"), c.f(p + "gru_rh"), (int)T, (int)Bn, (int)H, c.st));
-        TRY(gather_rows(hs + T * Bn * H, kb.inv, c.f(p + "bf_state"), Bn, H, c.st));      // back to caption order
         // ---- build_*_wordset
         TRY(vqa_embed_fwd(P->wordset_map, kb.wordsets, c.f(p + "wse"), (int)Bn, 1, (int)W, dims->n_ws, c.st));
         TRY(vqa_tanh_fwd(c.f(p + "wse"), c.f(p + "ws"), Bn * W, c.st));
         TRY(fc_ln_fwd(c, c.f(p + "ws"), Bn, W, H, P->wordset_ft, k, (int)n, 1, p + "wf_pre", p + "wf", p + "wf_mean",
                       p + "wf_rstd", nullptr, 1.f));
+    }
+    // ---- build_*_blank_fill of BOTH categories as one batch (shared L_GloVe / GRU weights): captions in length order
+    // when the host sorted them (live prefix recurrence); the final states go back to caption order as rows
+    // [0, Bn) = obj/bf_state and [Bn, 2 Bn) = attr/bf_state of the stacked "S/lft" block
+    {
+        const int64_t B2 = 2 * Bn;
+        TRY(gather_rows2(bt->kind[0].blanks, bt->kind[1].blanks, bt->perm, c.i32("J/blanks_s"), B2, T, Bn, c.st));
+        TRY(gather_rows2(bt->kind[0].blanks_len, bt->kind[1].blanks_len, bt->perm, c.i32("J/lens_s"), B2, 1, Bn, c.st));
+        TRY(vqa_embed_fwd_ld(P->l_glove, c.i32("J/blanks_s"), c.f("J/x_tm"), (int)B2, (int)T, (int)W, dims->Vq,
+                             (int)x_stride(W), c.st));
+        float* xp = c.f("J/xp");
+        TRY(c.gemm(0, 0, T * B2, 3 * H, W, c.f("J/x_tm"), (int)x_stride(W), c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H),
+                   c.f("bx_cat")));
+        float* hs = c.f("J/hs");
+        if (hipMemsetAsync(hs, 0, (size_t)B2 * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+        const float* Wg_h = P->gru_wg + W * 2 * H;
+        const float* Wc_h = P->gru_wc + W * H;
+        if (bt->live_rows != nullptr)
+            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, c.i32("J/lens_s"), bt->live_rows, hs, c.f("J/gru_r"), c.f("J/gru_u"),
+                                     c.f("J/gru_c"), c.f("J/gru_rh"), (int)T, (int)B2, (int)H, c.st));
+        else
+            TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, c.i32("J/lens_s"), hs, c.f("J/gru_r"), c.f("J/gru_u"), c.f("J/gru_c"),
+                                c.f("J/gru_rh"), (int)T, (int)B2, (int)H, c.st));
+        TRY(gather_rows(hs + T * B2 * H, bt->inv, c.f("S/lft"), B2, H, c.st));      // back to caption order
     }
     // ---- the four heads, stacked (ln = 2 t + k; see make_layout): every shared FC is one GEMM, LayerNorm (its own
     // gamma / beta per head) and the loss run per slice
@@ -484,36 +515,39 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(c.gemm(0, 1, 2 * Bn, D, H, c.f("d_vlpre"), (int)H, P->pooled_linear_l.w, (int)H, c.f("d_pooled"), (int)D));
         TRY(fc_bwd(c, acc, "d_llpre", c.f("S/lft"), 4 * Bn, H, H, P->q_linear_l, G->q_linear_l, c.f("d_lft")));
     }
+    // ---- blank fill -> GRU -> L_GloVe, both categories as the one batch of the forward
+    {
+        const int64_t B2 = 2 * Bn;
+        TRY(gather_rows(c.f("d_lft"), bt->perm, c.f("d_state_s"), B2, H, c.st));   // rows [0, 2 Bn) of d_lft, into the sorted order
+        const float* Wg_h = P->gru_wg + W * 2 * H;
+        const float* Wc_h = P->gru_wc + W * H;
+        float* dxp = c.f("dxp");
+        const float* hs = c.f("J/hs");
+        if (bt->live_rows != nullptr)
+            TRY(vqa_gru_seq_bwd_live(c.f("d_state_s"), Wg_h, Wc_h, c.i32("J/lens_s"), bt->live_rows, hs, c.f("J/gru_r"),
+                                     c.f("J/gru_u"), c.f("J/gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)B2, (int)H, c.st));
+        else
+            TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32("J/lens_s"), hs, c.f("J/gru_r"), c.f("J/gru_u"),
+                                c.f("J/gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)B2, (int)H, c.st));
+        const int ld3 = (int)(3 * H);
+        // x rows of both kernels' gradients as one GEMM into the packed [Wp, 3H] block; x_tm carries the constant 1 in
+        // column W, so row W of the block is the two bias gradients and dxp is not read again for them.  The h rows
+        // as before
+        const int64_t Wp = x_stride(W);
+        TRY(acc.weight(c.f("dwx_cat"), c.f("J/x_tm"), (int)Wp, dxp, ld3, Wp, 3 * H, T * B2));
+        TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * B2));
+        TRY(acc.weight(G->gru_wc + W * H, c.f("J/gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * B2));
+        TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
+        float* dx = c.f("dx");
+        TRY(c.gemm(0, 1, T * B2, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));   // packed by the forward
+        TRY(vqa_embed_bwd_len_det(dx, c.i32("J/blanks_s"), c.i32("J/lens_s"), G->l_glove, (int)B2, (int)T, (int)W,
+                                  dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
+        TRY(add_slice_sq(dx, T * B2 * W));
+    }
     for (int k = 0; k < 2; ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         const std::string p = std::string(KIND[k]) + "/";
         const float* d_pooled = c.f("d_pooled") + k * Bn * D;
-        // ---- blank fill -> GRU -> L_GloVe
-        TRY(gather_rows(c.f("d_lft") + k * Bn * H, kb.perm, c.f("d_state_s"), Bn, H, c.st));   // into the sorted order
-        const float* Wg_h = P->gru_wg + W * 2 * H;
-        const float* Wc_h = P->gru_wc + W * H;
-        float* dxp = c.f("dxp");
-        const float* hs = c.f(p + "hs");
-        if (kb.live_rows != nullptr)
-            TRY(vqa_gru_seq_bwd_live(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), kb.live_rows, hs, c.f(p + "gru_r"),
-                                     c.f(p + "gru_u"), c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H,
-                                     c.st));
-        else
-            TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32(p + "lens_s"), hs, c.f(p + "gru_r"), c.f(p + "gru_u"),
-                                c.f(p + "gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)Bn, (int)H, c.st));
-        const int ld3 = (int)(3 * H);
-        // x rows of both kernels' gradients as one GEMM into the packed [Wp, 3H] block (summed over the categories
-        // there, unpacked once after the loop); x_tm carries the constant 1 in column W, so row W of the block is the
-        // two bias gradients and dxp is not read again for them.  The h rows as before
-        const int64_t Wp = x_stride(W);
-        TRY(acc.weight(c.f("dwx_cat"), c.f(p + "x_tm"), (int)Wp, dxp, ld3, Wp, 3 * H, T * Bn));
-        TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * Bn));
-        TRY(acc.weight(G->gru_wc + W * H, c.f(p + "gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * Bn));
-        float* dx = c.f("dx");
-        TRY(c.gemm(0, 1, T * Bn, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));   // packed by the forward
-        TRY(vqa_embed_bwd_len_det(dx, c.i32(p + "blanks_s"), c.i32(p + "lens_s"), G->l_glove, (int)Bn, (int)T, (int)W,
-                                  dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
-        TRY(add_slice_sq(dx, T * Bn * W));
         // ---- word set -> wordset_ft -> tanh -> wordset_map
         TRY(fc_ln_bwd(c, acc, c.f("d_lft") + (2 + k) * Bn * H, c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, k, (int)n, 1, p + "wf_pre",
                       p + "wf_mean", p + "wf_rstd", nullptr, 1.f, "d_wfpre", c.f("d_ws")));
@@ -532,7 +566,6 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, k, (int)n, 0,
                       p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
     }
-    TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
     if (slice_sq != nullptr && sq_prev != nullptr)
         if (hipMemcpyAsync(slice_sq, sq_prev, sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
             return VQA_ERR_LAUNCH;

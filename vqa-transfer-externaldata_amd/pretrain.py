@@ -78,21 +78,21 @@ def init_random_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024):
 
 
 def add_length_sort(batch):
-    """Host-side: for each blank-fill category the permutation that orders the B*n captions by length (longest
-    first), its inverse and live_rows[t] = #captions longer than t.  The engine then embeds / encodes the
-    captions in that order, runs every GRU step on the live prefix only, and un-permutes the final states."""
-    for k in ("obj", "attr"):
-        kl, kb = k + "_blank_fill/blanks_len", k + "_blank_fill/blanks"
-        if kl not in batch or torch.is_tensor(batch[kl]):
-            continue
-        lens = np.asarray(batch[kl]).reshape(-1).astype(np.int64)
-        L = int(np.asarray(batch[kb]).shape[-1])
-        perm = np.argsort(-lens, kind="stable")
-        inv = np.empty_like(perm)
-        inv[perm] = np.arange(len(perm))
-        sl = np.clip(lens[perm], 0, L)
-        batch[k + "_blank_fill/sort"] = {"perm": perm, "inv": inv,
-                                         "live_rows": (sl[None, :] > np.arange(L)[:, None]).sum(1).astype(np.int32)}
+    """Host-side: the blank-fill captions of both categories are encoded as ONE batch of 2*B*n rows (object rows first).
+    This adds 'blank_fill/sort' = the permutation that orders those rows by length (longest first), its inverse and
+    live_rows[t] = #captions longer than t.  The engine then embeds / encodes the captions in that order, runs every GRU
+    step on the live prefix only, and un-permutes the final states."""
+    keys = [k + "_blank_fill/blanks_len" for k in KINDS]
+    if any(k not in batch or torch.is_tensor(batch[k]) for k in keys):
+        return batch
+    lens = np.concatenate([np.asarray(batch[k]).reshape(-1) for k in keys]).astype(np.int64)
+    L = int(np.asarray(batch[KINDS[0] + "_blank_fill/blanks"]).shape[-1])
+    perm = np.argsort(-lens, kind="stable")
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    sl = np.clip(lens[perm], 0, L)
+    batch["blank_fill/sort"] = {"perm": perm, "inv": inv,
+                                "live_rows": (sl[None, :] > np.arange(L)[:, None]).sum(1).astype(np.int32)}
     return batch
 
 
@@ -229,16 +229,16 @@ class PretrainEngine:
                 kb.keep_att = masks[k + "/att"].data_ptr()
                 kb.keep_bf_joint = masks[k + "/bf_joint"].data_ptr()
                 kb.keep_ws_joint = masks[k + "/ws_joint"].data_ptr()
-            srt = batch.get(pre + "sort")
-            if srt is not None:       # captions in length order: the recurrence skips finished ones (add_length_sort)
-                if "_dev" not in srt:
-                    live = np.ascontiguousarray(srt["live_rows"], dtype=np.int32)
-                    assert live.shape == (Lk,)
-                    srt["_dev"] = (self._dev(np.asarray(srt["perm"]), torch.int32),
-                                   self._dev(np.asarray(srt["inv"]), torch.int32), live)
-                perm, inv, live = srt["_dev"]
-                kb.perm, kb.inv, kb.live_rows = perm.data_ptr(), inv.data_ptr(), live.ctypes.data
-                keep.append(srt["_dev"])
+        srt = batch.get("blank_fill/sort")
+        if srt is not None:       # captions in length order: the recurrence skips finished ones (add_length_sort)
+            if "_dev" not in srt:
+                live = np.ascontiguousarray(srt["live_rows"], dtype=np.int32)
+                assert live.shape == (L,) and len(srt["perm"]) == 2 * int(cache[KINDS[0] + "_blank_fill/blanks_len"].numel())
+                srt["_dev"] = (self._dev(np.asarray(srt["perm"]), torch.int32),
+                               self._dev(np.asarray(srt["inv"]), torch.int32), live)
+            perm, inv, live = srt["_dev"]
+            bs.perm, bs.inv, bs.live_rows = perm.data_ptr(), inv.data_ptr(), live.ctypes.data
+            keep.append(srt["_dev"])
         return bs, B, L, keep
 
     def tensor(self, name, dtype=torch.float32):
@@ -253,7 +253,7 @@ class PretrainEngine:
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, batch, masks, want_dz=True):
-        """batch: dict of arrays / tensors (keys of dataset_vlmap's batches; optional '<kind>_blank_fill/sort' from
+        """batch: dict of arrays / tensors (keys of dataset_vlmap's batches; optional 'blank_fill/sort' from
         add_length_sort); masks: uint8 keep-masks keyed '<kind>/att|bf_joint|ws_joint' or None (no dropout)."""
         bs, B, L, keep = self._batch_struct(batch, masks)
         d = _lib.PtDims(B=B, n=self.n, R=self.R, D=self.D, H=self.H, W=self.W, A=self.A, Vq=self.Vq, n_ws=self.n_ws, L=L,
