@@ -89,15 +89,40 @@ class Model(object):
                 out[k] = out[k].float()
         if getattr(self.config, "sort_by_length", 1):
             host = PT.add_length_sort({k: v for k, v in self.batch.items() if k.endswith(("/blanks", "/blanks_len"))})
-            out.update({k: v for k, v in host.items() if k.endswith("/sort")})
+            for k, v in host.items():
+                if k.endswith("/sort"):       # permutation / inverse uploaded here (on the stream of prepare())
+                    v["_dev"] = (torch.from_numpy(np.asarray(v["perm"])).to(self.device, torch.int32),
+                                 torch.from_numpy(np.asarray(v["inv"])).to(self.device, torch.int32),
+                                 np.ascontiguousarray(v["live_rows"], dtype=np.int32))
+                    out[k] = v
         for k in list(out):
             if k.endswith("_blank_fill/normal_boxes"):
                 out[k] = out[k].float()
         return out
 
-    def build(self):
-        """build network architecture and loss (here: run it on self.batch)"""
-        db = self._device_batch()
+    def prepare(self, batch):
+        """Host side of a step for `batch`, ahead of time: device copies (on a side stream, so they do not queue behind
+        the step the GPU is running) and the length sort.  Returns a handle for build(prepared=...).  The trainer
+        calls this for batch i+1 right after it has queued step i (the reference's tf.data pipeline prefetches the
+        same way, vlmap_memft/datasets/dataset_vlmap.py:308-353)."""
+        self.batch = batch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._side):
+            db = self._device_batch()
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        return db, ev
+
+    def build(self, prepared=None, defer_report=False):
+        """build network architecture and loss (here: run it on self.batch, or on the batch handed to prepare()).
+        defer_report: queue the forward only; finish_report() then fetches the 13 scalars (one host sync per step,
+        after backward and the update have been queued as well)."""
+        if prepared is None:
+            db = self._device_batch()
+        else:
+            db, ev = prepared
+            torch.cuda.current_stream(self.device).wait_event(ev)
         if self._engine is None:
             cfg = self.data_cfg
             shapes = PT.variable_shapes(len(self.vocab["vocab"]), self.num_ws, self.num_answer, W_DIM, cfg.vfeat_dim,
@@ -114,14 +139,31 @@ class Model(object):
             B, int(getattr(self.config, "seed", 123)), self._step)
         self._step += 1
         eng.forward(db, masks)
-        self.report = eng.fetch_report()
-        self.losses = {k[:-5]: v for k, v in self.report.items() if k.endswith("_loss") and k != "total_loss"}
-        self.loss = self.report["total_loss"]
         for k in PT.KINDS:
             kt = eng._tape["kinds"][k]
             name = "object" if k == "obj" else "attribute"
             self.mid_result[name + "_pooled_V_ft"] = kt["pooled"].view(B, eng.n, -1)
             self.mid_result[k + "_blank_fill/logit"] = kt["wordset"]["z"].view(B, eng.n, -1)
+        if defer_report:
+            if getattr(self, "_report_host", None) is None:
+                self._report_host = torch.empty(16, dtype=torch.float32).pin_memory()
+            self._report_host.copy_(eng.tensor("report")[:16], non_blocking=True)      # stream-ordered after the forward
+            self._report_event = torch.cuda.Event()
+            self._report_event.record(torch.cuda.current_stream(self.device))
+            return None
+        return self.finish_report()
+
+    def finish_report(self):
+        eng = self._engine
+        if getattr(self, "_report_event", None) is not None:
+            self._report_event.synchronize()
+            r = self._report_host.numpy()
+            self.report = eng.report = {eng.lib.vqa_pretrain_report_key(i).decode(): float(r[i]) for i in range(13)}
+            self._report_event = None
+        else:
+            self.report = eng.fetch_report()
+        self.losses = {k[:-5]: v for k, v in self.report.items() if k.endswith("_loss") and k != "total_loss"}
+        self.loss = self.report["total_loss"]
         return self.loss
 
     def backward(self):

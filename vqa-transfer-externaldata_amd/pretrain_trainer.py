@@ -91,10 +91,15 @@ class Trainer(object):
 
     def run_train_step(self, use_heavy_summary):
         _start = time.time()
-        self.model.set_batch(self._next("train"))
-        self.model.build()
+        prepared, self._prepared = getattr(self, "_prepared", None), None
+        if prepared is None:
+            prepared = self.model.prepare(self._next("train"))
+        self.model.build(prepared=prepared, defer_report=True)
         self.model.backward()
         self.model.apply_gradients(self._lr())
+        # the GPU is busy with this step: draw the next batch and upload it now (tf.data prefetch of the reference)
+        self._prepared = self.model.prepare(self._next("train"))
+        self.model.finish_report()
         torch.cuda.synchronize(self.model.device)
         self.global_step += 1
         report = dict(self.model.report)
@@ -103,7 +108,7 @@ class Trainer(object):
 
     def run_val_step(self, use_heavy_summary):
         _start = time.time()
-        self.model.set_batch(self._next("val"))
+        self.model.set_batch(self._next("val"))     # (a prepared train batch, if any, stays queued for the next train step)
         self.model.build()
         torch.cuda.synchronize(self.model.device)
         report = dict(self.model.report)
