@@ -44,6 +44,9 @@ if os.environ.get("TUNE_SET") == "pretrain":      # cfg-5 pre-training step: 256
     ]
 
 
+if os.environ.get("TUNE_ONLY"):       # a subset of the shapes by name
+    SHAPES = [s for s in SHAPES if s[0] in os.environ["TUNE_ONLY"].split(",")]
+
 CFGS = [int(x) for x in os.environ.get('TUNE_CFGS', '0,1,3,4,6,7,10,11,12,13').split(',')]
 
 
