@@ -607,6 +607,22 @@ def test_ln_register_resident_kernels_equal_generic(drop, G, rows, N):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-6 * float(a.abs().max()))
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_persistent_gru_xcd_local_chains_in_a_fresh_process(mode):
+    """VQA_GRU_PERSIST_XCD (read once per process): eight chains of rows, one per XCD, 32-row tiles with 8 waves (1) or
+    64-row tiles with 16 waves (2); same results as the per-step kernels, also with empty chains and a ragged last tile
+    (B 70 -> chains of 32 / 64 rows, most of them empty)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VQA_GRU_PERSIST_XCD=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_ops.py", "-m", "gpu", "-q", "-x", "-k",
+                        "test_persistent_gru_forward_equals_stepwise", "-p", "no:cacheprovider"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize("T,B,H", [(5, 96, 512), (14, 512, 1024), (3, 70, 512)])
 def test_persistent_gru_forward_equals_stepwise(T, B, H):
     """vqa_gru_seq_fwd_persistent (one launch, two chains, per-chain grid barriers with write-through hand-offs)
@@ -634,8 +650,14 @@ def test_persistent_gru_forward_equals_stepwise(T, B, H):
             _lib.check(lib.vqa_gru_seq_fwd_persistent(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H,
                                                       P(sync), None), "persistent")
             torch.cuda.synchronize()
-            slots = int(sync[0]) // (2 * T)
-            assert int(sync[32]) == 0 and int(sync[0]) == int(sync[16]) == 2 * T * slots and slots >= 64
+            import os
+            if os.environ.get("VQA_GRU_PERSIST_XCD", "0") in ("1", "2"):      # eight XCD-local chains (experiment)
+                per_chain = int(sync[0]) // (2 * T)
+                assert int(sync[192]) == 0 and per_chain >= 8
+                assert all(int(sync[16 * x]) == 2 * T * per_chain for x in range(8))
+            else:
+                slots = int(sync[0]) // (2 * T)
+                assert int(sync[32]) == 0 and int(sync[0]) == int(sync[16]) == 2 * T * slots and slots >= 64
         else:
             _lib.check(lib.vqa_gru_seq_fwd(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, None), "stepwise")
             torch.cuda.synchronize()

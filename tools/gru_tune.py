@@ -60,7 +60,8 @@ if os.environ.get("PERSIST") == "1":
         x.fill_(float("nan"))
     hs[1:].fill_(float("nan"))
     fwd_persistent(); torch.cuda.synchronize()
-    print("persistent: sync words", sync[[0, 16, 32]].tolist(), flush=True)
+    print("persistent: sync words [0, 16, 32, 192]", sync[[0, 16, 32, 192]].tolist(),
+          "(xcd mode: chain counters at 16 * chain, error word 192)" if os.environ.get("VQA_GRU_PERSIST_XCD") == "1" else "", flush=True)
     census = torch.zeros(1024 + 2 * 64 * 4 * 2, dtype=torch.int32, device="cuda")
     lib.vqa_gru_persistent_set_census(P(census)); fwd_persistent(); torch.cuda.synchronize(); lib.vqa_gru_persistent_set_census(None)
     cz = census[:512].cpu().numpy().astype("int64")

@@ -50,6 +50,9 @@ struct PkArgs {
     unsigned spin_limit;
     int chain1_delay;     // tuning: chain 1 starts this many 100 MHz ticks late (phase offset between the chains)
     unsigned* census;     // optional [gridDim.x]: (XCC_ID << 16) | HW_ID[15:0] of every workgroup (placement study)
+    int xcd_mode;         // experiment: EIGHT chains of chain_rows rows, chain = blockIdx.x & 7 (one per XCD), one
+                          // workgroup per CU; counters at sync[16 * chain]
+    unsigned* err;        // error word (sync[32]; sync[192] in xcd_mode)
 };
 
 __device__ __forceinline__ f32x4n bload(__amdgpu_buffer_rsrc_t rs, unsigned off, bool sc1) {
@@ -91,12 +94,21 @@ __device__ __forceinline__ void pk_wait(unsigned* ctr, unsigned target, unsigned
 // One output tile of one phase.  GATES: BN 64, BK 64, WGK 4.  CAND: BN 32, BK 128, WGK 8.
 //   A [rows, K] k-contiguous, handed off by the previous phase -> sc1 loads;  B [K, N] weights, plain loads.
 // B's first tile is fetched BEFORE the barrier wait (weights do not depend on it).
-template <bool GATES>
+// BM 32: 8 waves (the two-chain form, two workgroups per CU).  BM 64: 16 waves, two 32-row halves (wm) that share the
+// weight tile -- one 64-row tile per workgroup, CU and phase in the XCD-local form.
+template <bool GATES, int BM>
 __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int row_hi, int m0, int n0, float* smem,
                                         unsigned* ctr, unsigned target) {
-    constexpr int BN = GATES ? 64 : 32, BK = GATES ? 64 : 128, WGK = GATES ? 4 : 8;
-    constexpr int WAVES_N = BN / 32;
-    static_assert(WAVES_N * WGK * 64 == PK_NT, "one 32x32 tile per (column sub-tile, k-group) wave");
+    constexpr int PK_BM = BM, PK_NT = BM * 16;
+    constexpr int BN = GATES ? 64 : 32, BK = (GATES && BM == 32) ? 64 : 128, WGK = GATES ? 4 : 8;   // 16 waves: half the barriers
+    constexpr int WAVES_N = BN / 32, WAVES_M = BM / 32;
+    // Hand-offs are stored write-through (sc1) in both forms.  The two-chain form reads them back with sc1 loads (its
+    // producers sit on other XCDs).  In the XCD-local form (BM 64) producer and consumer share an L2, every address is
+    // written once per launch before anyone reads it and a 4 KB row never straddles two chains, so a plain load either
+    // hits the producer's line in this L2 or -- should a workgroup ever be placed on another XCD -- misses and fetches
+    // what the write-through store put in memory.
+    constexpr bool LD_SC1 = (BM == 32);
+    static_assert(WAVES_M * WAVES_N * WGK * 64 == PK_NT, "one 32x32 tile per (row half, column sub-tile, k-group) wave");
     constexpr int A_LD = BK + 4;
     constexpr int A_FL = PK_BM * A_LD, B_FL = BK * BN;
     constexpr int NVA = PK_BM * BK / 4 / PK_NT, NVB = BK * BN / 4 / PK_NT;
@@ -104,7 +116,8 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     const int H = a.H, K = H, B = a.B;
     const int N = GATES ? 2 * H : H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wk = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wm = wave / (WAVES_N * WGK), wrest = wave % (WAVES_N * WGK);
+    const int wk = wrest / WAVES_N, wn = wrest % WAVES_N;
     const int64_t BH = (int64_t)B * H;
 
     const float* Aop = GATES ? a.hs + (int64_t)t * BH : a.rh + (int64_t)t * BH;      // [B, H]
@@ -131,7 +144,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     // fetched DA tiles ahead into a register queue (tile j lives in slot j % DA); the weights stay in this XCD's L2
     // and need one tile of cover.  Issue order inside an iteration is weights first, far A tile second, so waiting
     // for the weights (in-order vmcnt) leaves the far loads in flight.
-    constexpr int DA = GATES ? 4 : 2;
+    constexpr int DA = (GATES && BM == 32) ? 4 : 2;
     f32x4n ra[DA][NVA], rb[NVB];
     auto loadB = [&](int kt) {
 #pragma unroll
@@ -139,7 +152,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     };
     auto loadA = [&](f32x4n (&dst)[NVA], int kt) {
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) dst[i] = bload(rsA, offA[i] + (unsigned)(kt * BK) * 4u, true);
+        for (int i = 0; i < NVA; ++i) dst[i] = bload(rsA, offA[i] + (unsigned)(kt * BK) * 4u, LD_SC1);
     };
     auto stash = [&](float* L, const f32x4n (&srcA)[NVA]) {
 #pragma unroll
@@ -161,7 +174,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     if (stamp) stamp[0] = wall_clock64();
     loadB(0);
     // ---- the barrier: everything below reads what the previous phase of this chain wrote
-    pk_wait(ctr, target, a.sync + 32, a.spin_limit);
+    pk_wait(ctr, target, a.err, a.spin_limit);
     if (stamp) stamp[1] = wall_clock64();
     const int nt = K / BK;                 // a multiple of DA (H % 512 == 0 is required by the host)
 #pragma unroll
@@ -171,7 +184,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     constexpr int RPG = 32 / WGK;                       // rows per k-group: 8 (gates) / 4 (candidate)
     const int e_lr = lane >> 3;                         // 0..7
     const bool e_act = e_lr < RPG;
-    const int e_row = wk * RPG + e_lr;                  // row inside the 32-row tile
+    const int e_row = wm * 32 + wk * RPG + e_lr;        // row inside the BM-row tile
     const int grow = m0 + e_row, gcol = n0 + wn * 32 + (lane & 7) * 4;
     const bool e_ok = e_act && grow < row_hi;
     const __amdgpu_buffer_rsrc_t rsXp = mkrs(a.xp + (int64_t)t * B * 3 * H, (int64_t)B * 3 * H * 4);
@@ -183,9 +196,9 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
         const unsigned oxp = e_ok ? (unsigned)(((int64_t)grow * 3 * H + (GATES ? 0 : 2 * H) + gcol) * 4) : PK_OOB;
         e_d = bload(rsXp, oxp, false);
         const unsigned ohp = (e_ok && (!GATES || gcol < H)) ? (unsigned)(((int64_t)grow * H + gcol) * 4) : PK_OOB;
-        e_h = bload(rsHp, ohp, true);
+        e_h = bload(rsHp, ohp, LD_SC1);
         if (!GATES) {
-            e_u = bload(rsU, e_ok ? (unsigned)(((int64_t)grow * H + gcol) * 4) : PK_OOB, true);
+            e_u = bload(rsU, e_ok ? (unsigned)(((int64_t)grow * H + gcol) * 4) : PK_OOB, LD_SC1);
             e_len = e_ok ? a.len[grow] : 0;
         }
     }
@@ -200,7 +213,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc) {
             const int c = cc * WGK + wk;
-            const f32x4n af = *reinterpret_cast<const f32x4n*>(As + i * A_LD + c * 8 + h * 4);
+            const f32x4n af = *reinterpret_cast<const f32x4n*>(As + (wm * 32 + i) * A_LD + c * 8 + h * 4);
             const float* pb = Bs + (c * 8 + h * 4) * BN + wn * 32 + i;
             const float b0 = pb[0], b1 = pb[BN], b2 = pb[2 * BN], b3 = pb[3 * BN];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, b0, acc, 0, 0, 0);
@@ -232,12 +245,12 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
 
     if (stamp) stamp[2] = wall_clock64();
     // ---- epilogue: the WGK partial tiles meet in LDS (transposed 32 x 36 patches), every k-group finishes RPG rows
-    float* stg = smem + (wk * WAVES_N + wn) * 32 * STG_LD;
+    float* stg = smem + ((wm * WGK + wk) * WAVES_N + wn) * 32 * STG_LD;
 #pragma unroll
     for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (lane & 31)] = acc[r];
     __syncthreads();
     if (e_ok) {
-        const float* src = smem + wn * 32 * STG_LD + e_row * STG_LD + (lane & 7) * 4;
+        const float* src = smem + (wm * WGK * WAVES_N + wn) * 32 * STG_LD + (wk * RPG + e_lr) * STG_LD + (lane & 7) * 4;
         f32x4n v = *reinterpret_cast<const f32x4n*>(src);
 #pragma unroll
         for (int g = 1; g < WGK; ++g) v += *reinterpret_cast<const f32x4n*>(src + g * WAVES_N * 32 * STG_LD);
@@ -268,7 +281,9 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     if (stamp) stamp[3] = wall_clock64();
 }
 
-__global__ __launch_bounds__(PK_NT, 4) void gru_fwd_persistent_kernel(PkArgs a) {
+template <int BM>
+__global__ __launch_bounds__(BM * 16, 4) void gru_fwd_persistent_kernel(PkArgs a) {
+    constexpr int PK_BM = BM;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // The first `slots` workgroups are chain 0, the rest chain 1: workgroups are dealt round-robin over the XCDs and
     // (observed) over an XCD's CUs before any CU gets its second one, so a CU tends to host one workgroup of each
@@ -278,11 +293,15 @@ __global__ __launch_bounds__(PK_NT, 4) void gru_fwd_persistent_kernel(PkArgs a) 
     if (a.census != nullptr && threadIdx.x == 0)
         a.census[blockIdx.x] = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 16) |      // HW_REG_XCC_ID[3:0]
                                (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xFFFFu);   // HW_REG_HW_ID[15:0]
-    const int slots = gridDim.x >> 1;
-    const int chain = blockIdx.x >= slots ? 1 : 0, raw = blockIdx.x - chain * slots;
-    const int slot = (slots % 8 == 0) ? (raw & 7) * (slots >> 3) + (raw >> 3) : raw;
-    const int row_lo = chain ? a.chain_rows : 0;
-    const int row_hi = chain ? a.B : min(a.chain_rows, a.B);
+    // xcd_mode (experiment): the rows of a batch are independent sequences, so chain x = the workgroups with
+    // blockIdx.x % 8 == x (dealt to XCD x, see the census) owns rows [x * chain_rows, ...): its hand-offs and its
+    // barrier stay among the 32 workgroups of one XCD.
+    const int slots = a.xcd_mode ? (int)(gridDim.x >> 3) : (int)(gridDim.x >> 1);
+    const int chain = a.xcd_mode ? (int)(blockIdx.x & 7) : (blockIdx.x >= (unsigned)slots ? 1 : 0);
+    const int raw = a.xcd_mode ? (int)(blockIdx.x >> 3) : (int)blockIdx.x - chain * slots;
+    const int slot = (!a.xcd_mode && slots % 8 == 0) ? (raw & 7) * (slots >> 3) + (raw >> 3) : raw;
+    const int row_lo = a.xcd_mode ? min(chain * a.chain_rows, a.B) : (chain ? a.chain_rows : 0);
+    const int row_hi = a.xcd_mode ? min(row_lo + a.chain_rows, a.B) : (chain ? a.B : min(a.chain_rows, a.B));
     const int tiles_m = (row_hi - row_lo + PK_BM - 1) / PK_BM;
     const int tn_g = 2 * a.H / 64, tn_c = a.H / 32;
     unsigned* ctr = a.sync + chain * 16;
@@ -295,30 +314,31 @@ __global__ __launch_bounds__(PK_NT, 4) void gru_fwd_persistent_kernel(PkArgs a) 
         // gates
         bool did = false;
         for (int tile = slot; tile < tiles_m * tn_g; tile += slots) {
-            pk_tile<true>(a, t, row_lo, row_hi, row_lo + (tile % tiles_m) * PK_BM, (tile / tiles_m) * 64, smem, ctr,
+            pk_tile<true, BM>(a, t, row_lo, row_hi, row_lo + (tile % tiles_m) * PK_BM, (tile / tiles_m) * 64, smem, ctr,
                           phase * (unsigned)slots);
             did = true;
         }
-        if (!did) pk_wait(ctr, phase * (unsigned)slots, a.sync + 32, a.spin_limit);   // keep the phase order
+        if (!did) pk_wait(ctr, phase * (unsigned)slots, a.err, a.spin_limit);   // keep the phase order
         pk_arrive(ctr);
         ++phase;
         // candidate
         did = false;
         for (int tile = slot; tile < tiles_m * tn_c; tile += slots) {
-            pk_tile<false>(a, t, row_lo, row_hi, row_lo + (tile % tiles_m) * PK_BM, (tile / tiles_m) * 32, smem, ctr,
+            pk_tile<false, BM>(a, t, row_lo, row_hi, row_lo + (tile % tiles_m) * PK_BM, (tile / tiles_m) * 32, smem, ctr,
                            phase * (unsigned)slots);
             did = true;
         }
-        if (!did) pk_wait(ctr, phase * (unsigned)slots, a.sync + 32, a.spin_limit);
+        if (!did) pk_wait(ctr, phase * (unsigned)slots, a.err, a.spin_limit);
         pk_arrive(ctr);
         ++phase;
     }
 }
 
-constexpr size_t pk_lds_bytes() {
-    // max over the two phases of 2 x (A tile + B tile); the epilogue patches (8 x 32 x 36 floats) fit inside
-    constexpr size_t g = 2 * (PK_BM * (64 + 4) + 64 * 64), c = 2 * (PK_BM * (128 + 4) + 128 * 32);
-    constexpr size_t m = g > c ? g : c, p = 8 * 32 * STG_LD;
+constexpr size_t pk_lds_bytes(int bm = PK_BM) {
+    // max over the two phases of 2 x (A tile + B tile) and of the epilogue patches (one 32 x 36 patch per wave)
+    const size_t bkg = bm == 64 ? 128 : 64;
+    const size_t g = 2 * (bm * (bkg + 4) + bkg * 64), c = 2 * (bm * (128 + 4) + 128 * 32);
+    const size_t m = g > c ? g : c, p = (size_t)(bm / 4) * 32 * STG_LD;
     return (m > p ? m : p) * sizeof(float);
 }
 
@@ -338,7 +358,7 @@ extern "C" int vqa_gru_persistent_set_census(unsigned* dev_words) {
     return VQA_OK;
 }
 
-extern "C" int64_t vqa_gru_persistent_sync_bytes(void) { return 64 * sizeof(unsigned); }
+extern "C" int64_t vqa_gru_persistent_sync_bytes(void) { return 256 * sizeof(unsigned); }
 
 // 1 when the persistent form applies to this shape on this device (all workgroups co-resident), else 0
 extern "C" int vqa_gru_fwd_persistent_supported(int T, int B, int H) {
@@ -350,11 +370,14 @@ extern "C" int vqa_gru_fwd_persistent_supported(int T, int B, int H) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus = prop.multiProcessorCount;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<32>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes()) != hipSuccess)
             return 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(64)) != hipSuccess)
+            return 0;
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_fwd_persistent_kernel, PK_NT, pk_lds_bytes()) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_fwd_persistent_kernel<32>, PK_NT, pk_lds_bytes()) != hipSuccess)
             n = 0;
         blocks_per_cu = n;
     }
@@ -380,6 +403,21 @@ extern "C" int vqa_gru_seq_fwd_persistent(const float* xp, const float* Wg_h, co
     a.xp = xp; a.Wg = Wg_h; a.Wc = Wc_h; a.len = len; a.hs = hs; a.r = r; a.u = u; a.c = c; a.rh = rh; a.sync = sync;
     a.T = T; a.B = B; a.H = H;
     a.chain_rows = ((B + 1) / 2 + PK_BM - 1) / PK_BM * PK_BM;
+    a.xcd_mode = 0;
+    a.err = sync + 32;
+    {
+        static int xcd = -1;
+        if (xcd < 0) {
+            const char* e = getenv("VQA_GRU_PERSIST_XCD");
+            xcd = e ? atoi(e) : 0;
+        }
+        if (xcd && cus % 8 == 0) {       // experiment: eight XCD-local chains, one workgroup per CU
+            const int bm = xcd == 2 ? 64 : PK_BM;      // 2: one 64-row tile per workgroup and phase (16 waves)
+            a.xcd_mode = xcd == 2 ? 2 : 1;
+            a.chain_rows = ((B + 7) / 8 + bm - 1) / bm * bm;
+            a.err = sync + 192;
+        }
+    }
     a.spin_limit = 400000u;                       // ~0.5 s of polling before the launch gives up
     a.census = g_census;
     {
@@ -392,7 +430,10 @@ extern "C" int vqa_gru_seq_fwd_persistent(const float* xp, const float* Wg_h, co
     }
     // one workgroup per chain and CU: every workgroup of the grid must be resident at the same time
     const int slots = cus;
-    hipLaunchKernelGGL(gru_fwd_persistent_kernel, dim3(2 * slots), dim3(PK_NT), pk_lds_bytes(), st, a);
+    if (a.xcd_mode == 2)
+        hipLaunchKernelGGL(gru_fwd_persistent_kernel<64>, dim3(slots), dim3(1024), pk_lds_bytes(64), st, a);
+    else
+        hipLaunchKernelGGL(gru_fwd_persistent_kernel<32>, dim3(a.xcd_mode ? slots : 2 * slots), dim3(PK_NT), pk_lds_bytes(), st, a);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
