@@ -144,17 +144,21 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     // fetched DA tiles ahead into a register queue (tile j lives in slot j % DA); the weights stay in this XCD's L2
     // and need one tile of cover.  Issue order inside an iteration is weights first, far A tile second, so waiting
     // for the weights (in-order vmcnt) leaves the far loads in flight.
-    constexpr int DA = (GATES && BM == 32) ? 4 : 2;
-    f32x4n ra[DA][NVA], rb[NVB];
-    auto loadB = [&](int kt) {
+    // XCD-local form (BM 64): the left operand now comes from this XCD's L2 (one tile of cover is enough) while every
+    // XCD streams ALL of the weights each step (12 MB, more than its L2): the weights get the second tile of cover.
+    constexpr int DA = BM == 64 ? 1 : (GATES ? 4 : 2);
+    constexpr int DB = BM == 64 ? 2 : 1;
+    constexpr int UNR = DA > 2 ? DA : 2;
+    f32x4n ra[DA][NVA], rb[DB][NVB];
+    auto loadB = [&](f32x4n (&dst)[NVB], int kt) {
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) rb[i] = bload(rsB, offB[i] + (unsigned)(kt * BK * ldb) * 4u, false);
+        for (int i = 0; i < NVB; ++i) dst[i] = bload(rsB, offB[i] + (unsigned)(kt * BK * ldb) * 4u, false);
     };
     auto loadA = [&](f32x4n (&dst)[NVA], int kt) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) dst[i] = bload(rsA, offA[i] + (unsigned)(kt * BK) * 4u, LD_SC1);
     };
-    auto stash = [&](float* L, const f32x4n (&srcA)[NVA]) {
+    auto stash = [&](float* L, const f32x4n (&srcA)[NVA], const f32x4n (&srcB)[NVB]) {
 #pragma unroll
         for (int i = 0; i < NVA; ++i) {
             const int idx = threadIdx.x + i * PK_NT;
@@ -163,7 +167,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int idx = threadIdx.x + i * PK_NT;
-            *reinterpret_cast<f32x4n*>(L + A_FL + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = rb[i];
+            *reinterpret_cast<f32x4n*>(L + A_FL + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = srcB[i];
         }
     };
 
@@ -172,11 +176,12 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
         stamp = reinterpret_cast<unsigned long long*>(a.census + 1024) +
                 ((blockIdx.x ? 1 : 0) * 64 + (2 * t + (GATES ? 0 : 1))) * 4;
     if (stamp) stamp[0] = wall_clock64();
-    loadB(0);
+    loadB(rb[0], 0);
+    if (DB == 2) loadB(rb[DB - 1], 1);
     // ---- the barrier: everything below reads what the previous phase of this chain wrote
     pk_wait(ctr, target, a.err, a.spin_limit);
     if (stamp) stamp[1] = wall_clock64();
-    const int nt = K / BK;                 // a multiple of DA (H % 512 == 0 is required by the host)
+    const int nt = K / BK;                 // a multiple of UNR (H % 512 == 0 is required by the host)
 #pragma unroll
     for (int j = 0; j < DA; ++j) loadA(ra[j], j);
 
@@ -225,20 +230,20 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
 
     float* L0 = smem;
     float* L1 = smem + (A_FL + B_FL);
-    stash(L0, ra[0]);
+    stash(L0, ra[0], rb[0]);
     __syncthreads();
-    for (int k0 = 0; k0 < nt; k0 += DA) {
+    for (int k0 = 0; k0 < nt; k0 += UNR) {
 #pragma unroll
-        for (int j = 0; j < DA; ++j) {
+        for (int j = 0; j < UNR; ++j) {
             const int kt = k0 + j;
             float* cur = (j & 1) ? L1 : L0;
             float* nxt = (j & 1) ? L0 : L1;
-            if (kt + 1 < nt) loadB(kt + 1);
-            if (kt + DA < nt) loadA(ra[j], kt + DA);          // slot j: tile kt was stashed one iteration ago
+            if (kt + DB < nt) loadB(rb[j % DB], kt + DB);       // slot j % DB: tile kt was stashed one iteration ago
+            if (kt + DA < nt) loadA(ra[j % DA], kt + DA);
             __builtin_amdgcn_sched_barrier(0);
             compute(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nt) stash(nxt, ra[(j + 1) % DA]);
+            if (BM == 32) __builtin_amdgcn_sched_barrier(0);     // 16-wave form: the LDS writes may slide under the MFMA tail
+            if (kt + 1 < nt) stash(nxt, ra[(j + 1) % DA], rb[(j + 1) % DB]);
             __syncthreads();
         }
     }
