@@ -37,6 +37,13 @@ constexpr int PK_BM = 32;
 constexpr unsigned PK_OOB = 0xFFFFFFF0u;
 constexpr int SC1 = 16;                    // buffer aux bit: system-coherence level 1 (write-through / L1 bypass)
 constexpr int STG_LD = 36;
+// XCD-local form (64-row tiles, 16 waves), compile-time tuning: k tile of the gate phase, SIMD-partner stagger
+#ifndef PK_GATES_BK64
+#define PK_GATES_BK64 128
+#endif
+#ifndef PK_STAGGER
+#define PK_STAGGER 0
+#endif
 
 struct PkArgs {
     const float* xp;      // [T,B,3H]  x_t W_x + b for (r|u|c)
@@ -100,7 +107,7 @@ template <bool GATES, int BM>
 __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int row_hi, int m0, int n0, float* smem,
                                         unsigned* ctr, unsigned target) {
     constexpr int PK_BM = BM, PK_NT = BM * 16;
-    constexpr int BN = GATES ? 64 : 32, BK = (GATES && BM == 32) ? 64 : 128, WGK = GATES ? 4 : 8;   // 16 waves: half the barriers
+    constexpr int BN = GATES ? 64 : 32, BK = GATES ? (BM == 32 ? 64 : PK_GATES_BK64) : 128, WGK = GATES ? 4 : 8;
     constexpr int WAVES_N = BN / 32, WAVES_M = BM / 32;
     // Hand-offs are stored write-through (sc1) in both forms.  The two-chain form reads them back with sc1 loads (its
     // producers sit on other XCDs).  In the XCD-local form (BM 64) producer and consumer share an L2, every address is
@@ -146,7 +153,7 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
     // for the weights (in-order vmcnt) leaves the far loads in flight.
     // XCD-local form (BM 64): the left operand now comes from this XCD's L2 (one tile of cover is enough) while every
     // XCD streams ALL of the weights each step (12 MB, more than its L2): the weights get the second tile of cover.
-    constexpr int DA = BM == 64 ? 1 : (GATES ? 4 : 2);
+    constexpr int DA = BM == 64 ? (PK_STAGGER ? 2 : 1) : (GATES ? 4 : 2);
     constexpr int DB = BM == 64 ? 2 : 1;
     constexpr int UNR = DA > 2 ? DA : 2;
     f32x4n ra[DA][NVA], rb[DB][NVB];
@@ -241,9 +248,17 @@ __device__ __forceinline__ void pk_tile(const PkArgs& a, int t, int row_lo, int 
             if (kt + DB < nt) loadB(rb[j % DB], kt + DB);       // slot j % DB: tile kt was stashed one iteration ago
             if (kt + DA < nt) loadA(ra[j % DA], kt + DA);
             __builtin_amdgcn_sched_barrier(0);
-            compute(cur);
-            if (BM == 32) __builtin_amdgcn_sched_barrier(0);     // 16-wave form: the LDS writes may slide under the MFMA tail
-            if (kt + 1 < nt) stash(nxt, ra[(j + 1) % DA], rb[(j + 1) % DB]);
+            if (BM == 64 && PK_STAGGER && ((wave >> 2) & 1)) {
+                // SIMD partners (waves w and w + 4 share a SIMD): this half refills LDS first and computes second, so
+                // that on every SIMD one pair is in its MFMA burst while the other writes the next tile
+                if (kt + 1 < nt) stash(nxt, ra[(j + 1) % DA], rb[(j + 1) % DB]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(cur);
+            } else {
+                compute(cur);
+                if (BM == 32) __builtin_amdgcn_sched_barrier(0);     // 16-wave form: the LDS writes may slide under the MFMA tail
+                if (kt + 1 < nt) stash(nxt, ra[(j + 1) % DA], rb[(j + 1) % DB]);
+            }
             __syncthreads();
         }
     }
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(BM * 16, 4) void gru_fwd_persistent_kernel(PkArgs a
 
 constexpr size_t pk_lds_bytes(int bm = PK_BM) {
     // max over the two phases of 2 x (A tile + B tile) and of the epilogue patches (one 32 x 36 patch per wave)
-    const size_t bkg = bm == 64 ? 128 : 64;
+    const size_t bkg = bm == 64 ? PK_GATES_BK64 : 64;
     const size_t g = 2 * (bm * (bkg + 4) + bkg * 64), c = 2 * (bm * (128 + 4) + 128 * 32);
     const size_t m = g > c ? g : c, p = (size_t)(bm / 4) * 32 * STG_LD;
     return (m > p ? m : p) * sizeof(float);
