@@ -160,3 +160,31 @@ def test_a_failing_producer_raises_in_the_consumer():
     assert len(next(it)["image_id"]) == 3
     with pytest.raises(RuntimeError, match="producer thread failed"):
         next(it)
+
+
+def test_length_sort_covers_both_caption_categories_as_one_batch():
+    """pretrain.add_length_sort: ONE order over the 2*B*n blank-fill captions (object rows first, then attribute rows)
+    -- the engine encodes them as one GRU batch (vqa_pretrain_batch_t.perm / inv / live_rows): a permutation of all
+    rows, longest first and stable, its inverse, and live_rows[t] = number of captions longer than t."""
+    rng = np.random.default_rng(3)
+    B, n, L = 6, 5, 7
+    batch = {}
+    for k in PT.KINDS:
+        batch[k + "_blank_fill/blanks"] = rng.integers(0, 50, size=(B, n, L)).astype(np.int32)
+        batch[k + "_blank_fill/blanks_len"] = rng.integers(0, L + 3, size=(B, n)).astype(np.int32)   # some exceed L
+    out = PT.add_length_sort(dict(batch))
+    srt = out["blank_fill/sort"]
+    lens = np.concatenate([batch[k + "_blank_fill/blanks_len"].reshape(-1) for k in PT.KINDS])
+    perm, inv, live = np.asarray(srt["perm"]), np.asarray(srt["inv"]), np.asarray(srt["live_rows"])
+    assert sorted(perm.tolist()) == list(range(2 * B * n)) and np.array_equal(inv[perm], np.arange(2 * B * n))
+    sl = lens[perm]
+    assert np.all(sl[:-1] >= sl[1:])                                          # longest first
+    same = sl[:-1] == sl[1:]
+    assert np.all(perm[:-1][same] < perm[1:][same])                           # stable: ties keep caption order
+    assert live.shape == (L,) and live.dtype == np.int32
+    assert np.array_equal(live, [(np.minimum(lens, L) > t).sum() for t in range(L)])
+    assert np.all(live[:-1] >= live[1:])
+    # tensors already on a device are left alone (the host cannot sort them)
+    import torch
+    tb = {k: (torch.from_numpy(v) if k.endswith("blanks_len") else v) for k, v in batch.items()}
+    assert "blank_fill/sort" not in PT.add_length_sort(tb)
