@@ -209,3 +209,50 @@ def test_trainer_loop_with_tables_in_hbm_and_forked_producers_in_a_fresh_process
                         "64", "16"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "resident-workers" in r.stdout and "images/s" in r.stdout, r.stdout
+
+
+def test_trainer_step_with_prefetched_batch_and_deferred_report_equals_the_plain_sequence():
+    """Trainer.run_train_step draws and uploads batch i+1 on a side stream while step i runs and fetches the 13 report
+    scalars once per step (Model.prepare / build(prepared=, defer_report=True) / finish_report).  Same batches, same
+    dropout masks, same reports and parameters as set_batch -> build -> backward -> apply_gradients, one step at a time
+    (vlmap_memft/trainer.py:202-263)."""
+    import tempfile
+    from vqa_transfer_externaldata_amd import dataset_vlmap as DV, pretrain_trainer as PTT
+    R, D, L, Vq, n_ws, A, B = 36, 64, 6, 40, 12, 30, 8
+
+    def make():
+        data = DV.synthetic_dataset(40, Vq, n_ws, A, R=R, D=D, max_len=L, seed=5)
+        ds = {"train": DV.Dataset(split="train", data=data, seed=1), "val": DV.Dataset(split="val", data=data, seed=2)}
+        cfg = PTT.build_parser().parse_args(["--batch_size", str(B), "--max_train_iter", "4", "--learning_rate", "0.002",
+                                             "--features_on_device", "1", "--input_workers", "0", "--input_prefetch", "0"])
+        cfg.data_cfg = ds["train"].get_config()
+        cfg.vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
+        cfg.answer_dict, cfg.ws_dict = data["answer_dict"], data["ws_dict"]
+        cfg.synthetic, cfg.train_dir = 1, tempfile.mkdtemp()
+        return PTT.Trainer(cfg, ds)
+
+    ta, tb = make(), make()
+    reports_a, reports_b = [], []
+    for _ in range(4):
+        step, _, loss, report, _ = ta.run_train_step(False)
+        reports_a.append(report)
+        tb.model.set_batch(tb._next("train"))
+        tb.model.build()
+        tb.model.backward()
+        tb.model.apply_gradients(tb._lr())
+        torch.cuda.synchronize()
+        reports_b.append(dict(tb.model.report))
+    assert step == 4
+    for ra, rb in zip(reports_a, reports_b):
+        assert sorted(ra) == sorted(rb)
+        for k in ra:
+            assert abs(ra[k] - rb[k]) <= 1e-5 * max(1.0, abs(rb[k])), (k, ra[k], rb[k])
+    pa, pb = ta.model.engine.params, tb.model.engine.params
+    for k in pa:
+        if k.endswith("score/fc/biases"):
+            continue       # analytically zero gradient: Adam amplifies rounding noise
+        np.testing.assert_allclose(pa[k].cpu().numpy(), pb[k].cpu().numpy(), rtol=0, atol=5e-6, err_msg=k)
+    # a validation step in between leaves the prefetched training batch in place
+    ta.run_val_step(False)
+    assert ta._prepared is not None
+    ta.run_train_step(False)
