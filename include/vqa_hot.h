@@ -324,6 +324,7 @@ typedef struct {
 #define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
                                      * (vqa_gemm_f32_gather) and leaves V_ft behind as a by-product; default: a gather
                                      * pass in front of the GEMM (same step time, see csrc/fusion_model.hip) */
+#define VQA_FLAG_SHARED_LN 4        /* cfg-5 model only: one LayerNorm per shared fc_layer scope (see vqa_pt_fc_t) */
 
 /* One FC(+LN) layer: weights [in,out], biases [out], LayerNorm beta/gamma [out] (NULL if no LN). */
 typedef struct { float *w, *b, *beta, *gamma; } vqa_fc_t;
@@ -386,8 +387,14 @@ typedef struct {
     float keep_att, keep_joint;              /* 0.8 / 0.5 */
 } vqa_pretrain_dims_t;
 
-/* fc_layer scope shared by several call sites: one weight / bias, one LayerNorm (beta, gamma) PER CALL SITE in TF
- * graph order (layers.layer_norm is un-scoped: `LayerNorm`, `LayerNorm_1`, ...); unused slots NULL. */
+/* fc_layer scope entered by several call sites (vlmap/modules.py:630-650): one weight / bias and
+ *   - with VQA_FLAG_SHARED_LN in vqa_pretrain_dims_t.flags: ONE LayerNorm (slot 0) used by every call site, its gradient
+ *     the sum over the call sites.  This is what TF 1.x builds: leaving the string-named fc_layer scope zeroes the
+ *     sub-scope counts (close_variable_subscopes), so the un-scoped layers.layer_norm is named `LayerNorm` again at the
+ *     next call site and AUTO_REUSE shares it;
+ *   - without the flag: one LayerNorm PER CALL SITE in TF graph order (`LayerNorm`, `LayerNorm_1`, ...), the other
+ *     reading of the same code, kept selectable so that the variable names of a checkpoint decide.
+ * Unused slots NULL. */
 typedef struct { float *w, *b, *beta[4], *gamma[4]; } vqa_pt_fc_t;
 
 typedef struct {

@@ -14,9 +14,19 @@ Reference lines (relative to /root/reference):
   * n_way_classification_loss                  :675-706
   * modules: fc_layer vlmap/modules.py:630-650, hadamard_attention :67-97, attention_pooling :23-39,
     encode_L :124-140, learn_embedding_map :351-358, LearnGloVe :415-448
-TF quirk reproduced: layers.layer_norm is un-scoped, so every CALL SITE of a shared
-fc_layer scope owns its own LayerNorm variables (`LayerNorm`, `LayerNorm_1`, ...) in graph build order:
-object_V_ft, attribute_V_ft, object_blank_fill, attribute_blank_fill, object_wordset, attribute_wordset.
+LayerNorm variables of an fc_layer scope that several call sites enter (modules.py:630-650, `layers.layer_norm(out)`
+with no scope inside `with tf.variable_scope(scope, reuse=tf.AUTO_REUSE)`) -- the TF 1.x rule, the SAME one
+oracle/conv_oracle.py applies to I2V's BatchNorm (DESIGN.md section 2 spells it out):
+  * `variable_scope(None, default_name='LayerNorm')` uniquifies against VariableStore.variable_scopes_count of
+    '<parent>/LayerNorm' (`_get_unique_variable_scope`);
+  * leaving a STRING-named scope runs `close_variable_subscopes(name)`, which zeroes the counts of everything below it
+    (`_pure_variable_scope.__exit__`), so the next call site that re-enters 'pooled_linear_l' finds the count of
+    'pooled_linear_l/LayerNorm' at 0, gets the un-suffixed name again, and AUTO_REUSE hands it the existing beta / gamma.
+  => ONE LayerNorm per shared FC, trained by every call site (`ln_shared=True`, the default here).
+The per-call-site reading of SURVEY 5.1 (`LayerNorm`, `LayerNorm_1`, ... in graph build order: object_V_ft,
+attribute_V_ft, object_blank_fill, attribute_blank_fill, object_wordset, attribute_wordset) is kept as the second mode:
+the set of variable names in `p` decides (`.../LayerNorm_1/...` present = per call site), exactly as a reference
+checkpoint would.
 """
 from __future__ import annotations
 
@@ -32,14 +42,19 @@ def ln_name(scope, idx):
     return scope + ("/LayerNorm" if idx == 0 else "/LayerNorm_%d" % idx)
 
 
-def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024):
+def ln_shared_in(names):
+    """True when the variable names are those of the shared-LayerNorm graph (no `<scope>/LayerNorm_<k>/`)."""
+    return not any("/LayerNorm_" in k for k in names)
+
+
+def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024, ln_shared=True):
     s = {"wordset_map/learn": (n_ws, W), "V_GloVe/embed_map": (Vq, W), "L_GloVe/embed_map": (Vq, W),
          "LearnAnswerGloVe/embed_map": (A, W)}
 
     def fc(scope, fin, fout, n_ln):
         s[scope + "/fc/weights"] = (fin, fout)
         s[scope + "/fc/biases"] = (fout,)
-        for i in range(n_ln):
+        for i in range(min(n_ln, 1) if ln_shared else n_ln):
             s[ln_name(scope, i) + "/beta"] = (fout,)
             s[ln_name(scope, i) + "/gamma"] = (fout,)
 
@@ -62,9 +77,9 @@ def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024):
 NO_GRAD_VARS = ("V_GloVe/embed_map", "LearnAnswerGloVe/embed_map")
 
 
-def init_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024, dtype=np.float32, perturb=True):
+def init_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024, dtype=np.float32, perturb=True, ln_shared=True):
     p = {}
-    for n, shp in variable_shapes(Vq, n_ws, A, W, D, H).items():
+    for n, shp in variable_shapes(Vq, n_ws, A, W, D, H, ln_shared).items():
         if n.endswith("/weights") or n.endswith("/kernel"):
             lim = np.sqrt(6.0 / (shp[0] + shp[1]))
             p[n] = rng.uniform(-lim, lim, size=shp)
@@ -114,6 +129,8 @@ def make_masks(rng, B, n, R, H, dtype=np.float32):
 def _fc_ln(x, p, scope, ln_idx, act):
     """modules.fc_layer: FC on the last axis, layer_norm over ALL non-batch axes, activation."""
     pre = x @ p[scope + "/fc/weights"] + p[scope + "/fc/biases"]
+    if ln_shared_in(p):
+        ln_idx = 0
     ln, _, _ = O.layer_norm_forward(pre, p[ln_name(scope, ln_idx) + "/gamma"], p[ln_name(scope, ln_idx) + "/beta"])
     return np.maximum(ln, 0) if act == "relu" else np.tanh(ln)
 
@@ -188,9 +205,19 @@ def forward(p, batch, masks, n):
 
 
 # ----------------------------------------------------------------------------- torch restatement
-def torch_loss_and_grads(p, batch, masks, n, dtype=None):
+RELU_SITES = tuple("%s/%s" % (k, s) for k in KINDS for s in ("v", "qv", "bf/vl", "bf/ll", "bf/j", "ws/vl", "ws/ll", "ws/j"))
+
+
+def torch_loss_and_grads(p, batch, masks, n, dtype=None, gates=None, capture=None):
     """Independent torch composition (F.linear / manual LN / torch GRU loop / F.cross_entropy) + autograd.
-    Returns (total_loss, report-losses, grads dict, embedding slice grads dict)."""
+    Returns (total_loss, report-losses, grads dict, embedding slice grads dict).
+
+    gates: optional {site: bool array} for the ReLU sites in RELU_SITES ("<kind>/v", "<kind>/qv",
+    "<kind>/<bf|ws>/{vl,ll,j}").  relu(x) is then evaluated as x * gate with the GIVEN sign pattern -- the
+    gate-conditioned gradient: with the gates of a float32 forward pass fixed, the loss is a smooth function of the
+    parameters and a float32 backward must agree with this float64 one to rounding, whereas the unconditioned
+    comparison also sees every gate on which float32 and float64 disagree (pre-activations within ~1e-6 of 0).
+    capture: optional dict that receives this run's own sign pattern per site."""
     import torch
     import torch.nn.functional as F
     dtype = dtype or torch.float64
@@ -199,12 +226,19 @@ def torch_loss_and_grads(p, batch, masks, n, dtype=None):
     B, R, D = batch["image_ft"].shape
     img, spat = t(batch["image_ft"]), t(batch["spatial_ft"])
 
-    def fc_ln(x, scope, i, act):
+    shared = ln_shared_in(p)
+
+    def fc_ln(x, scope, i, act, site=None):
+        i = 0 if shared else i
         pre = F.linear(x, P[scope + "/fc/weights"].t(), P[scope + "/fc/biases"])
         dims = tuple(range(1, pre.dim()))
         mu = pre.mean(dims, keepdim=True)
         var = pre.var(dims, unbiased=False, keepdim=True)
         ln = (pre - mu) * torch.rsqrt(var + O.LN_EPS) * P[ln_name(scope, i) + "/gamma"] + P[ln_name(scope, i) + "/beta"]
+        if act == "relu" and capture is not None:
+            capture[site] = (ln.detach() > 0).numpy()
+        if act == "relu" and gates is not None:
+            return ln * torch.as_tensor(np.asarray(gates[site]).reshape(tuple(ln.shape))).to(dtype)
         return torch.relu(ln) if act == "relu" else torch.tanh(ln)
 
     def gru(x, lens):
@@ -224,8 +258,8 @@ def torch_loss_and_grads(p, batch, masks, n, dtype=None):
     for ki, k in enumerate(KINDS):
         key = t(batch[k + "_blank_fill/normal_boxes"])
         key6 = torch.cat([key, key[..., 2:3] - key[..., 0:1], key[..., 3:4] - key[..., 1:2]], -1)
-        v = fc_ln(spat, "spat_v_linear_v", ki, "relu")
-        qv = fc_ln(key6, "spat_q_linear_v", ki, "relu").reshape(B * n, -1)
+        v = fc_ln(spat, "spat_v_linear_v", ki, "relu", k + "/v")
+        qv = fc_ln(key6, "spat_q_linear_v", ki, "relu", k + "/qv").reshape(B * n, -1)
         vt = v.repeat_interleave(n, 0)
         feat = vt * qv[:, None, :] * t(masks[k + "/att"]) / O.KEEP_ATT
         s = F.linear(feat, P["spat_att/compute/score/fc/weights"].t(), P["spat_att/compute/score/fc/biases"])[..., 0]
@@ -237,9 +271,10 @@ def torch_loss_and_grads(p, batch, masks, n, dtype=None):
         fills = torch.tensor(batch[k + "_blank_fill/fills"].astype(np.int64))
 
         def head(l_ft, i, jm):
-            vl = fc_ln(pooled, "pooled_linear_l", i, "relu")
-            ll = fc_ln(l_ft, "q_linear_l", i, "relu")
-            j = fc_ln(vl * ll, "joint_fc", i, "relu") * t(jm) / O.KEEP_JOINT
+            site = "%s/%s/" % (k, "bf" if i < 2 else "ws")
+            vl = fc_ln(pooled, "pooled_linear_l", i, "relu", site + "vl")
+            ll = fc_ln(l_ft, "q_linear_l", i, "relu", site + "ll")
+            j = fc_ln(vl * ll, "joint_fc", i, "relu", site + "j") * t(jm) / O.KEEP_JOINT
             z = F.linear(j, P["classifier/fc/weights"].t(), P["classifier/fc/biases"])
             ce = F.cross_entropy(z.reshape(B * n, -1), fills.reshape(-1), reduction="none").reshape(B, n)
             return (ce * valid).sum() / valid.sum()

@@ -49,12 +49,14 @@ def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
     return z
 
 
-def pretrain_case(seed=7, B=3, n=5, R=6, D=16, H=8, L=4, W=12, Vq=20, n_ws=7, A=12):
+def pretrain_case(seed=7, B=3, n=5, R=6, D=16, H=8, L=4, W=12, Vq=20, n_ws=7, A=12, ln_shared=True):
     """cfg-5 pre-training model (vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py) at toy size: inputs, masks, the
-    13 report scalars, attention maps, logits and every gradient (float64 torch-autograd restatement)."""
+    13 report scalars, attention maps, logits and every gradient (float64 torch-autograd restatement).  ln_shared: one
+    LayerNorm per shared fc_layer scope (TF 1.x, the default) or one per call site; the parameter NAMES in the fixture
+    say which (oracle/pretrain_oracle.py)."""
     from oracle import pretrain_oracle as PO
     rng = np.random.default_rng(seed)
-    p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H)
+    p = PO.init_params(rng, Vq, n_ws, A, W=W, D=D, H=H, ln_shared=ln_shared)
     batch = PO.make_batch(rng, B, n, R, D, L, Vq, n_ws, A)
     masks = PO.make_masks(rng, B, n, R, H)
     to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
@@ -93,6 +95,7 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "fusion_standard_b8.npz"), **fusion_case("standard", 102))
     np.savez_compressed(os.path.join(HERE, "fusion_standard_word2vec_b4.npz"), **fusion_case("standard_word2vec", 103, B=4))
     np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy.npz"), **pretrain_case())
+    np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy_persite.npz"), **pretrain_case(ln_shared=False))
     np.savez_compressed(os.path.join(HERE, "vfeat_resnet_narrow.npz"), **conv_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -26,6 +26,7 @@ class Dims(C.Structure):
 
 FLAG_DETERMINISTIC = 1
 FLAG_FUSED_GATHER = 2
+FLAG_SHARED_LN = 4
 
 
 class Fc(C.Structure):

@@ -10,8 +10,11 @@
 //                                          prefix) -> fusion MLP -> classifier -> masked softmax-CE, top-1 / top-5
 //   build_*_wordset   :366-412, :457-503   tanh(word-set embedding) -> FC + LN + tanh -> the same fusion MLP
 //   n_way_classification_loss :675-706
-// LayerNorm instance indices follow the TF graph build order (oracle/pretrain_oracle.py): scope[ki] for the V_ft /
-// blank-fill / wordset_ft call sites, scope[2 + ki] for the word-set call sites of the shared fusion MLP.
+// LayerNorm variables of an fc_layer scope entered by several call sites: with VQA_FLAG_SHARED_LN (what TF 1.x builds:
+// leaving the string-named scope zeroes its sub-scope counts, so the un-scoped layers.layer_norm gets the un-suffixed
+// name again and AUTO_REUSE shares it -- oracle/pretrain_oracle.py) every call site uses slot 0 and the
+// call sites' d_gamma / d_beta are accumulated; without the flag each call site owns slot [ki] (V_ft / blank-fill /
+// wordset_ft) or [2 t + ki] (the four heads of the shared fusion MLP) in TF graph build order.
 //
 // The workspace layout is a function of the dims alone, so the host views named intermediates without copies.
 #include <string.h>
@@ -362,6 +365,8 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     const Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
     const int64_t B = dims->B, n = dims->n, R = dims->R, D = dims->D, H = dims->H, W = dims->W, A = dims->A, T = dims->L;
     const int64_t Bn = B * n;
+    const bool ln_shared = (dims->flags & VQA_FLAG_SHARED_LN) != 0;
+    auto li = [ln_shared](int site) { return ln_shared ? 0 : site; };
     VQA_REQUIRE(bt->image_ft && bt->spatial_ft && bt->num_boxes, VQA_ERR_ARG);
     VQA_REQUIRE((bt->perm == nullptr) == (bt->inv == nullptr) && (bt->perm == nullptr) == (bt->live_rows == nullptr), VQA_ERR_ARG);
     ReportArgs ra{};
@@ -376,9 +381,9 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         hipLaunchKernelGGL(box6_kernel, dim3((unsigned)((Bn + 255) / 256)), dim3(256), 0, c.st, kb.normal_boxes,
                            c.f(p + "key6"), (int)Bn);
         VQA_CHECK_LAUNCH();
-        TRY(fc_ln_fwd(c, bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, k, (int)R, 0, p + "v_pre", p + "v", p + "v_mean",
+        TRY(fc_ln_fwd(c, bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, li(k), (int)R, 0, p + "v_pre", p + "v", p + "v_mean",
                       p + "v_rstd", nullptr, 1.f));
-        TRY(fc_ln_fwd(c, c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, k, (int)n, 0, p + "qv_pre", p + "qv", p + "qv_mean",
+        TRY(fc_ln_fwd(c, c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, li(k), (int)n, 0, p + "qv_pre", p + "qv", p + "qv_mean",
                       p + "qv_rstd", nullptr, 1.f));
         TRY(vqa_attn_pool_fwd_rep(c.f(p + "v"), c.f(p + "qv"), bt->image_ft, bt->num_boxes, P->spat_att_score.w,
                                   P->spat_att_score.b, kb.keep_att, dims->keep_att, c.f(p + "att"), c.f(p + "pooled"),
@@ -390,7 +395,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         // ---- build_*_wordset
         TRY(vqa_embed_fwd(P->wordset_map, kb.wordsets, c.f(p + "wse"), (int)Bn, 1, (int)W, dims->n_ws, c.st));
         TRY(vqa_tanh_fwd(c.f(p + "wse"), c.f(p + "ws"), Bn * W, c.st));
-        TRY(fc_ln_fwd(c, c.f(p + "ws"), Bn, W, H, P->wordset_ft, k, (int)n, 1, p + "wf_pre", p + "wf", p + "wf_mean",
+        TRY(fc_ln_fwd(c, c.f(p + "ws"), Bn, W, H, P->wordset_ft, li(k), (int)n, 1, p + "wf_pre", p + "wf", p + "wf_mean",
                       p + "wf_rstd", nullptr, 1.f));
     }
     // ---- build_*_blank_fill of BOTH categories as one batch (shared L_GloVe / GRU weights): captions in length order
@@ -429,10 +434,10 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         TRY(c.gemm(0, 0, 4 * Bn, H, H, c.f("S/lft"), (int)H, P->q_linear_l.w, (int)H, c.f("S/ll_pre"), (int)H, P->q_linear_l.b));
         for (int ln = 0; ln < 4; ++ln) {
             const std::string q = hname(ln);
-            TRY(vqa_ln_act_fwd(c.f("S/vl_pre") + (ln & 1) * SH, P->pooled_linear_l.gamma[ln], P->pooled_linear_l.beta[ln],
+            TRY(vqa_ln_act_fwd(c.f("S/vl_pre") + (ln & 1) * SH, P->pooled_linear_l.gamma[li(ln)], P->pooled_linear_l.beta[li(ln)],
                                nullptr, 1.f, c.f("S/vl") + ln * SH, c.f(q + "vl_mean"), c.f(q + "vl_rstd"), (int)B, (int)n,
                                (int)H, 0, c.st));
-            TRY(vqa_ln_act_fwd(c.f("S/ll_pre") + ln * SH, P->q_linear_l.gamma[ln], P->q_linear_l.beta[ln], nullptr, 1.f,
+            TRY(vqa_ln_act_fwd(c.f("S/ll_pre") + ln * SH, P->q_linear_l.gamma[li(ln)], P->q_linear_l.beta[li(ln)], nullptr, 1.f,
                                c.f("S/ll") + ln * SH, c.f(q + "ll_mean"), c.f(q + "ll_rstd"), (int)B, (int)n, (int)H, 0, c.st));
         }
         TRY(vqa_mul(c.f("S/vl"), c.f("S/ll"), c.f("S/jin"), 4 * SH, c.st));
@@ -442,7 +447,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
             const std::string q = hname(ln);
             const vqa_pretrain_kind_t& kb = bt->kind[ln & 1];
             const uint8_t* jmask = (ln >> 1) == 0 ? kb.keep_bf_joint : kb.keep_ws_joint;
-            TRY(vqa_ln_act_fwd(c.f("S/j_pre") + ln * SJ, P->joint_fc.gamma[ln], P->joint_fc.beta[ln], jmask, dims->keep_joint,
+            TRY(vqa_ln_act_fwd(c.f("S/j_pre") + ln * SJ, P->joint_fc.gamma[li(ln)], P->joint_fc.beta[li(ln)], jmask, dims->keep_joint,
                                c.f("S/j") + ln * SJ, c.f(q + "j_mean"), c.f(q + "j_rstd"), (int)B, (int)n, (int)(2 * H), 0,
                                c.st));
         }
@@ -472,6 +477,8 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
     const Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
     const int64_t B = dims->B, n = dims->n, R = dims->R, D = dims->D, H = dims->H, W = dims->W, A = dims->A, T = dims->L;
     const int64_t Bn = B * n;
+    const bool ln_shared = (dims->flags & VQA_FLAG_SHARED_LN) != 0;
+    auto li = [ln_shared](int site) { return ln_shared ? 0 : site; };
     Acc acc{c, {}};
     // the two embedding tables are scatter-added: cleared here; every other gradient is overwritten on first touch
     if (hipMemsetAsync(G->l_glove, 0, (size_t)dims->Vq * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
@@ -493,7 +500,7 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
             const std::string q = hname(ln);
             const vqa_pretrain_kind_t& kb = bt->kind[ln & 1];
             const uint8_t* jmask = (ln >> 1) == 0 ? kb.keep_bf_joint : kb.keep_ws_joint;
-            TRY(ln_bwd_p(c, acc, c.f("d_j") + ln * SJ, Bn, 2 * H, P->joint_fc, G->joint_fc, ln, (int)n, 0,
+            TRY(ln_bwd_p(c, acc, c.f("d_j") + ln * SJ, Bn, 2 * H, P->joint_fc, G->joint_fc, li(ln), (int)n, 0,
                          c.f("S/j_pre") + ln * SJ, c.f(q + "j_mean"), c.f(q + "j_rstd"), jmask, dims->keep_joint,
                          c.f("d_jpre") + ln * SJ));
         }
@@ -501,10 +508,10 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(vqa_mul_bwd(c.f("d_jin"), c.f("S/vl"), c.f("S/ll"), c.f("d_vl"), c.f("d_ll"), 4 * SH, c.st));
         for (int ln = 0; ln < 4; ++ln) {
             const std::string q = hname(ln);
-            TRY(ln_bwd_p(c, acc, c.f("d_vl") + ln * SH, Bn, H, P->pooled_linear_l, G->pooled_linear_l, ln, (int)n, 0,
+            TRY(ln_bwd_p(c, acc, c.f("d_vl") + ln * SH, Bn, H, P->pooled_linear_l, G->pooled_linear_l, li(ln), (int)n, 0,
                          c.f("S/vl_pre") + (ln & 1) * SH, c.f(q + "vl_mean"), c.f(q + "vl_rstd"), nullptr, 1.f,
                          c.f("d_vlpre") + ln * SH));
-            TRY(ln_bwd_p(c, acc, c.f("d_ll") + ln * SH, Bn, H, P->q_linear_l, G->q_linear_l, ln, (int)n, 0,
+            TRY(ln_bwd_p(c, acc, c.f("d_ll") + ln * SH, Bn, H, P->q_linear_l, G->q_linear_l, li(ln), (int)n, 0,
                          c.f("S/ll_pre") + ln * SH, c.f(q + "ll_mean"), c.f(q + "ll_rstd"), nullptr, 1.f,
                          c.f("d_llpre") + ln * SH));
         }
@@ -549,7 +556,7 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         const std::string p = std::string(KIND[k]) + "/";
         const float* d_pooled = c.f("d_pooled") + k * Bn * D;
         // ---- word set -> wordset_ft -> tanh -> wordset_map
-        TRY(fc_ln_bwd(c, acc, c.f("d_lft") + (2 + k) * Bn * H, c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, k, (int)n, 1, p + "wf_pre",
+        TRY(fc_ln_bwd(c, acc, c.f("d_lft") + (2 + k) * Bn * H, c.f(p + "ws"), Bn, W, H, P->wordset_ft, G->wordset_ft, li(k), (int)n, 1, p + "wf_pre",
                       p + "wf_mean", p + "wf_rstd", nullptr, 1.f, "d_wfpre", c.f("d_ws")));
         TRY(vqa_tanh_bwd(c.f("d_ws"), c.f(p + "ws"), c.f("d_wse"), Bn * W, c.st));
         TRY(vqa_embed_bwd_len_det(c.f("d_wse"), kb.wordsets, nullptr, G->wordset_map, (int)Bn, 1, (int)W, dims->n_ws,
@@ -561,9 +568,9 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
                                   c.f("part_dw"), c.f("part_db"), (int)B, (int)n, (int)R, (int)H, (int)D, c.st));
         TRY(acc.colsum(c.f("part_dw"), Bn, H, (int)H, G->spat_att_score.w));
         TRY(acc.colsum(c.f("part_db"), Bn, 1, 1, G->spat_att_score.b));
-        TRY(fc_ln_bwd(c, acc, c.f("d_v"), bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, G->spat_v_linear_v, k, (int)R, 0,
+        TRY(fc_ln_bwd(c, acc, c.f("d_v"), bt->spatial_ft, B * R, 6, H, P->spat_v_linear_v, G->spat_v_linear_v, li(k), (int)R, 0,
                       p + "v_pre", p + "v_mean", p + "v_rstd", nullptr, 1.f, "d_vpre", nullptr));
-        TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, k, (int)n, 0,
+        TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, li(k), (int)n, 0,
                       p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
     }
     if (slice_sq != nullptr && sq_prev != nullptr)

@@ -125,8 +125,10 @@ class Model(object):
             torch.cuda.current_stream(self.device).wait_event(ev)
         if self._engine is None:
             cfg = self.data_cfg
+            # one LayerNorm per shared fc_layer scope (TF 1.x: pretrain.py) unless the config asks for the
+            # per-call-site variable set; a checkpoint's variable names override either (PretrainEngine.load_state_dict)
             shapes = PT.variable_shapes(len(self.vocab["vocab"]), self.num_ws, self.num_answer, W_DIM, cfg.vfeat_dim,
-                                        V_DIM)
+                                        V_DIM, bool(getattr(self.config, "ln_shared", 1)))
             self._engine = PT.PretrainEngine(n=cfg.n_obj_bf, R=cfg.max_box_num, D=cfg.vfeat_dim, H=V_DIM, W=W_DIM,
                                              A=self.num_answer, Vq=len(self.vocab["vocab"]), n_ws=self.num_ws,
                                              params=self._initial_params(shapes), device=self.device)

@@ -3,9 +3,12 @@ vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:54-94, 323-609, 675-706.
 
 Spatial attention over the 36 regions for n = 5 annotated boxes per image, blank-fill (GRU over the
 caption with a blank) and word-set conditioned heads for objects and attributes, all four heads
-sharing pooled_linear_l / q_linear_l / joint_fc / classifier with ONE LayerNorm variable set per call
-site (TF's un-scoped layer_norm: LayerNorm, LayerNorm_1, ... in graph build order), softmax-CE over
-the obj3000+attr1000 answers with top-1 / top-5 accuracy.  Forward and the hand-derived backward are
+sharing pooled_linear_l / q_linear_l / joint_fc / classifier, softmax-CE over the obj3000+attr1000 answers with
+top-1 / top-5 accuracy.  LayerNorm variables of those shared fc_layer scopes: ONE per scope, trained by every call
+site (`ln_shared=True`, the default: TF 1.x zeroes a string-named scope's sub-scope counts when it exits, so the
+un-scoped layer_norm is `LayerNorm` again at the next call site and AUTO_REUSE shares it -- DESIGN.md section 2), or one per
+call site (`LayerNorm`, `LayerNorm_1`, ... in graph build order) when a checkpoint carries those names:
+`ln_shared_in(names)` decides and `load_state_dict` switches the engine over.  Forward and the hand-derived backward are
 ONE C call each (vqa_pretrain_forward / vqa_pretrain_backward, csrc/pretrain_model.hip: every kernel of the
 pass is enqueued from C++, the workspace is carved from the dims, no torch op runs inside the step); the
 effective batch is B*n rows and the x n tile of V_ft / spatial_ft that the reference materialises (:324-333)
@@ -34,14 +37,19 @@ def ln_name(scope, idx):
     return scope + ("/LayerNorm" if idx == 0 else "/LayerNorm_%d" % idx)
 
 
-def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024):
+def ln_shared_in(names):
+    """True when the variable names are those of the shared-LayerNorm graph (no `<scope>/LayerNorm_<k>/...`)."""
+    return not any("/LayerNorm_" in k for k in names)
+
+
+def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024, ln_shared=True):
     s = {"wordset_map/learn": (n_ws, W), "V_GloVe/embed_map": (Vq, W), "L_GloVe/embed_map": (Vq, W),
          "LearnAnswerGloVe/embed_map": (A, W)}
 
     def fc(scope, fin, fout, n_ln):
         s[scope + "/fc/weights"] = (fin, fout)
         s[scope + "/fc/biases"] = (fout,)
-        for i in range(n_ln):
+        for i in range(min(n_ln, 1) if ln_shared else n_ln):
             s[ln_name(scope, i) + "/beta"] = (fout,)
             s[ln_name(scope, i) + "/gamma"] = (fout,)
 
@@ -60,11 +68,11 @@ def variable_shapes(Vq, n_ws, A, W=300, D=2048, H=1024):
     return s
 
 
-def init_random_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024):
+def init_random_params(rng, Vq, n_ws, A, W=300, D=2048, H=1024, ln_shared=True):
     """Random-init weights of the architecture (Xavier-uniform FCs, GRU gate bias 1, LN gamma 1,
     embeddings U(-0.01, 0.01); GloVe vectors are download-only)."""
     p = {}
-    for n, shp in variable_shapes(Vq, n_ws, A, W, D, H).items():
+    for n, shp in variable_shapes(Vq, n_ws, A, W, D, H, ln_shared).items():
         if n.endswith("/weights") or n.endswith("/kernel"):
             lim = np.sqrt(6.0 / (shp[0] + shp[1]))
             p[n] = rng.uniform(-lim, lim, size=shp).astype(np.float32)
@@ -101,13 +109,26 @@ def _pad4(n):
 
 
 class PretrainEngine:
-    def __init__(self, *, n, R, D, H, W, A, Vq, n_ws, params, device="cuda:0", deterministic=False):
+    def __init__(self, *, n, R, D, H, W, A, Vq, n_ws, params, device="cuda:0", deterministic=False, ln_shared=None):
+        """ln_shared: one LayerNorm per shared fc_layer scope (True) or one per call site (False); None = whatever the
+        variable names in `params` say (`.../LayerNorm_1/...` present -> per call site), as for a checkpoint."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("PretrainEngine needs a GPU (no CPU fallback)")
         self.device = torch.device(device)
         self.n, self.R, self.D, self.H, self.W, self.A = n, R, D, H, W, A
-        self.shapes = variable_shapes(Vq, n_ws, A, W, D, H)
+        self.Vq, self.n_ws, self.deterministic = Vq, n_ws, bool(deterministic)
+        self.step_count = 0
+        self.report = {}
+        self.workspace, self.dims = None, None
+        self._layout(ln_shared_in(params) if ln_shared is None else bool(ln_shared))
+        for k in self.shapes:
+            self.params[k].copy_(torch.as_tensor(np.asarray(params[k])).to(torch.float32))
+
+    def _layout(self, ln_shared):
+        """Flat parameter / gradient / Adam buffers and the C structs for one of the two LayerNorm variable sets."""
+        self.ln_shared = bool(ln_shared)
+        self.shapes = variable_shapes(self.Vq, self.n_ws, self.A, self.W, self.D, self.H, self.ln_shared)
         dense = sorted(k for k in self.shapes if k not in NO_GRAD_VARS and k not in SPARSE_VARS)
         self.train_names = list(SPARSE_VARS) + dense
         off, self._tab = 0, {}
@@ -129,14 +150,11 @@ class PretrainEngine:
             self.grads[k] = self.grad_flat[o:o + cnt].view(self.shapes[k])
         for k in NO_GRAD_VARS:
             self.params[k] = torch.zeros(self.shapes[k], **f32)
-        for k in self.shapes:
-            self.params[k].copy_(torch.as_tensor(np.asarray(params[k])).to(torch.float32))
-        self.step_count = 0
-        self.report = {}
-        self.Vq, self.n_ws, self.deterministic = Vq, n_ws, bool(deterministic)
-        self.workspace, self.dims = None, None
         self._p_struct = self._param_struct(self.params)
         self._g_struct = self._param_struct(self.grads)
+
+    def _flags(self):
+        return (_lib.FLAG_DETERMINISTIC if self.deterministic else 0) | (_lib.FLAG_SHARED_LN if self.ln_shared else 0)
 
     # ------------------------------------------------------------------ C-ABI plumbing
     def make_keep_masks(self, B, seed, step):
@@ -153,7 +171,7 @@ class PretrainEngine:
     def _param_struct(self, table):
         def fc(scope, n_ln):
             f = _lib.PtFc(w=table[scope + "/fc/weights"].data_ptr(), b=table[scope + "/fc/biases"].data_ptr())
-            for i in range(n_ln):
+            for i in range(min(n_ln, 1) if self.ln_shared else n_ln):
                 f.beta[i] = table[ln_name(scope, i) + "/beta"].data_ptr()
                 f.gamma[i] = table[ln_name(scope, i) + "/gamma"].data_ptr()
             return f
@@ -257,7 +275,7 @@ class PretrainEngine:
         add_length_sort); masks: uint8 keep-masks keyed '<kind>/att|bf_joint|ws_joint' or None (no dropout)."""
         bs, B, L, keep = self._batch_struct(batch, masks)
         d = _lib.PtDims(B=B, n=self.n, R=self.R, D=self.D, H=self.H, W=self.W, A=self.A, Vq=self.Vq, n_ws=self.n_ws, L=L,
-                        flags=_lib.FLAG_DETERMINISTIC if self.deterministic else 0, keep_att=KEEP_ATT,
+                        flags=self._flags(), keep_att=KEEP_ATT,
                         keep_joint=KEEP_JOINT)
         need = int(self.lib.vqa_pretrain_workspace_bytes(C.byref(d)))
         if need <= 0:
@@ -319,9 +337,20 @@ class PretrainEngine:
         out["global_step"] = torch.tensor(self.step_count, dtype=torch.int64)
         return out
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, strict=True):
         """Restores parameters, Adam moments and the step count (beta powers), so a resumed run continues the
-        optimiser trajectory of an uninterrupted one."""
+        optimiser trajectory of an uninterrupted one.  The LayerNorm variable set follows the NAMES in the checkpoint:
+        `<scope>/LayerNorm_1/...` present -> one LayerNorm per call site, absent -> one per shared scope; an engine
+        built for the other set is laid out again before loading.  strict: a model variable missing from the
+        checkpoint raises (a silently skipped name would resume from the initial weights)."""
+        model_keys = [k for k in sd if k != "global_step" and not k.endswith(("/Adam", "/Adam_1"))]
+        shared = ln_shared_in(model_keys)
+        if shared != self.ln_shared:
+            self._layout(shared)
+            self.workspace, self.dims = None, None
+        missing = [k for k in self.shapes if k not in sd]
+        if missing and strict:
+            raise KeyError("checkpoint lacks %d model variables, e.g. %s" % (len(missing), ", ".join(sorted(missing)[:4])))
         for k in self.shapes:
             if k in sd:
                 self.params[k].copy_(torch.as_tensor(sd[k]).to(torch.float32))
@@ -331,6 +360,7 @@ class PretrainEngine:
                 self.v_flat[o:o + cnt].copy_(torch.as_tensor(sd[k + "/Adam_1"]).reshape(-1))
         if "global_step" in sd:
             self.step_count = int(sd["global_step"])
+        return missing
 
 
 def export_word_weights(state_dict, vocab, answer_dict, save_dir):

@@ -196,6 +196,9 @@ def build_parser():
     # not in the reference: how the input side keeps up with a 18 ms step
     parser.add_argument("--features_on_device", type=int, default=1,
                         help="keep both splits' feature tables in HBM, batches carry image indices")
+    parser.add_argument("--ln_shared", type=int, default=1,
+                        help="1: one LayerNorm per shared fc_layer scope (what TF 1.x builds); 0: one per call site; "
+                             "a --checkpoint's variable names override this")
     parser.add_argument("--input_workers", type=int, default=4, help="forked batch producers (0: in-process)")
     parser.add_argument("--input_prefetch", type=int, default=2, help="batches assembled ahead of the step")
     return parser
