@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VQA_HOT_ABI_VERSION 3
+#define VQA_HOT_ABI_VERSION 4
 
 enum {
     VQA_OK = 0,
@@ -385,6 +385,9 @@ typedef struct {
     int32_t L;                               /* padded caption length of THIS batch (blanks [B,n,L]) */
     int32_t flags;                           /* VQA_FLAG_* */
     float keep_att, keep_joint;              /* 0.8 / 0.5 */
+    float global_valid[2];                   /* data parallel: number of valid entries of the GLOBAL batch per category
+                                              * (object, attribute) = the denominator of the masked mean losses
+                                              * (:675-706); 0 = this batch's own count (one process) */
 } vqa_pretrain_dims_t;
 
 /* fc_layer scope entered by several call sites (vlmap/modules.py:630-650): one weight / bias and
@@ -443,6 +446,17 @@ int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_par
 int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* params,
                           const vqa_pretrain_params_t* grads, const vqa_pretrain_batch_t* batch, void* workspace,
                           int64_t workspace_bytes, float* slice_sq, void* stream);
+/* The same backward in dependency-ordered phases (bit mask; a step runs them in ascending order, each reads what the
+ * lower ones left in the workspace) so that a data-parallel caller starts reducing a finished bucket while the next
+ * phase runs -- the wrap of vlmap_memft/trainer.py:129-137, 202-263 (optimize_loss over ALL variables):
+ *   1  stacked heads: classifier, joint_fc, pooled_linear_l, q_linear_l (weights, biases, LayerNorms)
+ *   2  BPTT of the joint caption batch + GRU kernel / bias gradients
+ *   4  dx of the packed x-projection -> L_GloVe scatter-add (starts the slice sum of squares)
+ *   8  per category: wordset_ft, wordset_map, spat_att, spat_v_linear_v, spat_q_linear_v (writes slice_sq)
+ * vqa_pretrain_backward == phases 15. */
+int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* params,
+                                 const vqa_pretrain_params_t* grads, const vqa_pretrain_batch_t* batch, void* workspace,
+                                 int64_t workspace_bytes, float* slice_sq, int phases, void* stream);
 
 /* ------------------------------------------------------------------------
  * Region-feature extractor, NHWC fp32.

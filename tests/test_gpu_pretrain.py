@@ -309,7 +309,10 @@ def test_trainer_step_with_prefetched_batch_and_deferred_report_equals_the_plain
     for k in pa:
         if k.endswith("score/fc/biases"):
             continue       # analytically zero gradient: Adam amplifies rounding noise
-        np.testing.assert_allclose(pa[k].cpu().numpy(), pb[k].cpu().numpy(), rtol=0, atol=5e-6, err_msg=k)
+        # the two runs differ by the order of the atomic adds only; Adam turns that noise into a visible step on the rare
+        # element whose gradient is ~0 (update = lr * g / (|g| + eps)), hence a bounded handful of outliers
+        d = np.abs(pa[k].cpu().numpy() - pb[k].cpu().numpy())
+        assert d.max() <= 5e-4 and np.mean(d > 5e-6) <= 2e-3, (k, d.max(), np.mean(d > 5e-6))
     # a validation step in between leaves the prefetched training batch in place
     ta.run_val_step(False)
     assert ta._prepared is not None

@@ -50,7 +50,7 @@ class Batch(C.Structure):
 
 class PtDims(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("B", "n", "R", "D", "H", "W", "A", "Vq", "n_ws", "L", "flags")] + \
-               [("keep_att", C.c_float), ("keep_joint", C.c_float)]
+               [("keep_att", C.c_float), ("keep_joint", C.c_float), ("global_valid", C.c_float * 2)]
 
 
 class PtFc(C.Structure):
@@ -166,11 +166,13 @@ SIGNATURES = {
     "vqa_pretrain_forward": (_I, [C.POINTER(PtDims), C.POINTER(PtParams), C.POINTER(PtBatch), _P, _L, _I, _P]),
     "vqa_pretrain_backward": (_I, [C.POINTER(PtDims), C.POINTER(PtParams), C.POINTER(PtParams), C.POINTER(PtBatch), _P, _L,
                                    _P, _P]),
+    "vqa_pretrain_backward_phases": (_I, [C.POINTER(PtDims), C.POINTER(PtParams), C.POINTER(PtParams),
+                                          C.POINTER(PtBatch), _P, _L, _P, _I, _P]),
     "vqa_fusion_backward": (_I, [C.POINTER(Dims), C.POINTER(Params), C.POINTER(Params), C.POINTER(Batch), _P, _L,
                                  _P, _P]),
 }
 
-ABI_VERSION = 3      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
+ABI_VERSION = 4      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
 
 _lib = None
 

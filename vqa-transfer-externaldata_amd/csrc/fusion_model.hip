@@ -548,7 +548,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }
     // embedding: un-aggregated slices dx [T,B,W], then scatter-add
     float* dx = c.f("dx_embed");
-    if (xcat_enabled()) {       // wx_cat was packed by the forward of this step (the weights have not moved since)
+    if (xcat_enabled()) {       // packed again here (one 3.7 MB kernel): no hidden dependence on the forward's copy
+        TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
         TRY(gemm(c, 0, 1, T * B, W, 3 * H, dxp, (int)(3 * H), c.f("wx_cat"), (int)(3 * H), dx, (int)W));
     } else {
         TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));

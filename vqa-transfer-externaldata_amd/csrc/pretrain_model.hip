@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void box6_kernel(const float* __restrict__ key
     o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = b.z - b.x; o[5] = b.w - b.y;
 }
 
-// valid[b, j] = j < num[b] ; inv_valid = 1 / sum(valid)     (tf.sequence_mask + reduce_sum, :675-706)
+// valid[b, j] = j < num[b] ; inv_valid = 1 / sum(valid)     (tf.sequence_mask + reduce_sum, :675-706); under data
+// parallelism the sum runs over the GLOBAL batch and is handed in (global_valid > 0)
 __global__ __launch_bounds__(256) void valid_kernel(const int32_t* __restrict__ num, float* __restrict__ valid,
-                                                    float* __restrict__ inv_valid, int B, int n) {
+                                                    float* __restrict__ inv_valid, int B, int n, float global_valid) {
     __shared__ float red[16];
     float tot = 0.f;
     for (int i = threadIdx.x; i < B * n; i += 256) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void valid_kernel(const int32_t* __restrict__ 
         tot += v;
     }
     tot = block_sum(tot, red);
-    if (threadIdx.x == 0) inv_valid[0] = 1.f / tot;
+    if (threadIdx.x == 0) inv_valid[0] = 1.f / (global_valid > 0.f ? global_valid : tot);
 }
 
 // out[i, :] = in[index[i], :]   (rows of `cols` 4-byte words; index == NULL copies)
@@ -389,7 +390,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
                                   P->spat_att_score.b, kb.keep_att, dims->keep_att, c.f(p + "att"), c.f(p + "pooled"),
                                   (int)B, (int)n, (int)R, (int)H, (int)D, c.st));
         hipLaunchKernelGGL(valid_kernel, dim3(1), dim3(256), 0, c.st, kb.num, c.f(p + "valid"), c.f(p + "inv_valid"),
-                           (int)B, (int)n);
+                           (int)B, (int)n, dims->global_valid[k]);
         VQA_CHECK_LAUNCH();
 
         // ---- build_*_wordset
@@ -468,10 +469,19 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     return VQA_OK;
 }
 
-extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* P,
-                                     const vqa_pretrain_params_t* G, const vqa_pretrain_batch_t* bt, void* workspace,
-                                     int64_t workspace_bytes, float* slice_sq, void* stream) {
+// Backward in dependency-ordered phases, so that a data-parallel caller can start reducing the gradients a phase
+// completed while the next phase runs (the cfg-5 counterpart of vqa_fusion_backward_phases):
+//   1  the four stacked heads: classifier, joint_fc, pooled_linear_l, q_linear_l (weights, biases, LayerNorms)
+//   2  back-propagation through time of the joint caption batch + the GRU kernels' and biases' gradients
+//   4  dx of the packed x-projection -> L_GloVe scatter-add (starts the running slice sum of squares)
+//   8  per category: wordset_ft / wordset_map, spatial attention, spat_v_linear_v / spat_q_linear_v (finishes slice_sq)
+// Each phase reads what the lower-numbered ones left in the workspace; a step runs them in this order.
+extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* P,
+                                            const vqa_pretrain_params_t* G, const vqa_pretrain_batch_t* bt,
+                                            void* workspace, int64_t workspace_bytes, float* slice_sq, int phases,
+                                            void* stream) {
     VQA_REQUIRE(dims_ok(dims) && P && G && bt && workspace, VQA_ERR_ARG);
+    VQA_REQUIRE(phases > 0 && phases < 16, VQA_ERR_ARG);
     const Layout L = make_layout(*dims);
     VQA_REQUIRE(workspace_bytes >= L.total, VQA_ERR_WORKSPACE);
     const Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream)};
@@ -479,10 +489,8 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
     const int64_t Bn = B * n;
     const bool ln_shared = (dims->flags & VQA_FLAG_SHARED_LN) != 0;
     auto li = [ln_shared](int site) { return ln_shared ? 0 : site; };
-    Acc acc{c, {}};
-    // the two embedding tables are scatter-added: cleared here; every other gradient is overwritten on first touch
-    if (hipMemsetAsync(G->l_glove, 0, (size_t)dims->Vq * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
-    if (hipMemsetAsync(G->wordset_map, 0, (size_t)dims->n_ws * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+    Acc acc{c, {}};      // no gradient is touched by two different phases, so the first-touch record may be per call
+    // the two embedding tables are scatter-added: cleared in their phase; every other gradient is overwritten on first touch
     const float* sq_prev = nullptr;
     auto add_slice_sq = [&](const float* g, int64_t cnt) -> int {     // running sum of the un-aggregated slice norms
         TRY(vqa_sumsq(g, cnt, sq_prev, c.f("sq"), c.f("sumsq_ws"), c.count("sumsq_ws"), c.st));
@@ -490,7 +498,7 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         return VQA_OK;
     };
     // ---- the four heads, stacked (ln = 2 t + k): every shared FC's dW and dx is one GEMM over the 4 Bn rows
-    {
+    if (phases & 1) {
         const int64_t SH = Bn * H, SJ = Bn * 2 * H;
         auto hname = [&](int ln) { return std::string(KIND[ln & 1]) + "/" + HEAD[ln >> 1] + "/"; };
         TRY(acc.weight(G->classifier.w, c.f("S/j"), (int)(2 * H), c.f("S/dz"), (int)A, 2 * H, A, 4 * Bn));
@@ -523,12 +531,13 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(fc_bwd(c, acc, "d_llpre", c.f("S/lft"), 4 * Bn, H, H, P->q_linear_l, G->q_linear_l, c.f("d_lft")));
     }
     // ---- blank fill -> GRU -> L_GloVe, both categories as the one batch of the forward
-    {
-        const int64_t B2 = 2 * Bn;
+    const int64_t B2 = 2 * Bn;
+    float* dxp = c.f("dxp");
+    const int ld3 = (int)(3 * H);
+    if (phases & 2) {
         TRY(gather_rows(c.f("d_lft"), bt->perm, c.f("d_state_s"), B2, H, c.st));   // rows [0, 2 Bn) of d_lft, into the sorted order
         const float* Wg_h = P->gru_wg + W * 2 * H;
         const float* Wc_h = P->gru_wc + W * H;
-        float* dxp = c.f("dxp");
         const float* hs = c.f("J/hs");
         if (bt->live_rows != nullptr)
             TRY(vqa_gru_seq_bwd_live(c.f("d_state_s"), Wg_h, Wc_h, c.i32("J/lens_s"), bt->live_rows, hs, c.f("J/gru_r"),
@@ -536,7 +545,6 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         else
             TRY(vqa_gru_seq_bwd(c.f("d_state_s"), Wg_h, Wc_h, c.i32("J/lens_s"), hs, c.f("J/gru_r"), c.f("J/gru_u"),
                                 c.f("J/gru_c"), dxp, c.f("d_hscratch"), (int)T, (int)B2, (int)H, c.st));
-        const int ld3 = (int)(3 * H);
         // x rows of both kernels' gradients as one GEMM into the packed [Wp, 3H] block; x_tm carries the constant 1 in
         // column W, so row W of the block is the two bias gradients and dxp is not read again for them.  The h rows
         // as before
@@ -545,13 +553,22 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(acc.weight(G->gru_wg + W * 2 * H, hs, (int)H, dxp, ld3, H, 2 * H, T * B2));
         TRY(acc.weight(G->gru_wc + W * H, c.f("J/gru_rh"), (int)H, dxp + 2 * H, ld3, H, H, T * B2));
         TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
+    }
+    if (phases & 4) {
+        if (hipMemsetAsync(G->l_glove, 0, (size_t)dims->Vq * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
         float* dx = c.f("dx");
-        TRY(c.gemm(0, 1, T * B2, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));   // packed by the forward
+        // packed again here (one small kernel): no hidden dependence on the forward's copy of the weights
+        TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
+        TRY(c.gemm(0, 1, T * B2, W, 3 * H, dxp, ld3, c.f("wx_cat"), (int)(3 * H), dx, (int)W));
         TRY(vqa_embed_bwd_len_det(dx, c.i32("J/blanks_s"), c.i32("J/lens_s"), G->l_glove, (int)B2, (int)T, (int)W,
                                   dims->Vq, (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
         TRY(add_slice_sq(dx, T * B2 * W));
     }
-    for (int k = 0; k < 2; ++k) {
+    if (phases & 8) {
+        if (hipMemsetAsync(G->wordset_map, 0, (size_t)dims->n_ws * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+        if (!(phases & 4)) sq_prev = c.f("sq");      // phase 4 of this step left the captions' slice sum of squares there
+    }
+    for (int k = 0; k < 2 && (phases & 8); ++k) {
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         const std::string p = std::string(KIND[k]) + "/";
         const float* d_pooled = c.f("d_pooled") + k * Bn * D;
@@ -573,8 +590,14 @@ extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_
         TRY(fc_ln_bwd(c, acc, c.f("d_qv"), c.f(p + "key6"), Bn, 6, H, P->spat_q_linear_v, G->spat_q_linear_v, li(k), (int)n, 0,
                       p + "qv_pre", p + "qv_mean", p + "qv_rstd", nullptr, 1.f, "d_qvpre", nullptr));
     }
-    if (slice_sq != nullptr && sq_prev != nullptr)
+    if ((phases & 8) && slice_sq != nullptr && sq_prev != nullptr)
         if (hipMemcpyAsync(slice_sq, sq_prev, sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
             return VQA_ERR_LAUNCH;
     return VQA_OK;
+}
+
+extern "C" int vqa_pretrain_backward(const vqa_pretrain_dims_t* dims, const vqa_pretrain_params_t* P,
+                                     const vqa_pretrain_params_t* G, const vqa_pretrain_batch_t* bt, void* workspace,
+                                     int64_t workspace_bytes, float* slice_sq, void* stream) {
+    return vqa_pretrain_backward_phases(dims, P, G, bt, workspace, workspace_bytes, slice_sq, 15, stream);
 }

@@ -30,7 +30,12 @@ KINDS = ("obj", "attr")
 KEEP_ATT, KEEP_JOINT = 0.8, 0.5
 ADAM_B1, ADAM_B2, ADAM_EPS, CLIP_NORM = 0.9, 0.999, 1e-8, 20.0
 NO_GRAD_VARS = ("V_GloVe/embed_map", "LearnAnswerGloVe/embed_map")      # created for export only
-SPARSE_VARS = ("L_GloVe/embed_map", "wordset_map/learn")                # IndexedSlices gradients
+SPARSE_VARS = ("wordset_map/learn", "L_GloVe/embed_map")                # IndexedSlices gradients
+# Order of the dense variables in the flat buffers = the order in which the phases of vqa_pretrain_backward_phases
+# complete their gradients, so every data-parallel bucket is one contiguous range:
+#   [wordset_map | L_GloVe | GRU (phase 2) | stacked heads (phase 1) | spatial attention, wordset_ft (phase 8) | tail]
+PHASE_SCOPES = (("encode_L_blank/",), ("classifier/", "joint_fc/", "pooled_linear_l/", "q_linear_l/"),
+                ("spat_att/", "spat_q_linear_v/", "spat_v_linear_v/", "wordset_ft/"))
 
 
 def ln_name(scope, idx):
@@ -130,13 +135,22 @@ class PretrainEngine:
         self.ln_shared = bool(ln_shared)
         self.shapes = variable_shapes(self.Vq, self.n_ws, self.A, self.W, self.D, self.H, self.ln_shared)
         dense = sorted(k for k in self.shapes if k not in NO_GRAD_VARS and k not in SPARSE_VARS)
-        self.train_names = list(SPARSE_VARS) + dense
+        groups = [[k for k in dense if k.startswith(sc)] for sc in PHASE_SCOPES]
+        assert sorted(sum(groups, [])) == dense, "a variable outside the phase scopes"
+        self.train_names = list(SPARSE_VARS) + sum(groups, [])
         off, self._tab = 0, {}
         for k in self.train_names:
             cnt = int(np.prod(self.shapes[k]))
             self._tab[k] = (off, cnt)
             off += _pad4(cnt)
         self.n_train = off
+        # bucket bounds (floats): wordset_map [0, b0), L_GloVe [b0, b1), GRU [b1, b2), heads [b2, b3), rest [b3, n_train)
+        ends, o = [], 0
+        for names in ([SPARSE_VARS[0]], [SPARSE_VARS[1]], groups[0], groups[1], groups[2]):
+            o += sum(_pad4(int(np.prod(self.shapes[k]))) for k in names)
+            ends.append(o)
+        self._bounds = tuple(ends)
+        assert ends[-1] == self.n_train
         self.sparse_floats = sum(_pad4(int(np.prod(self.shapes[k]))) for k in SPARSE_VARS)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.train_flat = torch.zeros(self.n_train, **f32)
@@ -157,15 +171,18 @@ class PretrainEngine:
         return (_lib.FLAG_DETERMINISTIC if self.deterministic else 0) | (_lib.FLAG_SHARED_LN if self.ln_shared else 0)
 
     # ------------------------------------------------------------------ C-ABI plumbing
-    def make_keep_masks(self, B, seed, step):
-        """reproducible dropout keep-masks for (seed, step): {kind/att, kind/bf_joint, kind/ws_joint}"""
+    def make_keep_masks(self, B, seed, step, row_offset=0, global_rows=None):
+        """reproducible dropout keep-masks for (seed, step): {kind/att, kind/bf_joint, kind/ws_joint}.  The stream is
+        indexed by the GLOBAL image row: a data-parallel shard of B images passes its first global row (row_offset) and
+        the global batch size and draws exactly the bits one process on the whole batch would draw for its rows."""
         n, R, H = self.n, self.R, self.H
-        out, off = {}, step * (2 * (B * n * R * H + 2 * B * n * 2 * H))
+        Bg = int(global_rows) if global_rows is not None else B
+        out, off = {}, step * (2 * (Bg * n * R * H + 2 * Bg * n * 2 * H))
         for k in KINDS:
-            for name, cnt, keep in ((k + "/att", B * n * R * H, KEEP_ATT), (k + "/bf_joint", B * n * 2 * H, KEEP_JOINT),
-                                    (k + "/ws_joint", B * n * 2 * H, KEEP_JOINT)):
-                out[name] = ops.dropout_mask(cnt, seed, off, keep, self.device)
-                off += cnt
+            for name, per_image, keep in ((k + "/att", n * R * H, KEEP_ATT), (k + "/bf_joint", n * 2 * H, KEEP_JOINT),
+                                          (k + "/ws_joint", n * 2 * H, KEEP_JOINT)):
+                out[name] = ops.dropout_mask(B * per_image, seed, off + row_offset * per_image, keep, self.device)
+                off += Bg * per_image
         return out
 
     def _param_struct(self, table):
@@ -270,13 +287,31 @@ class PretrainEngine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ forward / backward
-    def forward(self, batch, masks, want_dz=True):
+    def global_valid_counts(self, batch, group=None):
+        """(#valid object entries, #valid attribute entries) of the GLOBAL batch = the denominators of the masked mean
+        losses (n_way_classification_loss, :675-706): this shard's counts, SUM-all-reduced over the ranks.  A trainer
+        whose ranks slice one global batch can compute the same numbers from the host arrays without a collective."""
+        import torch.distributed as dist
+        cnt = torch.stack([torch.as_tensor(batch[k + "_blank_fill/num"]).to(torch.int64).clamp(0, self.n).sum()
+                           for k in KINDS]).to(torch.float64)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            if dist.get_backend(group) == "gloo":
+                cnt = cnt.cpu()
+            else:
+                cnt = cnt.to(self.device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        return tuple(float(v) for v in cnt.cpu())
+
+    def forward(self, batch, masks, want_dz=True, global_valid=None):
         """batch: dict of arrays / tensors (keys of dataset_vlmap's batches; optional 'blank_fill/sort' from
-        add_length_sort); masks: uint8 keep-masks keyed '<kind>/att|bf_joint|ws_joint' or None (no dropout)."""
+        add_length_sort); masks: uint8 keep-masks keyed '<kind>/att|bf_joint|ws_joint' or None (no dropout);
+        global_valid: data parallel only -- (object, attribute) valid-entry counts of the global batch."""
         bs, B, L, keep = self._batch_struct(batch, masks)
         d = _lib.PtDims(B=B, n=self.n, R=self.R, D=self.D, H=self.H, W=self.W, A=self.A, Vq=self.Vq, n_ws=self.n_ws, L=L,
                         flags=self._flags(), keep_att=KEEP_ATT,
                         keep_joint=KEEP_JOINT)
+        if global_valid is not None:
+            d.global_valid[0], d.global_valid[1] = float(global_valid[0]), float(global_valid[1])
         need = int(self.lib.vqa_pretrain_workspace_bytes(C.byref(d)))
         if need <= 0:
             raise _lib.VqaHotError("vqa_pretrain_workspace_bytes rejected the dims")
@@ -292,18 +327,47 @@ class PretrainEngine:
                 "blank_fill": {"z": self.tensor(k + "/bf/z").view(Bn, self.A)},
                 "wordset": {"z": self.tensor(k + "/ws/z").view(Bn, self.A)}} for k in KINDS}}
 
-    def fetch_report(self):
-        """report dict of the reference (13 scalars): <kind>_<task>_{loss,acc,top_5_acc}, total_loss"""
-        r = self.tensor("report")[:13].cpu().numpy()
+    def fetch_report(self, reduce=False, group=None):
+        """report dict of the reference (13 scalars): <kind>_<task>_{loss,acc,top_5_acc}, total_loss.  reduce: data
+        parallel -- every scalar is a sum over the shard's rows already divided by the GLOBAL valid count
+        (forward(global_valid=...)), so a SUM all-reduce gives what one process on the whole batch reports."""
+        import torch.distributed as dist
+        r = self.tensor("report")[:13]
+        if reduce and dist.is_initialized() and dist.get_world_size(group) > 1:
+            r = r.cpu() if dist.get_backend(group) == "gloo" else r.clone()
+            dist.all_reduce(r, op=dist.ReduceOp.SUM, group=group)
+        r = r.cpu().numpy()
         self.report = {self.lib.vqa_pretrain_report_key(i).decode(): float(r[i]) for i in range(13)}
         return self.report
 
-    def backward(self):
+    def _backward_phases(self, phases):
         tail = self.grad_flat[self.n_train:]
-        _lib.check(self.lib.vqa_pretrain_backward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct),
-                                                  C.byref(self._bs), C.c_void_p(self.workspace.data_ptr()),
-                                                  self.workspace.numel(), C.c_void_p(tail.data_ptr()), self._stream()),
-                   "vqa_pretrain_backward")
+        _lib.check(self.lib.vqa_pretrain_backward_phases(
+            C.byref(self.dims), C.byref(self._p_struct), C.byref(self._g_struct), C.byref(self._bs),
+            C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(), C.c_void_p(tail.data_ptr()), phases,
+            self._stream()), "vqa_pretrain_backward_phases")
+
+    def backward(self, reducer=None):
+        """All gradients into grad_flat (vlmap_memft/trainer.py:129-137: optimize_loss over every variable).  With a
+        bucketed `reducer` (dp.BucketedAllReduce) the dependency-ordered phases are enqueued one by one and each
+        finished bucket's all-reduce starts right away: the stacked heads' 50+ MB reduce under the back-propagation
+        through time, the GRU kernels under the dx GEMM + embedding scatter-add, L_GloVe under the spatial-attention
+        backward; only the last, small bucket (word sets, spatial FCs, slice sum of squares) is exposed."""
+        if reducer is None:
+            self._backward_phases(15)
+            return
+        b0, b1, b2, b3 = self._bounds[:4]
+        n = self.n_train
+        self._backward_phases(1)
+        reducer.start(self.grad_flat[b2:b3])
+        self._backward_phases(2)
+        reducer.start(self.grad_flat[b1:b2])
+        self._backward_phases(4)
+        reducer.start(self.grad_flat[b0:b1])
+        self._backward_phases(8)
+        reducer.start(self.grad_flat[:b0])
+        reducer.start(self.grad_flat[b3:])          # spatial attention / wordset_ft gradients + the tail (slice sum of squares)
+        reducer.finish()
 
     def optimizer_step(self, lr):
         """clip_by_global_norm(20) + Adam; the two embedding tables contribute their UN-AGGREGATED slice
@@ -321,9 +385,18 @@ class PretrainEngine:
                                           self.n_train, P(self.norm_sq), CLIP_NORM, lr_t, ADAM_B1, ADAM_B2, ADAM_EPS,
                                           st), "vqa_clip_adam")
 
-    def train_step(self, batch, masks, lr):
-        self.forward(batch, masks)
-        self.backward()
+    def train_step(self, batch, masks, lr, allreduce=None, global_valid=None):
+        """forward -> backward -> (gradient all-reduce) -> clip + Adam.  Data parallel: `allreduce` is a
+        dp.BucketedAllReduce (overlapped with the backward phases) or any callable on grad_flat; pass the global
+        valid counts so that every shard divides by the global denominators and a SUM reduce gives the gradient of
+        the global-batch losses; all ranks then apply the identical update."""
+        self.forward(batch, masks, global_valid=global_valid)
+        if allreduce is not None and hasattr(allreduce, "start"):
+            self.backward(reducer=allreduce)
+        else:
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.grad_flat)
         self.optimizer_step(lr)
 
     def state_dict(self):
