@@ -492,15 +492,26 @@ int vqa_crop_and_resize_nhwc(const float* fmap, int B, int H, int W, int C, cons
                              const int32_t* box_ind, int n_boxes, int crop_h, int crop_w, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
- * Measurement probe (bench.py): HIP events recorded by the library on the
- * op's own stream around every launch group whose label matches.  Labels:
- * "v_linear_v.fwd_gemm", "v_linear_v.dw_gemm", "gru.fwd", "gru.bwd",
- * "attn_pool.fwd", "attn_pool.bwd", "head.fwd_gemm", "forward", "backward".
- * vqa_probe_read synchronises the recorded events and returns the per-sample
- * durations in milliseconds (at most max_samples). */
-int vqa_probe_enable(const char* label, int max_samples);
+ * Measurement probe (bench.py) and trace ranges (csrc/probe.hip).  Every launch group of the whole-model entry points
+ * sits in a labelled scope on the group's own stream:
+ *   forward   "forward" = { "embed.fwd", "gru.xp_gemm", "gru.fwd", "fc.fwd_gemm", "fc.ln_fwd", "gather",
+ *             "v_linear_v.fwd_gemm", "v_linear_v.ln_fwd", "attn_pool.fwd", "eltwise", "head.fwd_gemm", "loss.fwd" }
+ *   backward  "backward" = { "head.bwd_gemm", "fc.ln_bwd", "fc.dw_gemm", "fc.dx_gemm", "eltwise", "attn_pool.bwd",
+ *             "v_linear_v.ln_bwd", "v_linear_v.dw_gemm", "gru.bwd", "gru.dx_gemm", "embed.bwd", "gru.dwx_gemm",
+ *             "gru.dwh_gemm" }
+ *   cfg-5     "pretrain.forward", "pretrain.backward" and "pt.*" groups (csrc/pretrain_model.hip)
+ * vqa_probe_enable(labels, max_samples): `labels` is a comma-separated list ("*" = every scope met); HIP events are
+ * recorded around every enabled group, at most max_samples per label.  vqa_probe_read_label synchronises the events of
+ * one label and returns its per-sample durations in milliseconds (vqa_probe_read: the first label of the list).
+ * vqa_probe_labels lists the labels ('\n'-separated; returns the buffer size needed).
+ * vqa_roctx_enable(1) (or VQA_HOT_ROCTX=1 in the environment) additionally opens a roctx range per scope, so that
+ * `rocprofv3 --kernel-trace --marker-trace` groups kernels by phase; VQA_ERR_UNSUPPORTED when no roctx library loads. */
+int vqa_probe_enable(const char* labels, int max_samples);
 int vqa_probe_read(float* ms_out, int capacity, int* n_out);
+int vqa_probe_read_label(const char* label, float* ms_out, int capacity, int* n_out);
+int vqa_probe_labels(char* buf, int capacity);
 int vqa_probe_disable(void);
+int vqa_roctx_enable(int on);
 
 /* The same in dependency-ordered phases (bit mask): 1 = head..attention..v_linear_v / q_linear_v /
  * score gradients, 2 = GRU BPTT + embedding gradient + slice sum of squares, 4 = GRU gate weight / bias

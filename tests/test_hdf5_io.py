@@ -261,6 +261,73 @@ def test_extractor_and_export_write_the_reference_layout(tmp_path):
     assert MV.load_word_weight_dir(d)["class_biases"].shape == (7,)
 
 
+def test_create_streams_rows_into_a_complete_file(tmp_path):
+    """hdf5_io.create: Empty placeholders are allocated as holes, the file is readable at once, rows written through the
+    memmaps appear in it; libhdf5 reads the result when the image has it"""
+    p = str(tmp_path / "stream.hdf5")
+    mm = H.create(p, {"image_features": H.Empty((5, 3, 4)), "num_boxes": np.arange(5, dtype=np.int32),
+                      "data_info": {"vfeat_dim": np.array(4, np.int32), "ids": H.Empty((2,), np.int32)}})
+    assert sorted(mm) == ["/data_info/ids", "/image_features"]
+    t = H.load_tree(p)
+    assert np.all(np.asarray(t["image_features"]) == 0) and t["image_features"].shape == (5, 3, 4)
+    mm["/image_features"][2] = 7.0
+    mm["/image_features"][4, 1] = [1, 2, 3, 4]
+    mm["/data_info/ids"][:] = [3, 4]
+    for m in mm.values():
+        m.flush()
+    t = H.load_tree(p)
+    want = np.zeros((5, 3, 4), np.float32); want[2] = 7; want[4, 1] = [1, 2, 3, 4]
+    np.testing.assert_array_equal(np.asarray(t["image_features"]), want)
+    np.testing.assert_array_equal(np.asarray(t["data_info"]["ids"]), [3, 4])
+    np.testing.assert_array_equal(np.asarray(t["num_boxes"]), np.arange(5))
+    if h5ref.load() is not None:
+        np.testing.assert_array_equal(h5ref.H5().read(p, "image_features", "f4").reshape(5, 3, 4), want)
+
+
+def test_sharded_extraction_parts_merge_into_the_single_run_table(tmp_path):
+    """Extractor(part=(rank, world)) + merge_parts: three ranks over 7 images (3 + 2 + 2, no collective on the data path)
+    give the file one process writes, num_boxes quirk included (every entry = the first image's count, :118-121)"""
+    import torch
+    from vqa_transfer_externaldata_amd import vfeat as VF, vfeat_extractor as VX
+
+    class FakeModel:
+        def build(self, batch):
+            return batch["image"].mean(dim=(1, 2))[:, None, :].repeat(1, batch["normal_box"].shape[1], 4)
+
+    rng = np.random.default_rng(9)
+    N, R = 7, 4
+    ids = ["COCO_%d.jpg" % i for i in range(N)]
+    id2idx = {k: (i * 3) % N for i, k in enumerate(ids)}                         # a non-trivial id -> row map
+    img = torch.from_numpy(rng.random((N, 8, 8, 3)).astype(np.float32))
+    nbx = torch.from_numpy(np.sort(rng.random((N, R, 4)).astype(np.float32), -1))
+    nums = [3, 4, 2, 4, 1, 4, 3]
+
+    def batches(lo, hi, bs=2):
+        for a in range(lo, hi, bs):
+            b = min(a + bs, hi)
+            yield {"image": img[a:b], "normal_box": nbx[a:b], "num_box": nums[a:b], "image_id": ids[a:b]}
+
+    single = str(tmp_path / "single.hdf5")
+    VF.Extractor(FakeModel(), id2idx, R, "w.ckpt").extract(batches(0, N), single)
+    sharded = str(tmp_path / "sharded.hdf5")
+    bounds = [VX.shard_of(N, r, 3) for r in range(3)]
+    assert bounds == [(0, 3), (3, 5), (5, 7)]
+    for r, (lo, hi) in enumerate(bounds):
+        out = VF.Extractor(FakeModel(), id2idx, R, "w.ckpt").extract(batches(lo, hi), sharded, part=(r, 3), n_part_rows=hi - lo)
+        assert out["image_features"].shape[0] == hi - lo and sorted(out["image_idx"]) == sorted(id2idx[i] for i in ids[lo:hi])
+        assert os.path.exists(VF.Extractor.part_path(sharded, r, 3))
+    VF.Extractor.merge_parts(sharded, 3, N)
+    assert not os.path.exists(VF.Extractor.part_path(sharded, 0, 3))
+    a, b = H.load_tree(single), H.load_tree(sharded)
+    for k in ("image_features", "normal_boxes", "spatial_features", "num_boxes"):
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+    assert np.all(np.asarray(b["num_boxes"]) == 3)
+    for k in ("vfeat_dim", "max_box_num"):
+        assert int(np.asarray(a["data_info"][k])) == int(np.asarray(b["data_info"][k]))
+    with H.File(sharded) as f:
+        assert f["data_info"]["pretrained_param_path"][()] == "w.ckpt"
+
+
 def _random_tree(rng, depth=0):
     dts = [np.float32, np.float64, np.int32, np.int64, np.uint8, np.int8, np.int16, np.uint16, np.uint32]
     tree = {}

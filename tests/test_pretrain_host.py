@@ -188,3 +188,27 @@ def test_length_sort_covers_both_caption_categories_as_one_batch():
     import torch
     tb = {k: (torch.from_numpy(v) if k.endswith("blanks_len") else v) for k, v in batch.items()}
     assert "blank_fill/sort" not in PT.add_length_sort(tb)
+
+
+def test_trainer_shards_the_global_batch_by_image_and_keeps_the_global_denominators():
+    """pretrain_trainer.Trainer._shard (data parallel, BASELINE configs[4]): contiguous image shards that cover the batch,
+    the global row of each shard's first image (dropout stream) and the GLOBAL valid-entry counts on every rank."""
+    from types import SimpleNamespace
+    from vqa_transfer_externaldata_amd import pretrain_trainer as PTT
+    rng = np.random.default_rng(0)
+    batch = PO.make_batch(rng, 7, 5, 6, 8, 4, 20, 9, 11)
+    batch["image_idx"] = np.arange(7, dtype=np.int64) * 3
+    want = tuple(float(np.clip(batch[k + "_blank_fill/num"], 0, 5).sum()) for k in ("obj", "attr"))
+    seen = []
+    for rank in range(3):
+        me = SimpleNamespace(world=3, rank=rank, config=SimpleNamespace(data_cfg=SimpleNamespace(n_obj_bf=5)))
+        sh = PTT.Trainer._shard(me, batch)
+        assert sh["_dp"]["global_rows"] == 7 and sh["_dp"]["global_valid"] == want
+        lo = sh["_dp"]["row_offset"]
+        n = len(sh["image_idx"])
+        for k, v in batch.items():
+            np.testing.assert_array_equal(sh[k], v[lo:lo + n], err_msg=k)
+        seen.extend(sh["image_idx"].tolist())
+    assert seen == batch["image_idx"].tolist()
+    one = SimpleNamespace(world=1, rank=0, config=None)
+    assert PTT.Trainer._shard(one, batch) is batch

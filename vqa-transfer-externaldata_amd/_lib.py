@@ -154,6 +154,9 @@ SIGNATURES = {
     "vqa_crop_and_resize_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "vqa_probe_enable": (_I, [C.c_char_p, _I]),
     "vqa_probe_read": (_I, [C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]),
+    "vqa_probe_read_label": (_I, [C.c_char_p, C.POINTER(C.c_float), _I, C.POINTER(_I)]),
+    "vqa_probe_labels": (_I, [C.c_char_p, _I]),
+    "vqa_roctx_enable": (_I, [_I]),
     "vqa_probe_disable": (_I, []),
     "vqa_fusion_workspace_bytes": (_L, [C.POINTER(Dims)]),
     "vqa_fusion_tensor": (_I, [C.POINTER(Dims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

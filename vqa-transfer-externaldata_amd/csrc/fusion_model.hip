@@ -206,31 +206,6 @@ bool join_side(const Ctx& c, Side& sd) {
     return join_side_record(sd) && hipStreamWaitEvent(c.st, sd.join, 0) == hipSuccess;
 }
 
-// ---- measurement probe -----------------------------------------------------
-struct Probe {
-    std::string label;
-    std::vector<hipEvent_t> ev;   // start/stop pairs
-    int used = 0, cap = 0;
-    bool on = false;
-} g_probe;
-
-struct ProbeScope {
-    bool active = false;
-    hipStream_t st;
-    ProbeScope(const char* label, hipStream_t s) : st(s) {
-        if (g_probe.on && g_probe.used < g_probe.cap && g_probe.label == label) {
-            active = true;
-            (void)hipEventRecord(g_probe.ev[2 * g_probe.used], st);
-        }
-    }
-    ~ProbeScope() {
-        if (active) {
-            (void)hipEventRecord(g_probe.ev[2 * g_probe.used + 1], st);
-            g_probe.used++;
-        }
-    }
-};
-
 #define TRY(x)                      \
     do {                            \
         int rc__ = (x);             \
@@ -261,6 +236,7 @@ int fc_ln_relu_fwd(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N
         ProbeScope ps(rows > 1 ? "v_linear_v.fwd_gemm" : "fc.fwd_gemm", c.st);
         TRY(gemm(c, 0, 0, M, N, K, x, (int)K, p.w, (int)N, c.f(pre), (int)N, p.b));
     }
+    ProbeScope ps(rows > 1 ? "v_linear_v.ln_fwd" : "fc.ln_fwd", c.st);
     return vqa_ln_relu_fwd(c.f(pre), p.gamma, p.beta, keep, keep_prob, c.f(y), c.f(mean), c.f(rstd), (int)(M / rows),
                            rows, (int)N, c.st);
 }
@@ -272,18 +248,24 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
                    const uint8_t* keep, float keep_prob, const char* d_pre, float* dx, bool dx_accumulate) {
     const bool train = g != nullptr && g->w != nullptr;
     const int64_t G = M / rows;
-    TRY(vqa_ln_relu_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma, p.beta, keep, keep_prob, c.f(d_pre),
-                        train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
-                        train ? c.part(2) : nullptr, (int)G, rows, (int)N, c.st));
+    {
+        ProbeScope ps(rows > 1 ? "v_linear_v.ln_bwd" : "fc.ln_bwd", c.st);
+        TRY(vqa_ln_relu_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma, p.beta, keep, keep_prob, c.f(d_pre),
+                            train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
+                            train ? c.part(2) : nullptr, (int)G, rows, (int)N, c.st));
+        if (train)
+            TRY(vqa_colsum3(c.part(0), c.part(1), c.part(2), (int)G, (int)N, (int)N, g->gamma, g->beta, g->b,
+                            c.colsum_ws(), c.colsum_ws_floats(), c.st));
+    }
     if (train) {
-        TRY(vqa_colsum3(c.part(0), c.part(1), c.part(2), (int)G, (int)N, (int)N, g->gamma, g->beta, g->b,
-                        c.colsum_ws(), c.colsum_ws_floats(), c.st));
         ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
         TRY(gemm(c, 1, 0, K, N, M, x, (int)K, c.f(d_pre), (int)N, g->w, (int)N));  // dW = x^T * d_pre
     }
-    if (dx != nullptr)
+    if (dx != nullptr) {
+        ProbeScope ps("fc.dx_gemm", c.st);
         TRY(gemm(c, 0, 1, M, K, N, c.f(d_pre), (int)N, p.w, (int)N, dx, (int)K, nullptr,
                  dx_accumulate ? dx : nullptr, (int)K));
+    }
     return VQA_OK;
 }
 
@@ -346,8 +328,11 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     // of having been pushed out by the recurrence's traffic.
     auto visual_branch = [&]() -> int {
         // a1: V_ft = features[image_idx] (a pass of its own, or inside the GEMM below), num_V_ft = num_boxes[image_idx]
-        TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
-                                cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, cv.st));
+        {
+            ProbeScope ps("gather", cv.st);
+            TRY(vqa_gather_features(bt->table, bt->nbox_table, bt->image_idx, fuse_gather ? nullptr : cv.f("V_ft"),
+                                    cv.i32("num_V_ft"), (int)B, (int)R, (int)D, dims->N_img, cv.st));
+        }
         // a2: v_linear_v, LN statistics over the whole [R,H] block of a sample
         if (fuse_gather) {
             {
@@ -356,6 +341,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                                         P->v_linear_v.w, (int)H, cv.f("pre_v"), (int)H, P->v_linear_v.b, cv.f("V_ft"), (int)D,
                                         cv.st));
             }
+            ProbeScope ps("v_linear_v.ln_fwd", cv.st);
             TRY(vqa_ln_relu_fwd(cv.f("pre_v"), P->v_linear_v.gamma, P->v_linear_v.beta, nullptr, 1.f, cv.f("v_linear_v"),
                                 cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
         } else {
@@ -371,15 +357,21 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     // x_tm rows carry the constant 1 after the W inputs (vqa_embed_fwd_ld): the x-part weight-gradient GEMM then also
     // delivers the bias gradients, and the two passes over dxp that summed its columns are gone
     const int64_t Wp = ((W + 1 + 3) / 4) * 4;
-    TRY(vqa_embed_fwd_ld(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, (int)Wp, c.st));
+    {
+        ProbeScope ps("embed.fwd", c.st);
+        TRY(vqa_embed_fwd_ld(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, dims->Vq, (int)Wp, c.st));
+    }
     // a4: GRU.  Input projections of all steps as two big GEMMs ...
     float* xp = c.f("xp");
+    {
+    ProbeScope ps("gru.xp_gemm", c.st);
     if (xcat_enabled()) {
         TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
         TRY(gemm(c, 0, 0, T * B, 3 * H, W, c.f("x_tm"), (int)Wp, c.f("wx_cat"), (int)(3 * H), xp, (int)(3 * H), c.f("bx_cat")));
     } else {
         TRY(gemm(c, 0, 0, T * B, 2 * H, W, c.f("x_tm"), (int)Wp, P->gru_wg, (int)(2 * H), xp, (int)(3 * H), P->gru_bg));
         TRY(gemm(c, 0, 0, T * B, H, W, c.f("x_tm"), (int)Wp, P->gru_wc, (int)H, xp + 2 * H, (int)(3 * H), P->gru_bc));
+    }
     }
     float* hs = c.f("hs");
     if (hipMemsetAsync(hs, 0, (size_t)B * H * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
@@ -420,7 +412,10 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                        "rstd_pl", nullptr, 1.f));
     TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
     // a9
-    TRY(vqa_mul(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), B * H, c.st));
+    {
+        ProbeScope ps("eltwise", c.st);
+        TRY(vqa_mul(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), B * H, c.st));
+    }
     TRY(fc_ln_relu_fwd(c, c.f("joint_in"), B, H, 2 * H, P->joint_fc, 1, "pre_j", "joint", "mean_j", "rstd_j",
                        bt->keep_joint, dims->keep_joint));
     // a10
@@ -436,6 +431,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
     }
     // a11 (the train loss is masked by the train-answer mask in vlmap_answer and standard_word2vec, not in standard)
+    ProbeScope ps("loss.fwd", c.st);
     TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
                      dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
                      want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
@@ -471,6 +467,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     float* dxp = c.f("dxp");
 
     if (phases & 1) {
+    {
+    ProbeScope ps_head("head.bwd_gemm", c.st);
     if (dims->model_type == 2) {
         // word2vec head: d_joint2 = dlogit * G^T (the GloVe matrix is a constant), then the classifier FC
         VQA_REQUIRE(P->answer_glove != nullptr, VQA_ERR_ARG);
@@ -488,11 +486,15 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }
     TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head.w, (int)A, c.f("d_joint"), (int)(2 * H)));
     }
+    }
     // joint_fc (dropout mask folded into the LN/ReLU backward)
     TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("joint_in"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j", "mean_j",
                        "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_joint_in"), false));
-    TRY(vqa_mul_bwd(c.f("d_joint_in"), c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("d_pl"), c.f("d_ll"), B * H,
-                    c.st));
+    {
+        ProbeScope ps("eltwise", c.st);
+        TRY(vqa_mul_bwd(c.f("d_joint_in"), c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("d_pl"), c.f("d_ll"), B * H,
+                        c.st));
+    }
     TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
                        "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));
     TRY(fc_ln_relu_bwd(c, c.f("d_ll"), h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll",
@@ -505,6 +507,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
                           c.f("part_db"), (int)B, (int)R, (int)H, (int)D, c.st));
     }
     if (G->score.w != nullptr) {
+        ProbeScope ps("attn_pool.bwd", c.st);
         TRY(colsum(c, c.f("part_dw"), B, H, (int)H, G->score.w));
         TRY(colsum(c, c.f("part_db"), B, 1, 1, G->score.b));
     }
@@ -548,6 +551,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }
     // embedding: un-aggregated slices dx [T,B,W], then scatter-add
     float* dx = c.f("dx_embed");
+    {
+    ProbeScope ps("gru.dx_gemm", c.st);
     if (xcat_enabled()) {       // packed again here (one 3.7 MB kernel): no hidden dependence on the forward's copy
         TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
         TRY(gemm(c, 0, 1, T * B, W, 3 * H, dxp, (int)(3 * H), c.f("wx_cat"), (int)(3 * H), dx, (int)W));
@@ -555,6 +560,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));
         TRY(gemm(c, 0, 1, T * B, W, H, dxp + 2 * H, (int)(3 * H), P->gru_wc, (int)H, dx, (int)W, nullptr, dx, (int)W));
     }
+    }
+    ProbeScope ps_embed("embed.bwd", c.st);
     if (G->embed != nullptr)
         TRY(vqa_embed_bwd_len_det(dx, bt->q_intseq, bt->q_intseq_len, G->embed, (int)B, (int)T, (int)W, dims->Vq,
                                   (dims->flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
@@ -563,6 +570,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }   // phase 2
 
     if ((phases & 4) && G->gru_wg != nullptr) {
+        {
+        ProbeScope ps("gru.dwx_gemm", c.st);
         if (xcat_enabled()) {   // x rows of BOTH kernels' gradients (the candidate's bucket is reduced after phase 4)
             // rows 0..W-1: x rows of both kernels' gradients; row W (the constant input): both bias gradients
             TRY(gemm(c, 1, 0, Wp, 3 * H, T * B, c.f("x_tm"), (int)Wp, dxp, (int)(3 * H), c.f("dwx_cat"), (int)(3 * H)));
@@ -571,49 +580,19 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
             TRY(gemm(c, 1, 0, W, 2 * H, T * B, c.f("x_tm"), (int)Wp, dxp, (int)(3 * H), G->gru_wg, (int)(2 * H)));
             TRY(colsum(c, dxp, T * B, 2 * H, (int)(3 * H), G->gru_bg));
         }
+        }
+        ProbeScope ps("gru.dwh_gemm", c.st);
         TRY(gemm(c, 1, 0, H, 2 * H, T * B, hs, (int)H, dxp, (int)(3 * H), G->gru_wg + W * 2 * H, (int)(2 * H)));
     }   // phase 3: gates
     if ((phases & 8) && G->gru_wg != nullptr) {
         if (!xcat_enabled()) {
+            ProbeScope ps("gru.dwx_gemm", c.st);
             TRY(gemm(c, 1, 0, W, H, T * B, c.f("x_tm"), (int)Wp, dxp + 2 * H, (int)(3 * H), G->gru_wc, (int)H));
             TRY(colsum(c, dxp + 2 * H, T * B, H, (int)(3 * H), G->gru_bc));
         }
+        ProbeScope ps("gru.dwh_gemm", c.st);
         TRY(gemm(c, 1, 0, H, H, T * B, c.f("gru_rh"), (int)H, dxp + 2 * H, (int)(3 * H), G->gru_wc + W * H, (int)H));
     }   // phase 4: candidate
-    return VQA_OK;
-}
-
-extern "C" int vqa_probe_enable(const char* label, int max_samples) {
-    VQA_REQUIRE(label != nullptr && max_samples > 0 && max_samples <= 4096, VQA_ERR_ARG);
-    vqa_probe_disable();
-    g_probe.ev.resize(2 * (size_t)max_samples);
-    for (auto& e : g_probe.ev)
-        if (hipEventCreate(&e) != hipSuccess) return VQA_ERR_LAUNCH;
-    g_probe.label = label;
-    g_probe.cap = max_samples;
-    g_probe.used = 0;
-    g_probe.on = true;
-    return VQA_OK;
-}
-
-extern "C" int vqa_probe_read(float* ms_out, int capacity, int* n_out) {
-    VQA_REQUIRE(ms_out != nullptr && n_out != nullptr && capacity >= 0, VQA_ERR_ARG);
-    int n = 0;
-    for (int i = 0; i < g_probe.used && n < capacity; ++i) {
-        if (hipEventSynchronize(g_probe.ev[2 * i + 1]) != hipSuccess) return VQA_ERR_LAUNCH;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]) != hipSuccess) return VQA_ERR_LAUNCH;
-        ms_out[n++] = ms;
-    }
-    *n_out = n;
-    return VQA_OK;
-}
-
-extern "C" int vqa_probe_disable(void) {
-    for (auto& e : g_probe.ev) (void)hipEventDestroy(e);
-    g_probe.ev.clear();
-    g_probe.on = false;
-    g_probe.used = g_probe.cap = 0;
     return VQA_OK;
 }
 

@@ -372,6 +372,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     VQA_REQUIRE((bt->perm == nullptr) == (bt->inv == nullptr) && (bt->perm == nullptr) == (bt->live_rows == nullptr), VQA_ERR_ARG);
     ReportArgs ra{};
     ra.rows = (int)Bn;
+    ProbeScope ps_all("pretrain.forward", c.st);
     // the x rows of the two GRU kernels side by side (vqa_gru_pack_wx): one projection GEMM per category
     TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
     for (int k = 0; k < 2; ++k) {
@@ -379,6 +380,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
         VQA_REQUIRE(kb.normal_boxes && kb.fills && kb.blanks && kb.blanks_len && kb.wordsets && kb.num, VQA_ERR_ARG);
         const std::string p = std::string(KIND[k]) + "/";
         // ---- build_*_V_ft: spatial attention over the regions
+        ProbeScope ps_sp("pt.spatial_wordset.fwd", c.st);
         hipLaunchKernelGGL(box6_kernel, dim3((unsigned)((Bn + 255) / 256)), dim3(256), 0, c.st, kb.normal_boxes,
                            c.f(p + "key6"), (int)Bn);
         VQA_CHECK_LAUNCH();
@@ -404,6 +406,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     // [0, Bn) = obj/bf_state and [Bn, 2 Bn) = attr/bf_state of the stacked "S/lft" block
     {
         const int64_t B2 = 2 * Bn;
+        ProbeScope ps_g("pt.caption_gru.fwd", c.st);
         TRY(gather_rows2(bt->kind[0].blanks, bt->kind[1].blanks, bt->perm, c.i32("J/blanks_s"), B2, T, Bn, c.st));
         TRY(gather_rows2(bt->kind[0].blanks_len, bt->kind[1].blanks_len, bt->perm, c.i32("J/lens_s"), B2, 1, Bn, c.st));
         TRY(vqa_embed_fwd_ld(P->l_glove, c.i32("J/blanks_s"), c.f("J/x_tm"), (int)B2, (int)T, (int)W, dims->Vq,
@@ -428,6 +431,7 @@ extern "C" int vqa_pretrain_forward(const vqa_pretrain_dims_t* dims, const vqa_p
     {
         const int64_t SH = Bn * H, SJ = Bn * 2 * H, SA = Bn * A;
         auto hname = [&](int ln) { return std::string(KIND[ln & 1]) + "/" + HEAD[ln >> 1] + "/"; };
+        ProbeScope ps_h("pt.heads.fwd", c.st);
         // pooled_linear_l: both heads of a category apply the SAME FC to the same pooled features, so the product is
         // computed once per category (2 Bn rows)
         TRY(c.gemm(0, 0, 2 * Bn, H, D, c.f("S/pooled"), (int)D, P->pooled_linear_l.w, (int)H, c.f("S/vl_pre"), (int)H,
@@ -489,6 +493,7 @@ extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, con
     const int64_t Bn = B * n;
     const bool ln_shared = (dims->flags & VQA_FLAG_SHARED_LN) != 0;
     auto li = [ln_shared](int site) { return ln_shared ? 0 : site; };
+    ProbeScope ps_all("pretrain.backward", c.st);
     Acc acc{c, {}};      // no gradient is touched by two different phases, so the first-touch record may be per call
     // the two embedding tables are scatter-added: cleared in their phase; every other gradient is overwritten on first touch
     const float* sq_prev = nullptr;
@@ -499,6 +504,7 @@ extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, con
     };
     // ---- the four heads, stacked (ln = 2 t + k): every shared FC's dW and dx is one GEMM over the 4 Bn rows
     if (phases & 1) {
+        ProbeScope ps_h("pt.heads.bwd", c.st);
         const int64_t SH = Bn * H, SJ = Bn * 2 * H;
         auto hname = [&](int ln) { return std::string(KIND[ln & 1]) + "/" + HEAD[ln >> 1] + "/"; };
         TRY(acc.weight(G->classifier.w, c.f("S/j"), (int)(2 * H), c.f("S/dz"), (int)A, 2 * H, A, 4 * Bn));
@@ -535,6 +541,7 @@ extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, con
     float* dxp = c.f("dxp");
     const int ld3 = (int)(3 * H);
     if (phases & 2) {
+        ProbeScope ps_g("pt.caption_gru.bwd", c.st);
         TRY(gather_rows(c.f("d_lft"), bt->perm, c.f("d_state_s"), B2, H, c.st));   // rows [0, 2 Bn) of d_lft, into the sorted order
         const float* Wg_h = P->gru_wg + W * 2 * H;
         const float* Wc_h = P->gru_wc + W * H;
@@ -555,6 +562,7 @@ extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, con
         TRY(vqa_gru_unpack_dwx_bias(c.f("dwx_cat"), G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc, (int)W, (int)H, c.st));
     }
     if (phases & 4) {
+        ProbeScope ps_e("pt.caption_embed.bwd", c.st);
         if (hipMemsetAsync(G->l_glove, 0, (size_t)dims->Vq * W * 4, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
         float* dx = c.f("dx");
         // packed again here (one small kernel): no hidden dependence on the forward's copy of the weights
@@ -569,6 +577,7 @@ extern "C" int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, con
         if (!(phases & 4)) sq_prev = c.f("sq");      // phase 4 of this step left the captions' slice sum of squares there
     }
     for (int k = 0; k < 2 && (phases & 8); ++k) {
+        ProbeScope ps_sp("pt.spatial_wordset.bwd", c.st);
         const vqa_pretrain_kind_t& kb = bt->kind[k];
         const std::string p = std::string(KIND[k]) + "/";
         const float* d_pooled = c.f("d_pooled") + k * Bn * D;

@@ -19,6 +19,22 @@
         if (!(cond)) return (code); \
     } while (0)
 
+// Measurement / trace scope around a launch group (csrc/probe.hip): HIP events on `st` when the label is probed, a roctx
+// range when ranges are on.  Costs one branch when neither is.
+int vqa_probe_begin(const char* label, hipStream_t st, void** handle);
+void vqa_probe_end(int flags, hipStream_t st, void* handle);
+struct ProbeScope {
+    hipStream_t st;
+    void* handle = nullptr;
+    int flags;
+    ProbeScope(const char* label, hipStream_t s) : st(s) { flags = vqa_probe_begin(label, s, &handle); }
+    ~ProbeScope() {
+        if (flags) vqa_probe_end(flags, st, handle);
+    }
+    ProbeScope(const ProbeScope&) = delete;
+    ProbeScope& operator=(const ProbeScope&) = delete;
+};
+
 static inline bool vqa_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -531,12 +531,21 @@ def _object_header(msgs):
     return struct.pack("<BBHII", 1, 0, len(msgs), 1, len(body)) + b"\0\0\0\0" + body
 
 
+class Empty:
+    """Placeholder for `create`: a contiguous dataset of this shape / dtype whose data region is allocated (zeros, a hole
+    in the file) but not written -- the caller fills it through the np.memmap `create` hands back."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape, self.dtype = tuple(int(s) for s in shape), np.dtype(dtype).newbyteorder("<")
+
+
 class _Writer:
     LEAF_K, INTERNAL_K = 4, 16
 
     def __init__(self, fh):
         self.fh = fh
         self.pos = 0
+        self.regions = {}            # "/group/name" -> (address, shape, dtype) of every Empty placeholder
 
     def alloc(self, n, align=8):
         self.pos = (self.pos + align - 1) // align * align
@@ -548,7 +557,19 @@ class _Writer:
         self.fh.seek(addr)
         self.fh.write(data)
 
-    def dataset(self, value):
+    def dataset(self, value, name=None):
+        if isinstance(value, Empty):
+            nbytes = int(np.prod(value.shape, dtype=np.int64)) * value.dtype.itemsize
+            daddr = self.alloc(nbytes, 8) if nbytes else UNDEF
+            self.regions[name] = (daddr, value.shape, value.dtype)
+            space = struct.pack("<BBBBI", 1, len(value.shape), 0, 0, 0) + b"".join(struct.pack("<Q", d) for d in value.shape)
+            hdr = _object_header([_message(MSG_DATASPACE, space),
+                                  _message(MSG_DATATYPE, _dtype_message(value.dtype), flags=1),
+                                  _message(MSG_FILL, struct.pack("<BBBBI", 2, 2, 2, 1, 0)),
+                                  _message(MSG_LAYOUT, struct.pack("<BBQQ", 3, 1, daddr, nbytes))])
+            a = self.alloc(len(hdr))
+            self.put(a, hdr)
+            return a
         if isinstance(value, str):
             value = value.encode("utf-8")
         if isinstance(value, bytes):
@@ -583,7 +604,7 @@ class _Writer:
         self.put(a, hdr)
         return a
 
-    def group(self, tree):
+    def group(self, tree, prefix=""):
         """Writes the children first, then heap + symbol nodes + B-tree + header; returns (header, btree, heap)."""
         if len(tree) > 2 * self.LEAF_K * 2 * self.INTERNAL_K:
             raise Hdf5FormatError("too many entries in one group (%d)" % len(tree))
@@ -593,10 +614,10 @@ class _Writer:
                 raise Hdf5FormatError("bad object name %r" % name)
             v = tree[name]
             if isinstance(v, dict):
-                h, bt, hp = self.group(v)
+                h, bt, hp = self.group(v, prefix + "/" + name)
                 children.append((name, h, 1, bt, hp))
             else:
-                children.append((name, self.dataset(v), 0, 0, 0))
+                children.append((name, self.dataset(v, prefix + "/" + name), 0, 0, 0))
         # local heap data: "" at offset 0, then the names, 8-byte aligned each
         heap_data = bytearray(8)
         offs = []
@@ -638,6 +659,34 @@ class _Writer:
         return h_addr, bt_addr, heap_addr
 
 
+def _finish_file(w, fh, root, bt, hp):
+    eof = w.alloc(0, 8)
+    sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, w.LEAF_K, w.INTERNAL_K, 0)
+    sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+    sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", bt, hp)
+    assert len(sb) == 96
+    w.put(0, sb)
+    fh.seek(0, 2)
+    if fh.tell() < eof:
+        fh.truncate(eof)
+
+
+def create(path, tree):
+    """Like `write`, for tables that are filled row by row: `Empty(shape, dtype)` values become contiguous datasets whose
+    data region is allocated but left as a hole; returns {"/name": np.memmap opened r+} for them.  The file is complete
+    and readable (zeros where nothing was written yet) from the moment this returns -- the streaming counterpart of
+    h5py's `f.create_dataset(...)` followed by row assignments (vqa/vfeat_extractor_tf_record_memft.py:118-139)."""
+    with open(path, "wb") as fh:
+        w = _Writer(fh)
+        w.alloc(96)
+        root, bt, hp = w.group(tree)
+        _finish_file(w, fh, root, bt, hp)
+        regions = dict(w.regions)
+    return {name: (np.memmap(path, dtype=dt, mode="r+", offset=addr, shape=shape) if addr != UNDEF
+                   else np.zeros(shape, dt))
+            for name, (addr, shape, dt) in regions.items()}
+
+
 def write(path, tree):
     """Creates `path` from a nested dict: dict -> group, ndarray / scalar / str -> contiguous dataset.
     Format: superblock v0, v1 object headers, symbol-table groups -- what h5py's defaults produce."""
@@ -646,14 +695,6 @@ def write(path, tree):
         w = _Writer(fh)
         w.alloc(96)                                          # superblock
         root, bt, hp = w.group(tree)
-        eof = w.alloc(0, 8)
-        sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, w.LEAF_K, w.INTERNAL_K, 0)
-        sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
-        sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", bt, hp)
-        assert len(sb) == 96
-        w.put(0, sb)
-        fh.seek(0, 2)
-        if fh.tell() < eof:
-            fh.truncate(eof)
+        _finish_file(w, fh, root, bt, hp)
     os.replace(tmp, path)
     return path

@@ -98,6 +98,8 @@ class Model(object):
         for k in list(out):
             if k.endswith("_blank_fill/normal_boxes"):
                 out[k] = out[k].float()
+        if "_dp" in self.batch:               # data parallel: the shard's place in the global batch (Trainer._shard)
+            out["_dp"] = self.batch["_dp"]
         return out
 
     def prepare(self, batch):
@@ -137,15 +139,21 @@ class Model(object):
         tables = getattr(self.config, "feature_tables", None)
         if tables is not None and getattr(eng, "_tables", None) is None:
             eng.bind_tables(*tables)           # (image_features, spatial_features, num_boxes): gathered on the device
+        dpi = db.get("_dp") or {}
         masks = None if getattr(self.config, "dropout_off", False) else eng.make_keep_masks(
-            B, int(getattr(self.config, "seed", 123)), self._step)
+            B, int(getattr(self.config, "seed", 123)), self._step, row_offset=dpi.get("row_offset", 0),
+            global_rows=dpi.get("global_rows"))
         self._step += 1
-        eng.forward(db, masks)
+        self._reduce_report = bool(dpi)
+        eng.forward(db, masks, global_valid=dpi.get("global_valid"))
         for k in PT.KINDS:
             kt = eng._tape["kinds"][k]
             name = "object" if k == "obj" else "attribute"
             self.mid_result[name + "_pooled_V_ft"] = kt["pooled"].view(B, eng.n, -1)
             self.mid_result[k + "_blank_fill/logit"] = kt["wordset"]["z"].view(B, eng.n, -1)
+        if defer_report and self._reduce_report:
+            self._report_event = None             # data parallel: the scalars are reduced over the ranks in finish_report
+            return None
         if defer_report:
             if getattr(self, "_report_host", None) is None:
                 self._report_host = torch.empty(16, dtype=torch.float32).pin_memory()
@@ -163,13 +171,13 @@ class Model(object):
             self.report = eng.report = {eng.lib.vqa_pretrain_report_key(i).decode(): float(r[i]) for i in range(13)}
             self._report_event = None
         else:
-            self.report = eng.fetch_report()
+            self.report = eng.fetch_report(reduce=getattr(self, "_reduce_report", False))
         self.losses = {k[:-5]: v for k, v in self.report.items() if k.endswith("_loss") and k != "total_loss"}
         self.loss = self.report["total_loss"]
         return self.loss
 
-    def backward(self):
-        self._engine.backward()
+    def backward(self, reducer=None):
+        self._engine.backward(reducer=reducer)
 
     def apply_gradients(self, learning_rate):
         self._engine.optimizer_step(learning_rate)

@@ -31,11 +31,21 @@ class Trainer(object):
 
     def __init__(self, config, dataset):
         self.config = config
+        # Data parallel (BASELINE configs[4]: bs 512 over 8 GPUs; the reference runs one process, vlmap_memft/trainer.py:
+        # 129-137): every rank draws the SAME global batch (same seed), keeps its contiguous shard of the images, and
+        # the gradients meet in a bucketed all-reduce overlapped with the backward phases (pretrain.PretrainEngine).
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self._allreduce = None
+        if self.world > 1:
+            from . import dp
+            self._allreduce = dp.BucketedAllReduce()
         hyper = "bs{}_lr{}".format(config.batch_size, config.learning_rate)
         self.train_dir = getattr(config, "train_dir", None) or "./train_dir/{}_{}_{}_{}".format(
             config.model_type, config.prefix, hyper, time.strftime("%Y%m%d-%H%M%S"))
-        os.makedirs(self.train_dir, exist_ok=True)
-        log.infov("Train Dir: %s", self.train_dir)
+        if self.rank == 0:
+            os.makedirs(self.train_dir, exist_ok=True)
+            log.infov("Train Dir: %s", self.train_dir)
         self.batch_size = config.batch_size
         # Input side (not in the reference, whose sequential py_func pipeline fed a 2018 GPU): the feature tables of
         # both splits stay in HBM and batches carry image indices (features_on_device), batches are assembled by
@@ -62,7 +72,7 @@ class Trainer(object):
                         b["image_idx"] = b["image_idx"] + n_train
                         yield b
                 self._iters["val"] = offset(self._iters["val"])
-        self._pending = next(self._iters["train"])
+        self._pending = self._shard(next(self._iters["train"]))
         self.model = self.get_model_class(config.model_type)(self._pending, config, is_train=True)
         self.global_step = 0
         self.learning_rate = config.learning_rate
@@ -83,11 +93,27 @@ class Trainer(object):
             return self.learning_rate * (0.5 ** (self.global_step // 10000))
         return self.learning_rate
 
+    def _shard(self, batch):
+        """This rank's images of the global batch + what the step needs to know about the whole: the global row of its
+        first image (dropout stream), the global image count, and the global valid-entry counts per category (the
+        denominators of the masked mean losses), all from the host arrays -- no collective."""
+        if self.world == 1:
+            return batch
+        from . import dp
+        n_img = len(batch["image_idx"] if "image_idx" in batch else batch["image_ft"])
+        lo, hi = dp.shard_bounds(n_img, self.rank, self.world)
+        n_entries = int(self.config.data_cfg.n_obj_bf)
+        gv = tuple(float(np.clip(np.asarray(batch[k + "_blank_fill/num"]), 0, n_entries).sum()) for k in ("obj", "attr"))
+        out = {k: (v[lo:hi] if hasattr(v, "__len__") and not isinstance(v, (str, bytes, dict)) and len(v) == n_img else v)
+               for k, v in batch.items()}
+        out["_dp"] = {"row_offset": lo, "global_rows": n_img, "global_valid": gv}
+        return out
+
     def _next(self, split):
         if split == "train" and self._pending is not None:
             b, self._pending = self._pending, None
             return b
-        return next(self._iters[split])
+        return self._shard(next(self._iters[split]))
 
     def run_train_step(self, use_heavy_summary):
         _start = time.time()
@@ -95,7 +121,7 @@ class Trainer(object):
         if prepared is None:
             prepared = self.model.prepare(self._next("train"))
         self.model.build(prepared=prepared, defer_report=True)
-        self.model.backward()
+        self.model.backward(reducer=self._allreduce)
         self.model.apply_gradients(self._lr())
         # the GPU is busy with this step: draw the next batch and upload it now (tf.data prefetch of the reference)
         self._prepared = self.model.prepare(self._next("train"))
@@ -116,12 +142,14 @@ class Trainer(object):
         return self.global_step, summary, report["total_loss"], report, time.time() - _start
 
     def add_summary(self, s):
-        if s is not None:
+        if s is not None and self.rank == 0:
             with open(self._summary_path, "a") as f:
                 f.write(json.dumps(s) + "\n")
 
     def save_checkpoint(self):
         path = os.path.join(self.train_dir, "model-{}".format(self.global_step))
+        if self.rank != 0:          # every rank holds the same parameters and Adam slots
+            return path
         sd = self.model.engine.state_dict()
         sd["global_step"] = torch.tensor(self.global_step, dtype=torch.int64)
         sd["dropout_step"] = torch.tensor(int(getattr(self.model, "_step", 0)), dtype=torch.int64)
@@ -162,7 +190,8 @@ class Trainer(object):
         log_str += "({:.3f} sec/batch, {:.3f} instances/sec)]\n".format(step_time, self.batch_size / step_time)
         for key in sorted(avg_report.keys()):
             log_str += "  * {}: {:.5f}\n".format(key, np.array(avg_report[key], dtype=np.float32).mean())
-        (log.info if is_train else log.infov)(log_str)
+        if self.rank == 0:
+            (log.info if is_train else log.infov)(log_str)
         return log_str
 
 
@@ -206,6 +235,11 @@ def build_parser():
 
 def main(argv=None):
     config = build_parser().parse_args(argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        config.device = "cuda:%d" % local
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        config.input_workers = 0      # ranks are already one process per GPU; producers are forked before the GPU is touched
     torch.manual_seed(config.seed)
     np.random.seed(config.seed)
     dataset = {"train": dataset_vlmap.Dataset(config, "train", seed=config.seed),

@@ -11,6 +11,7 @@ contract of data/nets/resnet_v1_50.ckpt.  Layout NHWC, fp32, convolutions on the
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -268,19 +269,37 @@ class Extractor:
     """vqa/vfeat_extractor_tf_record_memft.py:26-147: run the model over batches and fill dense
     [N, max_roi, D] arrays (image_features, normal_boxes, spatial_features, num_boxes, data_info).  save_path
     ending in .hdf5 / .h5 writes the reference's HDF5 layout (hdf5_io, no h5py: the four datasets + group data_info
-    with max_box_num, vfeat_dim, pretrained_param_path); any other name writes an .npz with the same keys."""
+    with max_box_num, vfeat_dim, pretrained_param_path); any other name writes an .npz with the same keys.
+
+    HDF5 output is STREAMED like the reference's h5py datasets (:118-139): the file is created with the three tables
+    as holes when the first batch comes back, and every batch's rows go straight into np.memmap views of the file --
+    the 36 GB table of the real feature set is never held in host RAM, and rows extracted before a failure are on disk.
+    `part=(rank, world)`: this process extracts a SHARD of the images (feature extraction shards by image with no
+    collective); it writes a compact part file `<save_path>.part<rank>of<world>` (only its rows + their
+    image indices) that `merge_parts` folds into the final table."""
 
     def __init__(self, model, image_id2idx, max_roi_num, pretrained_param_path="random_init"):
         self.model, self.image_id2idx, self.max_roi_num = model, image_id2idx, max_roi_num
         self.pretrained_param_path = pretrained_param_path
 
-    def extract(self, batches, save_path=None):
+    @staticmethod
+    def part_path(save_path, rank, world):
+        return "%s.part%dof%d" % (save_path, rank, world)
+
+    def extract(self, batches, save_path=None, part=None, n_part_rows=None):
         """One batch in flight: while the GPU runs batch i, the host writes the rows of batch i-1 (its features come back
         through an asynchronous copy into pinned memory, awaited through an event) and the loader threads decode batch
-        i+1 -- the reference's loop is session.run, then the Python row loop, serially (:99-139)."""
+        i+1 -- the reference's loop is session.run, then the Python row loop, serially (:99-139).
+        part / n_part_rows: shard mode, see the class docstring (n_part_rows = number of images this shard will see)."""
+        from . import hdf5_io
         N = len(self.image_id2idx)
-        state = {"feats": None, "boxes": None, "spat": None}
+        stream = save_path is not None and save_path.endswith((".hdf5", ".h5"))
+        if part is not None and not stream:
+            raise ValueError("sharded extraction writes HDF5 parts: save_path must end in .hdf5 / .h5")
+        rows_total = N if part is None else int(n_part_rows)
+        state = {"feats": None, "boxes": None, "spat": None, "next": 0, "first_n": None}
         num_boxes = np.zeros([N], np.int32)
+        part_idx = np.full([rows_total], -1, np.int32) if part is not None else None
         pool = {}
 
         def pinned(t, slot):
@@ -288,6 +307,33 @@ class Extractor:
             if key not in pool:
                 pool[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
             return pool[key]
+
+        def data_info(D):
+            return {"pretrained_param_path": self.pretrained_param_path.replace("/", "-"),
+                    "max_box_num": np.array(self.max_roi_num, np.int32), "vfeat_dim": np.array(D, np.int32)}
+
+        def init_tables(D, n):
+            state["first_n"] = n
+            num_boxes[:] += n                            # reference initialises every entry to the first n
+            if not stream:
+                state["feats"] = np.zeros((rows_total, self.max_roi_num, D), np.float32)
+                state["boxes"] = np.zeros((rows_total, self.max_roi_num, 4), np.float32)
+                state["spat"] = np.zeros((rows_total, self.max_roi_num, 6), np.float32)
+                return
+            tree = {"image_features": hdf5_io.Empty((rows_total, self.max_roi_num, D)),
+                    "normal_boxes": hdf5_io.Empty((rows_total, self.max_roi_num, 4)),
+                    "spatial_features": hdf5_io.Empty((rows_total, self.max_roi_num, 6)),
+                    "data_info": data_info(D)}
+            if part is None:
+                tree["num_boxes"] = num_boxes.copy()
+                path = save_path
+            else:
+                tree["image_idx"] = hdf5_io.Empty((rows_total,), np.int32)
+                tree["first_num_box"] = np.array(n, np.int32)
+                path = self.part_path(save_path, *part)
+            mm = hdf5_io.create(path, tree)
+            state["feats"], state["boxes"], state["spat"] = mm["/image_features"], mm["/normal_boxes"], mm["/spatial_features"]
+            state["idx_mm"] = mm.get("/image_idx")
 
         def finish(p):
             v_host, nb_host, nums, ids, ev = p
@@ -297,11 +343,11 @@ class Extractor:
             for b in range(v.shape[0]):
                 n = min(int(nums[b]), self.max_roi_num)
                 if state["feats"] is None:
-                    state["feats"] = np.zeros((N, self.max_roi_num, v.shape[2]), np.float32)
-                    state["boxes"] = np.zeros((N, self.max_roi_num, 4), np.float32)
-                    state["spat"] = np.zeros((N, self.max_roi_num, 6), np.float32)
-                    num_boxes[:] += n                            # reference initialises every entry to the first n
+                    init_tables(v.shape[2], n)
                 idx = self.image_id2idx[ids[b]]
+                if part is not None:                     # compact rows in arrival order + where they belong
+                    part_idx[state["next"]] = idx
+                    idx, state["next"] = state["next"], state["next"] + 1
                 state["feats"][idx, :n] = v[b, :n]
                 state["boxes"][idx, :n] = nbx[b, :n]
                 state["spat"][idx, :n] = spatial_features(nbx[b, :n])
@@ -325,16 +371,50 @@ class Extractor:
         if pending is not None:
             finish(pending)
         feats, boxes, spat = state["feats"], state["boxes"], state["spat"]
+        if part is not None and state.get("idx_mm") is not None:
+            state["idx_mm"][:] = part_idx
+            state["idx_mm"].flush()
+        if stream and feats is not None:
+            for m in (feats, boxes, spat):
+                m.flush()
         out = {"image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
                "max_box_num": np.int32(self.max_roi_num), "vfeat_dim": np.int32(feats.shape[2])}
-        if save_path is not None:
-            if save_path.endswith((".hdf5", ".h5")):
-                from . import hdf5_io
-                hdf5_io.write(save_path, {
-                    "image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
-                    "data_info": {"pretrained_param_path": self.pretrained_param_path.replace("/", "-"),
-                                  "max_box_num": np.array(self.max_roi_num, np.int32),
-                                  "vfeat_dim": np.array(feats.shape[2], np.int32)}})
-            else:
-                np.savez(save_path, **out)
+        if part is not None:
+            out["image_idx"] = part_idx
+        if save_path is not None and not stream:
+            np.savez(save_path, **out)
         return out
+
+    @staticmethod
+    def merge_parts(save_path, world, n_images, remove=True):
+        """Rank 0, after every rank finished its part: the final `<save_path>` in the reference's layout, rows copied from
+        the parts (memmap to memmap, one part at a time).  num_boxes follows the reference: every entry = the count of the
+        FIRST image of the run (:118-121), i.e. of rank 0's first image."""
+        from . import hdf5_io
+        parts = [hdf5_io.File(Extractor.part_path(save_path, r, world)) for r in range(world)]
+        first = parts[0]
+        _, R, D = first["image_features"].shape
+        di = first["data_info"]
+        ppp = di["pretrained_param_path"][()]
+        ppp = ppp.decode() if isinstance(ppp, bytes) else str(ppp)
+        n0 = int(np.asarray(first["first_num_box"].read()))
+        mm = hdf5_io.create(save_path, {
+            "image_features": hdf5_io.Empty((n_images, R, D)), "normal_boxes": hdf5_io.Empty((n_images, R, 4)),
+            "spatial_features": hdf5_io.Empty((n_images, R, 6)), "num_boxes": np.zeros([n_images], np.int32) + n0,
+            "data_info": {"pretrained_param_path": ppp, "max_box_num": np.array(R, np.int32), "vfeat_dim": np.array(D, np.int32)}})
+        for f in parts:
+            idx = np.asarray(f["image_idx"].read())
+            ok = idx >= 0
+            for name in ("image_features", "normal_boxes", "spatial_features"):
+                src = f[name].read()
+                dst = mm["/" + name]
+                for lo in range(0, len(idx), 256):         # bounded host memory per copy
+                    sel = ok[lo:lo + 256]
+                    dst[idx[lo:lo + 256][sel]] = np.asarray(src[lo:lo + 256])[sel]
+        for m in mm.values():
+            m.flush()
+        for r, f in enumerate(parts):
+            f.close()
+            if remove:
+                os.remove(Extractor.part_path(save_path, r, world))
+        return save_path

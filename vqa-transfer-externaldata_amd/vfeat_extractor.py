@@ -69,15 +69,33 @@ def build_parser():
     return parser
 
 
-def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device="cuda:0"):
+def shard_of(n, rank, world):
+    """contiguous shard [lo, hi) of the image list for `rank` (the first n % world ranks get one extra image)"""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device=None, rank=None, world=None, barrier=None):
+    """rank / world (default: RANK / WORLD_SIZE of the environment, i.e. `torchrun -m ...vfeat_extractor`): feature
+    extraction shards BY IMAGE with no collective -- every rank runs the conv stack over its contiguous slice of the
+    image list on its own GPU and writes `<save_path>.part<r>of<w>`; after a barrier rank 0 merges the parts into the
+    reference's single table (the one loop of vqa/vfeat_extractor_tf_record_memft.py:77-147, split N ways)."""
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    if device is None:
+        device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     config.image_info_path = os.path.join(config.tf_record_memft_dir, "image_info.json")
     config.save_path = os.path.join(config.tf_record_memft_dir, config.save_name)
-    check_config(config)
+    if rank == 0:
+        check_config(config)
     log.infov("loading image_info: {}".format(config.image_info_path))
     with open(config.image_info_path) as f:
         image_info = json.load(f)
+    paths = list(image_info["image_path2idx"].keys())
+    lo, hi = shard_of(len(paths), rank, world)
     if dataset is None:
-        dataset = dataset_vfeat.create_dataset(list(image_info["image_path2idx"].keys()), config.image_dir,
+        dataset = dataset_vfeat.create_dataset(paths[lo:hi] if world > 1 else paths, config.image_dir,
                                                config.densecap_dir, is_train=False)
     params = load_params(config.pretrained_param_path, config.model_type, blocks)
     model = get_model_class(config.model_type)(params, blocks, device=device)
@@ -87,7 +105,19 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device="cuda:0"):
                                      pinned=torch.cuda.is_available(), image_dtype=np.uint8)
     ex = vfeat.Extractor(model, image_info["image_id2idx"], dataset.get_config().max_roi_num,
                          config.pretrained_param_path)
-    out = ex.extract(device_batches(batches, device), config.save_path)
+    if world == 1:
+        out = ex.extract(device_batches(batches, device), config.save_path)
+    else:
+        out = ex.extract(device_batches(batches, device), config.save_path, part=(rank, world), n_part_rows=len(dataset))
+        if barrier is None:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo")          # host-side barrier only; the data path has no collective
+            barrier = dist.barrier
+        barrier()
+        if rank == 0:
+            vfeat.Extractor.merge_parts(config.save_path, world, len(image_info["image_id2idx"]))
+        barrier()
     log.warning("vfeat extraction is done: {}".format(config.save_path))
     return out
 
