@@ -668,8 +668,13 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
         {   // full tiles: fixed per-lane offsets, the k advance in the loads' scalar offset
             sa0.init_full(p.lda, m0, kbeg, p.M); sa1.init_full(p.lda, m0, kbeg, p.M);
             sb0.init_full(p.ldb, n0, kbeg, p.N); sb1.init_full(p.ldb, n0, kbeg, p.N);
+#if defined(VQA_DBG_KFREEZE)   // timing experiment only (tools/gru_tune.py, a second build): every k tile re-reads tile 0,
+            // so the loop runs with its operands hot in L1 / L2 -- what is left is the tile loop's own structure
+            const unsigned stepA = 0, stepB = 0;
+#else
             const unsigned stepA = (unsigned)(A_KC ? BK : BK * p.lda) * 4u;
             const unsigned stepB = (unsigned)(B_KC ? BK : BK * p.ldb) * 4u;
+#endif
             const int nfull = (kend - kbeg) / BK;
             unsigned oa = 2 * stepA, ob = 2 * stepB;   // scalar byte offsets of tile t + 2
             // (The SIMD-partner stagger of the one-tile-prefetch loop above was tried here as well -- upper half of the

@@ -64,122 +64,154 @@ class Evaler(object):
             log.info("Loaded the checkpoint")
         log.warning("Evaluation initialization is done")
 
+    # ------------------------------------------------------------------ evaluation pass
+    # Per-sample outputs of the model that go into results.pkl (vqa/evaler.py:129-160), result key -> model.output key
+    _RESULT_FIELDS = (("score", "all_score"), ("max_train_score", "max_train_score"),
+                      ("test_obj_score", "test_obj_score"), ("test_obj_max_score", "test_obj_max_score"),
+                      ("test_attr_score", "test_attr_score"), ("test_attr_max_score", "test_attr_max_score"))
+
+    def _launch(self, batch, slot):
+        """Queue the forward pass of `batch` and the device->host copies of everything the result file needs into the
+        pinned staging buffers of `slot`; returns a handle for _collect.  Nothing here waits for the GPU."""
+        model = self.model
+        model.set_batch(batch)               # (re)build: the constructor ran before the checkpoint was loaded
+        model.build()
+        n = len(batch["id"])
+        stage = self._stage[slot]
+        want = {k: model.output[src] for k, src in self._RESULT_FIELDS}
+        want["pred"] = model.output["pred"]
+        want["report"] = model.engine.tensor("report")[:13]
+        if self.dump_heavy_output:
+            want.update({"heavy/" + k: v for k, v in model.heavy_output.items()})
+        host = {}
+        for k, t in want.items():
+            buf = stage.get(k)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = stage[k] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            buf.copy_(t, non_blocking=True)  # stream-ordered after the forward, before the next batch overwrites the workspace
+            host[k] = buf
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(model.device))
+        return batch, n, host, done
+
+    def _collect(self, handle, acc):
+        """Host side of one batch, run while the GPU works on the next one: whole-batch array operations, no per-sample
+        Python arithmetic.  Fills acc['qid2result'] and the running statistics of avg_eval_report."""
+        batch, n, host, done = handle
+        done.synchronize()
+        col = {k: host[k].numpy().astype(np.float64) for k, _ in self._RESULT_FIELDS}
+        pred_words = self._answers[host["pred"].numpy().astype(np.int64)]
+        tokens = self._words[np.asarray(batch["q_intseq"], dtype=np.int64)]            # [n, T] vocabulary strings
+        lens = np.asarray(batch["q_intseq_len"], dtype=np.int64)
+        questions = [" ".join(row[:m]) for row, m in zip(tokens.tolist(), lens.tolist())]
+        qids = np.asarray(batch["id"]).astype(np.int64).tolist()
+        names = ("image_id", "pred", "question") + tuple(k for k, _ in self._RESULT_FIELDS)
+        columns = [list(batch["image_id"]), pred_words.tolist(), questions] + [col[k].tolist() for k, _ in self._RESULT_FIELDS]
+        records = [dict(zip(names, row)) for row in zip(*columns)]
+        if self.dump_heavy_output:
+            base = acc["n_heavy"]
+            for i, rec in enumerate(records):
+                rec["heavy_output_idx"] = base + i
+            for k in acc["heavy"]:
+                acc["heavy"][k].append(host["heavy/" + k].numpy().copy())
+            acc["n_heavy"] = base + n
+        acc["qid2result"].update(zip(qids, records))
+        # test-only statistics (:162-166): questions none of whose answers is a training answer, and among them the
+        # ones that only have attribute / object test answers
+        unseen = col["max_train_score"] <= 0
+        acc["extra"]["testonly_score"].append(col["score"][unseen])
+        acc["extra"]["test_attr_only_score"].append(col["test_attr_score"][unseen & (col["test_obj_max_score"] <= 0)])
+        acc["extra"]["test_obj_only_score"].append(col["test_obj_score"][unseen & (col["test_attr_max_score"] <= 0)])
+        # the batch's report scalars count once per SAMPLE, as in the reference (:167-168)
+        rep = host["report"].numpy()
+        scalars = self.model.map_report({self._report_keys[i]: float(rep[i]) for i in range(13)})
+        for k, v in scalars.items():
+            acc["report"].setdefault(k, []).append((v, n))
+
     def eval(self):
-        log.infov("Training starts")
-        vocab = self.model.vocab
-        answer_dict = self.model.answer_dict
-        result_dict = {"qid2result": {}}
-        avg_eval_report = {key: [] for key in self.model.report.keys()}
-        avg_eval_report["testonly_score"] = []
-        avg_eval_report["test_attr_only_score"] = []
-        avg_eval_report["test_obj_only_score"] = []
-        heavy_outputs = {key: [] for key in self.model.heavy_output.keys()}
-        heavy_output_idx = 0
-        if self.max_iter < 0:
-            self.max_iter = 50000
-        batch = self._first
-        for s in range(self.max_iter):
-            if batch is None:
-                log.warning("OutOfRangeError happens at {} iter".format(s + 1))
+        log.infov("Evaluation of split {} starts".format(self.split))
+        model = self.model
+        self._words = np.asarray(model.vocab["vocab"], dtype=object)
+        self._answers = np.asarray(model.answer_dict["vocab"], dtype=object)
+        self._report_keys = [model.engine.lib.vqa_report_key(i).decode() for i in range(13)]
+        self._stage = ({}, {})
+        acc = {"qid2result": {}, "report": {k: [] for k in model.report},
+               "extra": {"testonly_score": [], "test_attr_only_score": [], "test_obj_only_score": []},
+               "heavy": {k: [] for k in model.heavy_output}, "n_heavy": 0}
+        limit = self.max_iter if self.max_iter >= 0 else 50000
+        batch, in_flight, it = self._first, None, 0
+        t_start = time.time()
+        while True:
+            handle = None
+            if batch is not None and it < limit:
+                handle = self._launch(batch, it & 1)       # the GPU starts on batch `it` ...
+                it += 1
+            if in_flight is not None:
+                self._collect(in_flight, acc)              # ... while the host writes up batch `it - 1`
+            if handle is None:
+                if batch is None and it < limit:
+                    log.warning("OutOfRangeError happens at {} iter".format(it + 1))
                 break
-            self.model.set_batch(batch)      # (re)build: the constructor ran before the checkpoint was loaded
-            self.model.build()
-            torch.cuda.synchronize(self.model.device)
-            reports = self.model.map_report(self.model.engine.report())
-            outputs = {k: v.detach().cpu().numpy() for k, v in self.model.output.items()
-                       if k not in ("att_score", "logit")}
-            inputs = batch
-            heavy_output = {k: v.detach().cpu().numpy() for k, v in self.model.heavy_output.items()} \
-                if self.dump_heavy_output else None
-
-            batch_size = len(inputs["id"])
-            for b in range(batch_size):
-                q_intseq = inputs["q_intseq"][b]
-                q_intseq_len = inputs["q_intseq_len"][b]
-                question = " ".join([vocab["vocab"][v] for v in q_intseq[:q_intseq_len]])
-                id = int(inputs["id"][b])
-                image_id = inputs["image_id"][b]
-                pred = answer_dict["vocab"][int(outputs["pred"][b])]
-                score = float(outputs["all_score"][b])
-                max_train_score = float(outputs["max_train_score"][b])
-                test_obj_score = float(outputs["test_obj_score"][b])
-                test_obj_max_score = float(outputs["test_obj_max_score"][b])
-                test_attr_score = float(outputs["test_attr_score"][b])
-                test_attr_max_score = float(outputs["test_attr_max_score"][b])
-                result_dict["qid2result"][id] = {
-                    "image_id": image_id, "pred": pred, "question": question, "score": score,
-                    "max_train_score": max_train_score, "test_obj_score": test_obj_score,
-                    "test_obj_max_score": test_obj_max_score, "test_attr_score": test_attr_score,
-                    "test_attr_max_score": test_attr_max_score,
-                }
-                if self.dump_heavy_output:
-                    result_dict["qid2result"][id]["heavy_output_idx"] = heavy_output_idx
-                    for key in heavy_output:
-                        heavy_outputs[key].append(heavy_output[key][b])
-                    heavy_output_idx += 1
-                if max_train_score <= 0:
-                    avg_eval_report["testonly_score"].append(score)
-                    if test_obj_max_score <= 0:
-                        avg_eval_report["test_attr_only_score"].append(test_attr_score)
-                    if test_attr_max_score <= 0:
-                        avg_eval_report["test_obj_only_score"].append(test_obj_score)
-                for key in reports:          # appended once per SAMPLE, as the reference does (:167-168)
-                    avg_eval_report[key].append(reports[key])
+            in_flight = handle
             batch = next(self._iter, None)
+        elapsed = time.time() - t_start
 
-        result_dict["avg_eval_report"] = {
-            key: np.array(avg_eval_report[key], dtype=np.float32).mean() for key in avg_eval_report}
-        for key in avg_eval_report:
-            result_dict["avg_eval_report"]["{}_num_point".format(key)] = len(avg_eval_report[key])
+        series = {k: (np.repeat(np.array([v for v, _ in pairs], np.float32), [m for _, m in pairs])
+                      if pairs else np.zeros([0], np.float32)) for k, pairs in acc["report"].items()}
+        for k, chunks in acc["extra"].items():
+            series[k] = np.concatenate(chunks).astype(np.float32) if chunks else np.zeros([0], np.float32)
+        avg = {k: v.mean() for k, v in series.items()}           # (an empty selection gives nan, as np.mean of [] does)
+        avg.update({"{}_num_point".format(k): len(v) for k, v in series.items()})
+        result_dict = {"qid2result": acc["qid2result"], "avg_eval_report": avg}
+        self.eval_seconds, self.eval_samples = elapsed, len(acc["qid2result"])
         log.info("saving pickle file to: {}".format(self.save_pkl))
         with open(self.save_pkl, "wb") as f:
             pickle.dump(result_dict, f)
         if self.dump_heavy_output:
             from . import hdf5_io
-            hdf5_io.write(self.save_hdf5, {k: np.stack(v, axis=0) for k, v in heavy_outputs.items()})
-        log.info("evaluation is done")
+            hdf5_io.write(self.save_hdf5, {k: np.concatenate(v, axis=0) for k, v in acc["heavy"].items()})
+        log.info("evaluation is done: {} questions in {:.2f} s".format(self.eval_samples, elapsed))
         return result_dict
 
 
-def check_config(config):
-    pass
+_SPLIT_ROOT = "data/preprocessed/vqa_v2"
 
 
 def parse_checkpoint(config):
-    config.ckpt_name = config.checkpoint.split("/")[-1]
-    dirname = config.checkpoint.split("/")[-2]
-    config.model_type = dirname.split("vqa_")[1].split("_d_")[0]
-    qa_split_name = dirname.split("_d_")[1].split("_tf_record_memft")[0]
-    config.tf_record_dir = os.path.join("data/preprocessed/vqa_v2", qa_split_name, "tf_record_memft")
-    if "vfeat_bottomup_36_my" in dirname:
-        config.vfeat_name = "vfeat_bottomup_36_my.hdf5"
-    else:
-        config.vfeat_name = "vfeat_bottomup_36.hdf5"
+    """Everything but the checkpoint file is encoded in the name of its run directory (vqa/evaler.py:195-211),
+    `vqa_<model_type>_d_<qa split>_tf_record_memft_<vfeat name>_...`: model type, tf-record directory, feature file."""
+    run_dir, config.ckpt_name = config.checkpoint.split("/")[-2:]
+    after_prefix = run_dir.split("vqa_")[1]
+    config.model_type, rest = after_prefix.split("_d_")[0], run_dir.split("_d_")[1]
+    config.tf_record_dir = os.path.join(_SPLIT_ROOT, rest.split("_tf_record_memft")[0], "tf_record_memft")
+    config.vfeat_name = "vfeat_bottomup_36%s.hdf5" % ("_my" if "vfeat_bottomup_36_my" in run_dir else "")
     config.vocab_path = os.path.join(config.tf_record_dir, config.vocab_name)
     config.vfeat_path = os.path.join(config.tf_record_dir, config.vfeat_name)
 
 
+# flags and defaults of vqa/evaler.py:214-232 (the contract of the command line)
+_FLAGS = (("--image_dir", dict(type=str, default="data/VQA_v2/images")),
+          ("--vocab_name", dict(type=str, default="vocab.pkl")),
+          ("--max_iter", dict(type=int, default=-1)),
+          ("--split", dict(type=str, default="testval", choices=["train", "val", "testval", "test"])),
+          ("--prefix", dict(type=str, default="default")),
+          ("--checkpoint", dict(type=str, default=None, required=True)),
+          ("--batch_size", dict(type=int, default=512)),
+          ("--debug", dict(type=int, default=0, help="0: normal, 1: debug")),
+          ("--dump_heavy_output", dict(action="store_true", default=False)))
+
+
 def build_parser():
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("--image_dir", type=str, default="data/VQA_v2/images", help=" ")
-    parser.add_argument("--vocab_name", type=str, default="vocab.pkl", help=" ")
-    parser.add_argument("--max_iter", type=int, default=-1, help=" ")
-    parser.add_argument("--split", type=str, default="testval", help=" ",
-                        choices=["train", "val", "testval", "test"])
-    parser.add_argument("--prefix", type=str, default="default", help=" ")
-    parser.add_argument("--checkpoint", type=str, default=None, required=True)
-    parser.add_argument("--batch_size", type=int, default=512, help=" ")
-    parser.add_argument("--debug", type=int, default=0, help="0: normal, 1: debug")
-    parser.add_argument("--dump_heavy_output", action="store_true", default=False, help=" ")
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **dict({"help": " "}, **kw))
     return parser
 
 
 def main(argv=None):
     config = build_parser().parse_args(argv)
-    check_config(config)
     parse_checkpoint(config)
-    evaler = Evaler(config)
-    evaler.eval()
+    Evaler(config).eval()
 
 
 if __name__ == "__main__":

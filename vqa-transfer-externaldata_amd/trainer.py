@@ -204,11 +204,8 @@ class Trainer(object):
             with open(self._summary_path, "a") as f:
                 f.write(json.dumps(summary) + "\n")
 
-    def write_average_summary(self, avg_report, split="train"):
-        s = {"split": "average_" + split, "step": self.global_step}
-        for key in avg_report:
-            s[key] = float(np.array(avg_report[key], dtype=np.float32).mean())
-        return self.global_step, s
+    def write_average_summary(self, window, split="train"):
+        return self.global_step, dict({"split": "average_" + split, "step": self.global_step}, **window.means())
 
     def save_checkpoint(self):
         path = os.path.join(self.train_dir, "model-{}".format(self.global_step))
@@ -219,63 +216,69 @@ class Trainer(object):
             torch.save(sd, path)
         return path
 
+    def _validate(self, split):
+        """val_average_iter inference steps on `split`, their running averages logged and summarised (:208-229)"""
+        window, last = _Window(self.model.report), None
+        for i in range(self.val_average_iter):
+            _, last, _, report, seconds = self.run_val_step(i + 1 == self.val_average_iter, split=split)
+            window.add(report, seconds)
+        self.add_summary(last)
+        step, averaged = self.write_average_summary(window, split=split)
+        self.add_summary(averaged)
+        self.log_message(step, window.report, window.seconds, split=split, is_train=False)
+
     def train(self):
+        """The schedule of vqa/trainer.py:188-263: every train_average_iter steps the running averages are logged and
+        reset, every validation_step steps the validation splits are sampled, heavy summaries every heavy_summary_step,
+        a checkpoint every checkpoint_step (step 0 included)."""
         log.infov("Training starts")
-        avg_step_time = [0]
-        avg_train_report = {key: [0] for key in self.model.report}
+        window = _Window(self.model.report, seed=0)         # the reference's first log line averages a single 0
         for s in range(self.max_train_iter):
-            # write average summary and print log
             if s % self.train_average_iter == 0:
-                step, avg_train_summary = self.write_average_summary(avg_train_report, split="train")
-                self.add_summary(avg_train_summary)
-                self.log_message(step, avg_train_report, avg_step_time, split="train", is_train=True)
-                for key in avg_train_report:
-                    avg_train_report[key] = []
-                avg_step_time = []
-            # periodic inference on the validation splits
+                step, averaged = self.write_average_summary(window, split="train")
+                self.add_summary(averaged)
+                self.log_message(step, window.report, window.seconds, split="train", is_train=True)
+                window = _Window(self.model.report)
             if s % self.validation_step == 0:
                 for split in ("val", "testval"):
-                    if split not in self._iters:
-                        continue
-                    avg_val_report = {key: [] for key in self.model.report}
-                    avg_val_step_time = []
-                    summary = None
-                    for i in range(self.val_average_iter):
-                        step, summary, loss, report, step_time = self.run_val_step(
-                            i == (self.val_average_iter - 1), split=split)
-                        for key in avg_val_report:
-                            avg_val_report[key].append(report[key])
-                        avg_val_step_time.append(step_time)
-                    self.add_summary(summary)
-                    step, avg_val_summary = self.write_average_summary(avg_val_report, split=split)
-                    self.add_summary(avg_val_summary)
-                    self.log_message(step, avg_val_report, avg_val_step_time, split=split, is_train=False)
-            # run TRAINING step
-            step, train_summary, loss, train_report, step_time = self.run_train_step(
-                s % self.heavy_summary_step == 0)
-            for key in avg_train_report:
-                avg_train_report[key].append(train_report[key])
-            avg_step_time.append(step_time)
-            if s % self.heavy_summary_step == 0:
-                self.add_summary(train_summary)
-            # save checkpoint
+                    if split in self._iters:
+                        self._validate(split)
+            heavy = s % self.heavy_summary_step == 0
+            step, summary, _, report, seconds = self.run_train_step(heavy)
+            window.add(report, seconds)
+            if heavy:
+                self.add_summary(summary)
             if s % self.checkpoint_step == 0:
                 log.infov("Saved checkpoint at {}".format(step))
                 self.save_checkpoint()
 
     def log_message(self, step, avg_report, avg_step_time, split="train", is_train=True):
-        step_time = np.array(avg_step_time, dtype=np.float32).mean()
-        if step_time == 0:
-            step_time = 0.001
-        log_str = ""
-        log_str += "[{:5s} step {:4d} ".format(split, step)
-        log_str += "({:.3f} sec/batch, {:.3f} instances/sec)]\n".format(
-            step_time, self.batch_size / step_time)
-        for key in sorted(avg_report.keys()):
-            report = np.array(avg_report[key], dtype=np.float32).mean()
-            log_str += "  * {}: {:.5f}\n".format(key, report)
-        (log.info if is_train else log.infov)(log_str)
-        return log_str
+        """The reference's log block (vqa/trainer.py:302-313), character for character: header with seconds per batch and
+        instances per second, then one `  * key: value` line per report key in sorted order."""
+        mean32 = lambda xs: np.asarray(xs, dtype=np.float32).mean()
+        per_batch = mean32(avg_step_time) or 0.001
+        lines = ["[{:5s} step {:4d} ({:.3f} sec/batch, {:.3f} instances/sec)]".format(
+            split, step, per_batch, self.batch_size / per_batch)]
+        lines += ["  * {}: {:.5f}".format(k, mean32(avg_report[k])) for k in sorted(avg_report)]
+        text = "\n".join(lines) + "\n"
+        (log.info if is_train else log.infov)(text)
+        return text
+
+
+class _Window:
+    """Per-key lists of the report scalars and step times since the last log line."""
+
+    def __init__(self, keys, seed=None):
+        self.report = {k: ([] if seed is None else [seed]) for k in keys}
+        self.seconds = [] if seed is None else [seed]
+
+    def add(self, report, seconds):
+        for k in self.report:
+            self.report[k].append(report[k])
+        self.seconds.append(seconds)
+
+    def means(self):
+        return {k: float(np.asarray(v, dtype=np.float32).mean()) for k, v in self.report.items()}
 
 
 def check_config(config):
