@@ -276,6 +276,14 @@ enum {
 int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, const float* obj_mask,
                  const float* attr_mask, const float* exist_mask, int use_train_mask_in_loss, float inv_batch,
                  float* stats, int32_t* pred, float* dz, int B, int A, void* stream);
+/* The two-headed loss of vqa/model_vlmap_answer_vqa_all2.py:226-339 (z_fixed = WordWeightAnswer logits, z_tuned =
+ * TunedWordWeightAnswer logits): stats[.,LOSS_TRAIN] = sum_a ce(z_fixed)*train_mask + ce(z_tuned), [.,LOSS_REPORT] =
+ * sum_a ce(z_fixed) + ce(z_tuned); pred = first argmax of z_fixed*(1-train_mask) + z_tuned*train_mask; the other
+ * statistics as in vqa_loss_fwd on that prediction; dz_fixed = (sigmoid(z_fixed)-t)*train_mask*inv_batch, dz_tuned =
+ * (sigmoid(z_tuned)-t)*inv_batch (both or neither NULL); z_sum (may be NULL) = z_fixed + z_tuned = output['logit']. */
+int vqa_loss2_fwd(const float* z_fixed, const float* z_tuned, const float* target, const float* train_mask,
+                  const float* obj_mask, const float* attr_mask, const float* exist_mask, float inv_batch, float* stats,
+                  int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int B, int A, void* stream);
 /* n-way softmax cross-entropy with a validity mask + top-1 / top-k hits (n_way_classification_loss,
  * vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:675-706).  z [rows,A], label i32[rows], valid f32[rows];
  * stats [rows,4] = {ce*valid, top1*valid, topk*valid, valid}; dz = (softmax-onehot)*valid*inv_valid_sum[0]
@@ -314,7 +322,9 @@ typedef struct {
     int32_t B, R, D, H, T, W, A, Vq;
     int64_t N_img;
     int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec, 3 = standard_testmask (= 1 with
-                              * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268) */
+                              * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268),
+                              * 4 = vlmap_answer_vqa_all2 (= 0 + the trainable TunedWordWeightAnswer head, summed logits,
+                              * two-term loss, mixed-mask argmax: vqa/model_vlmap_answer_vqa_all2.py:196-244) */
     float keep_att;          /* 0.8  vlmap/modules.py:82 */
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
@@ -342,6 +352,8 @@ typedef struct {
     vqa_fc_t head;                      /* WordWeightAnswer | reasoning/classifier [2H,A]  ([2H,W] for standard_word2vec) */
     float* answer_glove;                /* standard_word2vec only: constant [W,A] GloVe matrix of the answers
                                          * (vqa/model_standard_word2vec.py:185-188); NULL otherwise */
+    vqa_fc_t head2;                     /* vlmap_answer_vqa_all2 only: TunedWordWeightAnswer [2H,A], the trainable second
+                                         * head on `joint` (vqa/model_vlmap_answer_vqa_all2.py:216-220); NULL otherwise */
 } vqa_params_t;
 
 typedef struct {

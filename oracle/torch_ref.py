@@ -86,6 +86,17 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     z = F.linear(j, P[sc["head"] + "/fc/weights"].t(), P[sc["head"] + "/fc/biases"])
     if model_type == "standard_word2vec":
         z = z @ P[sc["glove"]].detach()
+    if model_type == "vlmap_answer_vqa_all2":       # vqa/model_vlmap_answer_vqa_all2.py:216-241, composed independently
+        z2 = F.linear(j, P[sc["head2"] + "/fc/weights"].t(), P[sc["head2"] + "/fc/biases"])
+        train = _t(answer_masks["train"], dtype)
+        per_answer = (F.binary_cross_entropy_with_logits(z, tgt, reduction="none") * train
+                      + F.binary_cross_entropy_with_logits(z2, tgt, reduction="none"))
+        loss = per_answer.sum(-1).mean()
+        mid = {"v_linear_v": v, "condition": h, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
+               "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z + z2, "embed": e,
+               "pred": torch.argmax(z * (1 - train) + z2 * train, dim=-1),
+               "tuned_l_linear_l": _fc_ln_relu(h, P, sc["tuned_q_linear_l"])}
+        return loss, mid
     ell = F.binary_cross_entropy_with_logits(z, tgt, reduction="none")
     if model_type in O.TRAIN_MASKED_LOSS:
         loss = (ell * _t(answer_masks["train"], dtype)).sum(-1).mean()

@@ -50,6 +50,12 @@ OUTPUT_GLOVE = "reasoning/output_glove:const"
 # loss masked by the train-answer mask (:266-268) and an older, shorter report (:295-304)
 STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
 TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask")
+# vqa/model_vlmap_answer_vqa_all2.py: model_vlmap_answer (fixed transferred fusion MLP + WordWeightAnswer head, :128-196)
+# plus a TRAINABLE second head `TunedWordWeightAnswer` on the same `joint` (:216-220); logits are summed (:226-227), the
+# loss is untuned * train_mask + tuned (:240-241) and the prediction takes the tuned logit on training answers and the
+# fixed one on test answers (:243-244).  `tuned_q_linear_l` / `tuned_joint_fc` (:202-214) are built but feed nothing:
+# the tuned head reads `joint`, not `tuned_joint` (:216-217) -- reproduced: variables that never receive a gradient.
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2")
 # report keys of vqa/model_standard_testmask.py:295-304 in terms of the 13 keys of the current models
 TESTMASK_REPORT = {"answer_train_loss": "answer_train_loss", "answer_report_loss": "answer_report_loss",
                    "answer_accuracy": "answer_acc", "exist_answer_accuracy": "exist_acc",
@@ -83,7 +89,7 @@ def scope_names(model_type: str) -> dict:
     latter nests the fusion MLP under 'reasoning/' and uses a plain
     'classifier' fc_layer as head).
     """
-    if model_type == "vlmap_answer":
+    if model_type in VLMAP_FAMILY:
         pre = ""
         head = "WordWeightAnswer"
     elif model_type in STANDARD_FAMILY:
@@ -105,6 +111,8 @@ def scope_names(model_type: str) -> dict:
         "q_linear_l": pre + "q_linear_l",
         "joint_fc": pre + "joint_fc",
         "head": head,
+        # vlmap_answer_vqa_all2 only
+        "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc",
     }
 
 
@@ -162,6 +170,10 @@ def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=
     fc(sc["pooled_linear_l"], D, H, True)
     fc(sc["q_linear_l"], H, H, True)
     fc(sc["joint_fc"], H, 2 * H, True)
+    if model_type == "vlmap_answer_vqa_all2":
+        fc(sc["tuned_q_linear_l"], H, H, True)
+        fc(sc["tuned_joint_fc"], H, 2 * H, True)
+        fc(sc["head2"], 2 * H, A, False)                    # fc_layer(joint, num_answer, use_bias=True), Xavier / zero
     if model_type == "standard_word2vec":
         fc(sc["head"], 2 * H, W, False)                     # 'classifier' FC to the 300-d word space
         p[sc["glove"]] = (0.3 * rng.standard_normal((W, A))).astype(dtype)   # stands in for the answers' GloVe vectors
@@ -334,6 +346,22 @@ def loss_and_report(z, tgt, answer_masks, model_type):
     return train_loss, report, out, ell
 
 
+def loss_and_report_all2(z1, z2, tgt, answer_masks):
+    """vqa/model_vlmap_answer_vqa_all2.py:232-339: z1 = fixed WordWeightAnswer logits, z2 = TunedWordWeightAnswer logits.
+    train loss = mean_B sum_A (ce(z1) * train_mask + ce(z2)); report loss = mean_B sum_A (ce(z1) + ce(z2));
+    pred = argmax(z1 * test_mask + z2 * train_mask); everything downstream of pred as in model_vlmap_answer."""
+    dt = z1.dtype.type
+    train = answer_masks["train"]
+    test = dt(1) - train
+    ell1, ell2 = sigmoid_ce(z1, tgt), sigmoid_ce(z2, tgt)
+    mixed = z1 * test + z2 * train
+    _, report, out, _ = loss_and_report(mixed, tgt, answer_masks, "standard")     # pred and the 11 accuracy scalars
+    train_loss = (ell1 * train + ell2).sum(axis=1).mean()
+    report["answer_train_loss"] = train_loss
+    report["answer_report_loss"] = (ell1 + ell2).sum(axis=1).mean()
+    return train_loss, report, out
+
+
 # ----------------------------------------------------------------------------
 # full forward (SURVEY.md 3.5)
 # ----------------------------------------------------------------------------
@@ -370,15 +398,30 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
     if model_type == "standard_word2vec":                   # logit = joint2 x output_glove
         j2 = z
         z = j2 @ params[sc["glove"]]
-    loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)  # a11
+    z1 = z2 = None
+    extra_mid = {}
+    if model_type == "vlmap_answer_vqa_all2":
+        z1 = z
+        z2 = fc_forward(j, params[sc["head2"] + "/fc/weights"], params[sc["head2"] + "/fc/biases"])   # reads `joint` (:216-217)
+        loss, report, out = loss_and_report_all2(z1, z2, batch["answer_target"], answer_masks)
+        z = z1 + z2                                                                    # output['logit'] (:226-227)
+        # the dead branch (:202-214), for mid_result only: needs its own dropout mask when asked for
+        tll, _ = fc_ln_relu_forward(h, params, sc["tuned_q_linear_l"])
+        extra_mid.update(tuned_l_linear_l=tll, logit_fixed=z1, logit_tuned=z2)
+        if "tuned_joint" in masks:
+            tj0, _ = fc_ln_relu_forward(pl * tll, params, sc["tuned_joint_fc"])
+            extra_mid["tuned_joint"] = tj0 * masks["tuned_joint"] * dt(1.0 / KEEP_JOINT)
+    else:
+        loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)  # a11
     out["att_score"] = att
     out["logit"] = z
     mid = {"num_V_ft": nb, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
            "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z,
            "pred": out["pred"], "v_linear_v": v, "condition": h, "V_ft": V}
+    mid.update(extra_mid)
     tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att,
                 feat=feat, p=p, pl=pl, t_pl=t_pl, ll=ll, t_ll=t_ll, jin=jin, j0=j0, t_j=t_j,
-                j=j, z=z, j2=j2)
+                j=j, z=z, j2=j2, z1=z1, z2=z2)
     return loss, report, out, mid, tape
 
 
@@ -417,8 +460,10 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     z = tape["z"]
     B = z.shape[0]
     tgt = batch["answer_target"]
+    if model_type == "vlmap_answer_vqa_all2":
+        z = tape["z1"]
     dz = (sigmoid(z) - tgt) / dt(B)
-    if model_type in TRAIN_MASKED_LOSS:
+    if model_type in TRAIN_MASKED_LOSS or model_type == "vlmap_answer_vqa_all2":
         dz = dz * answer_masks["train"]
     Wh = params[sc["head"] + "/fc/weights"]
     if model_type == "standard_word2vec":
@@ -426,6 +471,14 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     g[sc["head"] + "/fc/weights"] = tape["j"].T @ dz
     g[sc["head"] + "/fc/biases"] = dz.sum(axis=0)
     dj = dz @ Wh.T
+    if model_type == "vlmap_answer_vqa_all2":
+        dz2 = (sigmoid(tape["z2"]) - tgt) / dt(B)               # the tuned term of the loss is not masked (:240-241)
+        g[sc["head2"] + "/fc/weights"] = tape["j"].T @ dz2
+        g[sc["head2"] + "/fc/biases"] = dz2.sum(axis=0)
+        dj = dj + dz2 @ params[sc["head2"] + "/fc/weights"].T
+        for scope in (sc["tuned_q_linear_l"], sc["tuned_joint_fc"]):   # no path to the loss: TF hands back None
+            for v in ("/fc/weights", "/fc/biases", "/LayerNorm/beta", "/LayerNorm/gamma"):
+                g[scope + v] = np.zeros_like(params[scope + v])
     dj0 = dj * masks["joint"] * dt(1.0 / KEEP_JOINT)
     djin = _fc_ln_relu_backward(dj0, tape["t_j"], params, sc["joint_fc"], g)
     dpl = djin * tape["ll"]

@@ -46,6 +46,8 @@ def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
                                                        "test_attr_score", "test_obj_max_score", "test_attr_max_score")})
     z.update({"grad/" + k: v.astype(np.float32) for k, v in grads.items()})
     z["dx_embed"] = dx.astype(np.float32)
+    if model_type == "vlmap_answer_vqa_all2":
+        z["mid/logit_fixed"], z["mid/logit_tuned"] = np.asarray(tape["z1"]), np.asarray(tape["z2"])
     return z
 
 
@@ -94,6 +96,7 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "fusion_vlmap_answer_b8.npz"), **fusion_case("vlmap_answer", 101))
     np.savez_compressed(os.path.join(HERE, "fusion_standard_b8.npz"), **fusion_case("standard", 102))
     np.savez_compressed(os.path.join(HERE, "fusion_standard_word2vec_b4.npz"), **fusion_case("standard_word2vec", 103, B=4))
+    np.savez_compressed(os.path.join(HERE, "fusion_vlmap_answer_vqa_all2_b8.npz"), **fusion_case("vlmap_answer_vqa_all2", 104))
     np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy.npz"), **pretrain_case())
     np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy_persite.npz"), **pretrain_case(ln_shared=False))
     np.savez_compressed(os.path.join(HERE, "vfeat_resnet_narrow.npz"), **conv_case())

@@ -9,7 +9,8 @@ from oracle import conv_oracle as CO
 from oracle import vqa_oracle as O
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FUSION = ["fusion_vlmap_answer_b8.npz", "fusion_standard_b8.npz", "fusion_standard_word2vec_b4.npz"]
+FUSION = ["fusion_vlmap_answer_b8.npz", "fusion_standard_b8.npz", "fusion_standard_word2vec_b4.npz",
+          "fusion_vlmap_answer_vqa_all2_b8.npz"]
 # one LayerNorm per shared fc_layer scope (TF 1.x; default) / one per call site: the parameter names say which
 PRETRAIN = ["pretrain_cfg5_toy.npz", "pretrain_cfg5_toy_persite.npz"]
 

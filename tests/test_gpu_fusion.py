@@ -36,7 +36,8 @@ def grad_close(got, want, name, tol=5e-4):
     assert err <= tol * sc + 1e-9, "%s: max err %.3e vs scale %.3e" % (name, err, sc)
 
 
-@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask"])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
+                                        "vlmap_answer_vqa_all2"])
 @pytest.mark.parametrize("cfg", [("small", SMALL, 5, 6, 7, 9), ("med", MED, 32, 36, 14, 64),
                                  ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
 def test_forward_backward_match_oracle(model_type, cfg):
@@ -68,6 +69,44 @@ def test_forward_backward_match_oracle(model_type, cfg):
     grad_close(eng.tensor("dx_embed").view(T, B, dims["W"]).transpose(0, 1), dx, "dx_embed")
     sq = float(eng.grad_flat[eng.n_train])
     assert abs(sq - (dx ** 2).sum()) <= 1e-3 * (dx ** 2).sum() + 1e-12
+
+
+def test_vqa_all2_two_heads_and_dead_branch():
+    """model_type 4 (vqa/model_vlmap_answer_vqa_all2.py:196-244): both heads' logits, their sum, the mixed-mask argmax on
+    a case where the two heads disagree, the frozen set, zero gradients on the tuned layers that feed nothing, two train
+    steps against the oracle, and the dead branch's mid results on request."""
+    mt, dims, B, R, T, N = "vlmap_answer_vqa_all2", MED, 24, 36, 14, 32
+    p, table, nbox, batch, am, masks = make_case(61, mt, B, R, T, N, dims)
+    eng = make_engine(mt, p, table, nbox, am, B, R, T, dims)
+    assert eng.frozen_names == sorted(n for n in p if n.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer"))
+    assert "TunedWordWeightAnswer/fc/weights" in eng.train_names and "tuned_joint_fc/fc/weights" in eng.train_names
+    run_engine(eng, batch, masks)
+    loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am), to64(masks), mt)
+    z1 = eng.tensor("logit_fixed").view(B, -1).cpu().numpy()
+    z2 = eng.tensor("logit_tuned").view(B, -1).cpu().numpy()
+    assert np.abs(z1 - tape["z1"]).max() < 1e-3 and np.abs(z2 - tape["z2"]).max() < 1e-3
+    np.testing.assert_array_equal(eng.tensor("logit").view(B, -1).cpu().numpy(), z1 + z2)       # output['logit'] (:226-227)
+    pred = eng.tensor("pred").cpu().numpy()
+    np.testing.assert_array_equal(pred, out["pred"])
+    train = am["train"]
+    np.testing.assert_array_equal(pred, np.argmax(z1 * (1 - train) + z2 * train, axis=1))
+    assert (pred != np.argmax(z1 + z2, axis=1)).any()               # the mixed-mask rule is not the argmax of the sum
+    for n in eng.train_names:
+        if n.startswith(("tuned_q_linear_l/", "tuned_joint_fc/")):
+            assert not eng.grads[n].any(), n                        # no path to the loss (:216-217 reads `joint`)
+    before = {n: eng.params[n].clone() for n in eng.params if n.startswith(("tuned_q_linear_l/", "tuned_joint_fc/", "joint_fc/"))}
+    st = O.new_opt_state()
+    pp = {k: v.copy() for k, v in p.items()}
+    for it in range(2):
+        run_engine(eng, batch, masks, lr=1e-3)
+        loss, report, out, mid, grads, norm = O.train_step(pp, batch, table, nbox, am, masks, st, 1e-3, mt)
+        assert abs(float(eng.norm_sq[0]) ** 0.5 - norm) <= 1e-3 * norm
+        assert abs(eng.report()["answer_train_loss"] - loss) <= 2e-4 * max(1, abs(loss))
+    for n, v in before.items():
+        assert torch.equal(eng.params[n], v), n                      # frozen, or trainable with a zero gradient: unchanged
+    got = eng.params["TunedWordWeightAnswer/fc/weights"].cpu().numpy()
+    assert np.abs(got - p["TunedWordWeightAnswer/fc/weights"]).max() > 1e-4
+    assert np.mean(np.abs(got - pp["TunedWordWeightAnswer/fc/weights"]) > 1e-4) < 0.02
 
 
 def test_train_steps_match_oracle_f32():

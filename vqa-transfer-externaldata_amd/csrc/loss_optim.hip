@@ -21,13 +21,19 @@ __device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ z, const float* __restrict__ tgt,
+// TWO: the two-headed form of vqa/model_vlmap_answer_vqa_all2.py:226-244 -- z = fixed head, z2 = tuned head:
+// loss = ce(z) * train_mask + ce(z2), report loss = ce(z) + ce(z2), pred = argmax(z * test_mask + z2 * train_mask),
+// dz = d ce(z) * train_mask, dz2 = d ce(z2) (unmasked), zsum = z + z2 (output['logit'])
+template <bool TWO>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ z, const float* __restrict__ z2,
+                                                       const float* __restrict__ tgt,
                                                        const float* __restrict__ train_m,
                                                        const float* __restrict__ obj_m,
                                                        const float* __restrict__ attr_m,
                                                        const float* __restrict__ exist_m, int use_train_mask,
                                                        float inv_batch, float* __restrict__ stats,
-                                                       int32_t* __restrict__ pred, float* __restrict__ dz, int A) {
+                                                       int32_t* __restrict__ pred, float* __restrict__ dz,
+                                                       float* __restrict__ dz2, float* __restrict__ zsum, int A) {
     __shared__ float redv[4];
     __shared__ int redi[4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -40,15 +46,26 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
           mx_test = -INFINITY, mx_test_exist = -INFINITY, mx_train = -INFINITY;
     ArgMax am{-INFINITY, 0x7fffffff};
     for (int a = threadIdx.x; a < A; a += 256) {
-        const float x = zb[a], t = tb[a];
+        float x = zb[a];
+        const float t = tb[a];
         const float tr = train_m[a], te = 1.f - tr, ob = obj_m[a], at = attr_m[a], ex = exist_m[a];
         const float ell = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-        l_all += ell;
-        l_train += ell * tr;
         if (dz != nullptr) {
             float g = (sigmoidf_stable(x) - t) * inv_batch;
-            if (use_train_mask) g *= tr;
+            if (use_train_mask || TWO) g *= tr;
             dz[(int64_t)b * A + a] = g;
+        }
+        if (TWO) {
+            const float y = z2[(int64_t)b * A + a];
+            const float ell2 = fmaxf(y, 0.f) - y * t + log1pf(expf(-fabsf(y)));
+            l_all += ell + ell2;
+            l_train += ell * tr + ell2;
+            if (dz2 != nullptr) dz2[(int64_t)b * A + a] = (sigmoidf_stable(y) - t) * inv_batch;
+            if (zsum != nullptr) zsum[(int64_t)b * A + a] = x + y;
+            x = x * te + y * tr;               // the logit the prediction is taken from (:243-244)
+        } else {
+            l_all += ell;
+            l_train += ell * tr;
         }
         if (x > am.v) { am.v = x; am.i = a; }  // strided ascending a per thread: first max kept
         mx_exist = fmaxf(mx_exist, t * ex);
@@ -92,7 +109,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
         const float tp = tb[p];
         const float tr = train_m[p], te = 1.f - tr, ob = obj_m[p], at = attr_m[p], ex = exist_m[p];
         float* s = stats + (int64_t)b * VQA_STAT_COUNT;
-        s[VQA_STAT_LOSS_TRAIN] = use_train_mask ? l_train : l_all;
+        s[VQA_STAT_LOSS_TRAIN] = (use_train_mask || TWO) ? l_train : l_all;
         s[VQA_STAT_LOSS_REPORT] = l_all;
         s[VQA_STAT_ALL_SCORE] = tp;
         s[VQA_STAT_EXIST_SCORE] = tp * ex;
@@ -360,8 +377,23 @@ extern "C" int vqa_loss_fwd(const float* z, const float* target, const float* tr
     VQA_REQUIRE(z && target && train_mask && obj_mask && attr_mask && exist_mask && stats && pred, VQA_ERR_ARG);
     VQA_REQUIRE(B >= 0 && A > 0, VQA_ERR_ARG);
     if (B == 0) return VQA_OK;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z, target, train_mask, obj_mask,
-                       attr_mask, exist_mask, use_train_mask_in_loss, inv_batch, stats, pred, dz, A);
+    hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, z, (const float*)nullptr, target,
+                       train_mask, obj_mask, attr_mask, exist_mask, use_train_mask_in_loss, inv_batch, stats, pred, dz,
+                       (float*)nullptr, (float*)nullptr, A);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_loss2_fwd(const float* z_fixed, const float* z_tuned, const float* target, const float* train_mask,
+                             const float* obj_mask, const float* attr_mask, const float* exist_mask, float inv_batch,
+                             float* stats, int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int B, int A,
+                             void* stream) {
+    VQA_REQUIRE(z_fixed && z_tuned && target && train_mask && obj_mask && attr_mask && exist_mask && stats && pred,
+                VQA_ERR_ARG);
+    VQA_REQUIRE(B >= 0 && A > 0 && (dz_fixed == nullptr) == (dz_tuned == nullptr), VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, z_fixed, z_tuned, target,
+                       train_mask, obj_mask, attr_mask, exist_mask, 1, inv_batch, stats, pred, dz_fixed, dz_tuned, z_sum, A);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

@@ -38,12 +38,14 @@ _INT_TENSORS = {"num_V_ft", "pred"}
 # model_standard and its variants: one architecture, every variable trainable (vqa/model_standard.py:80-84,
 # vqa/model_standard_word2vec.py, vqa/model_standard_testmask.py:64-68)
 STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
+# model_vlmap_answer and its variant with a second, trainable head on the fixed joint (vqa/model_vlmap_answer_vqa_all2.py)
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2")
 
 
 def scope_names(model_type):
     """logical layer -> TF variable scope (vqa/model_vlmap_answer.py:126-185,
     vqa/model_standard.py:223-275)."""
-    if model_type == "vlmap_answer":
+    if model_type in VLMAP_FAMILY:
         pre, head = "", "WordWeightAnswer"
     elif model_type in STANDARD_FAMILY:
         pre, head = "reasoning/", "reasoning/classifier"
@@ -53,7 +55,9 @@ def scope_names(model_type):
             "gru_gates": "encode_L/rnn/gru_cell/gates", "gru_cand": "encode_L/rnn/gru_cell/candidate",
             "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
             "pooled_linear_l": pre + "pooled_linear_l", "q_linear_l": pre + "q_linear_l",
-            "joint_fc": pre + "joint_fc", "head": head}
+            "joint_fc": pre + "joint_fc", "head": head,
+            # vlmap_answer_vqa_all2 only (:202-220): the tuned head and the two tuned layers that feed nothing
+            "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc"}
 
 
 def variable_shapes(model_type, Vq, W, D, H, A):
@@ -80,6 +84,10 @@ def variable_shapes(model_type, Vq, W, D, H, A):
     fc(sc["joint_fc"], H, 2 * H, True)
     # standard_word2vec: the classifier maps into the 300-d word space (vqa/model_standard_word2vec.py:180-183)
     fc(sc["head"], 2 * H, W if model_type == "standard_word2vec" else A, False)
+    if model_type == "vlmap_answer_vqa_all2":
+        fc(sc["tuned_q_linear_l"], H, H, True)
+        fc(sc["tuned_joint_fc"], H, 2 * H, True)
+        fc(sc["head2"], 2 * H, A, False)
     return s
 
 
@@ -102,7 +110,8 @@ def _pad4(n):
 
 
 class FusionEngine:
-    MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3}
+    MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
+                     "vlmap_answer_vqa_all2": 4}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
@@ -245,7 +254,8 @@ class FusionEngine:
             q_linear_v=fc(sc["q_linear_v"], True), score=fc(sc["score"], False),
             pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
             joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False),
-            answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None)
+            answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None,
+            head2=fc(sc["head2"], False) if self.model_type == "vlmap_answer_vqa_all2" else _lib.Fc())
 
     def resize(self, B, T, global_batch=None):
         """Re-target the engine to another batch size / padded question length (the reference pads

@@ -133,7 +133,8 @@ class Model(object):
                                         V_DIM, bool(getattr(self.config, "ln_shared", 1)))
             self._engine = PT.PretrainEngine(n=cfg.n_obj_bf, R=cfg.max_box_num, D=cfg.vfeat_dim, H=V_DIM, W=W_DIM,
                                              A=self.num_answer, Vq=len(self.vocab["vocab"]), n_ws=self.num_ws,
-                                             params=self._initial_params(shapes), device=self.device)
+                                             params=self._initial_params(shapes), device=self.device,
+                                             deterministic=bool(getattr(self.config, "deterministic", 0)))
         eng = self._engine
         B = int((db["image_ft"] if "image_ft" in db else db["image_idx"]).shape[0])
         tables = getattr(self.config, "feature_tables", None)
