@@ -1,0 +1,107 @@
+"""Host-only exercise of libvqahot's dispatch layer: every path that runs BEFORE a kernel launch -- argument validation,
+workspace layouts, named-tensor lookups, report keys, probe bookkeeping.  No GPU is touched.  Run directly, or by
+tests/test_sanitizers.py against the ASan + UBSan build (csrc/build.py --sanitize) with the ASan runtime preloaded:
+
+    python tests/host_abi_exercise.py [path/to/libvqahot(.so | _asan.so)]
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vqa_transfer_externaldata_amd import _lib  # noqa: E402
+
+if len(sys.argv) > 1:
+    _lib._LIB_PATH = os.path.abspath(sys.argv[1])
+lib = _lib.load()
+checks = 0
+
+
+def ok(cond, what):
+    global checks
+    checks += 1
+    if not cond:
+        raise SystemExit("host ABI exercise failed: " + what)
+
+
+ok(lib.vqa_hot_version() == _lib.ABI_VERSION, "version")
+ok(lib.vqa_hot_error_string(0) == b"ok" and lib.vqa_hot_error_string(-99) is not None, "error strings")
+ok([lib.vqa_report_key(i) is not None for i in range(-2, 16)] == [False] * 2 + [True] * 13 + [False] * 3, "report keys")
+ok([lib.vqa_pretrain_report_key(i) is not None for i in range(-1, 15)] == [False] + [True] * 13 + [False] * 2, "pretrain keys")
+
+# fusion model: workspace + every named tensor, for all five model types and a sweep of sizes (ragged, tiny, full)
+off, n = C.c_int64(), C.c_int64()
+names = [b"V_ft", b"num_V_ft", b"v_linear_v", b"condition", b"q_linear_v", b"att_score", b"pooled_V_ft", b"pooled_linear_l",
+         b"l_linear_l", b"joint", b"logit", b"pred", b"stats", b"report", b"dlogit", b"dx_embed", b"hs", b"xp", b"x_tm"]
+for mt in range(5):
+    for (B, R, D, H, T, W, A, Vq, N) in ((1, 1, 4, 4, 1, 1, 1, 1, 1), (5, 6, 24, 16, 7, 12, 21, 30, 9),
+                                         (7, 36, 64, 32, 3, 300, 50, 60, 16), (512, 36, 2048, 1024, 14, 300, 3000, 16384, 8192)):
+        d = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N, model_type=mt, keep_att=0.8, keep_joint=0.5,
+                      inv_global_batch=1.0 / B)
+        total = lib.vqa_fusion_workspace_bytes(C.byref(d))
+        ok(total > 0, "workspace bytes %r" % ((mt, B),))
+        for nm in names + ([b"logit_fixed", b"logit_tuned", b"dlogit_tuned"] if mt == 4 else []):
+            ok(lib.vqa_fusion_tensor(C.byref(d), nm, C.byref(off), C.byref(n)) == 0, "tensor %s" % nm)
+            ok(off.value % 16 == 0 and 0 <= off.value and off.value + 4 * n.value <= total, "tensor %s inside the workspace" % nm)
+        ok(lib.vqa_fusion_tensor(C.byref(d), b"logit_tuned", C.byref(off), C.byref(n)) == (0 if mt == 4 else -1), "variant tensor")
+        ok(lib.vqa_fusion_tensor(C.byref(d), b"", C.byref(off), C.byref(n)) == -1, "empty name")
+        ok(lib.vqa_fusion_tensor(C.byref(d), b"x" * 300, None, None) == -1, "long unknown name")
+for bad in (dict(B=0), dict(R=0), dict(model_type=5), dict(model_type=-1), dict(H=-4), dict(N_img=0)):
+    kw = dict(B=4, R=4, D=8, H=8, T=2, W=4, A=4, Vq=4, N_img=4, model_type=0)
+    kw.update(bad)
+    ok(lib.vqa_fusion_workspace_bytes(C.byref(_lib.Dims(**kw))) < 0, "bad dims %r" % (bad,))
+ok(lib.vqa_fusion_workspace_bytes(None) < 0 and lib.vqa_fusion_tensor(None, b"logit", None, None) < 0, "null dims")
+
+# entry points with null / undersized arguments: rejected before any launch
+d = _lib.Dims(B=4, R=4, D=8, H=8, T=2, W=4, A=4, Vq=4, N_img=4, model_type=0, keep_att=0.8, keep_joint=0.5, inv_global_batch=0.25)
+ok(lib.vqa_fusion_forward(C.byref(d), None, None, None, 0, 1, None) == -1, "forward null")
+p, b = _lib.Params(), _lib.Batch()
+ok(lib.vqa_fusion_forward(C.byref(d), C.byref(p), C.byref(b), C.c_void_p(4096), 16, 1, None) == -5, "forward small workspace")
+ok(lib.vqa_fusion_backward_phases(C.byref(d), C.byref(p), C.byref(p), C.byref(b), None, 0, None, 15, None) == -1, "backward null")
+ok(lib.vqa_gemm_f32(1, 1, 4, 4, 4, 16, 4, 16, 4, 16, 4, None, None, 0, 0, None, 0, None) == -4, "gemm TT")
+ok(lib.vqa_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, 0, None, 0, None) == -1, "gemm null")
+ok(lib.vqa_ln_relu_fwd(None, None, None, None, 1.0, None, None, None, 1, 1, 4, None) == -1, "ln null")
+ok(lib.vqa_loss2_fwd(None, None, None, None, None, None, None, 1.0, None, None, None, None, None, 1, 4, None) == -1, "loss2 null")
+for M, N, K in ((1, 1, 1), (512, 3000, 2048), (18432, 1024, 2048), (7168, 300, 3072), (10240, 4000, 2048)):
+    for tA, tB in ((0, 0), (0, 1), (1, 0)):
+        for sk in (0, 1, 3, 8):
+            ok(lib.vqa_gemm_workspace_floats(tA, tB, M, N, K, sk) >= 0, "gemm workspace")
+ok(lib.vqa_colsum_workspace_floats(1, 1) >= 0 and lib.vqa_colsum_workspace_floats(25600, 2048) > 0, "colsum workspace")
+ok(lib.vqa_sumsq_workspace_floats(0) >= 0 and lib.vqa_sumsq_workspace_floats(1 << 30) > 0, "sumsq workspace")
+
+# cfg-5 model: layouts for both LayerNorm modes, ragged sizes
+pnames = [b"report", b"S/z", b"S/dz", b"S/pooled", b"J/hs", b"J/xp", b"dxp", b"wx_cat"] + \
+    [("%s/%s" % (k, t)).encode() for k in ("obj", "attr") for t in ("att", "pooled", "v", "qv", "valid", "bf/z", "ws/z", "bf/j", "ws/ll", "bf/vl")]
+for flags in (0, 4, 5):
+    for (B, n_, R, D, H, W, A, Vq, nws, L) in ((1, 1, 1, 4, 4, 1, 1, 1, 1, 1), (3, 5, 6, 16, 8, 12, 12, 20, 7, 4),
+                                               (512, 5, 36, 2048, 1024, 300, 4000, 5000, 2000, 10)):
+        pd = _lib.PtDims(B=B, n=n_, R=R, D=D, H=H, W=W, A=A, Vq=Vq, n_ws=nws, L=L, flags=flags, keep_att=0.8, keep_joint=0.5)
+        total = lib.vqa_pretrain_workspace_bytes(C.byref(pd))
+        ok(total > 0, "pretrain workspace")
+        for nm in pnames:
+            ok(lib.vqa_pretrain_tensor(C.byref(pd), nm, C.byref(off), C.byref(n)) == 0, "pretrain tensor %s" % nm)
+            ok(off.value + 4 * n.value <= total and off.value >= 0, "pretrain tensor %s inside" % nm)
+        ok(lib.vqa_pretrain_tensor(C.byref(pd), b"nope", C.byref(off), C.byref(n)) == -1, "pretrain unknown")
+ok(lib.vqa_pretrain_workspace_bytes(C.byref(_lib.PtDims(B=1, n=9, R=1, D=4, H=4, W=1, A=1, Vq=1, n_ws=1, L=1))) < 0, "n > 8")
+ok(lib.vqa_pretrain_forward(None, None, None, None, 0, 1, None) == -1, "pretrain forward null")
+pd = _lib.PtDims(B=2, n=5, R=6, D=16, H=8, W=12, A=12, Vq=20, n_ws=7, L=4, keep_att=0.8, keep_joint=0.5)
+ok(lib.vqa_pretrain_backward_phases(C.byref(pd), C.byref(_lib.PtParams()), C.byref(_lib.PtParams()), C.byref(_lib.PtBatch()),
+                                    C.c_void_p(4096), 1 << 40, None, 0, None) == -1, "phases = 0")
+ok(lib.vqa_pretrain_backward_phases(C.byref(pd), C.byref(_lib.PtParams()), C.byref(_lib.PtParams()), C.byref(_lib.PtBatch()),
+                                    C.c_void_p(4096), 1 << 40, None, 16, None) == -1, "phases = 16")
+
+# probe bookkeeping (no scope runs without a launch: labels only)
+ok(lib.vqa_probe_enable(None, 4) == -1 and lib.vqa_probe_enable(b"", 4) == -1 and lib.vqa_probe_enable(b"a", 0) == -1, "probe args")
+ok(lib.vqa_probe_enable(b"gru.fwd,,gru.bwd,gru.fwd,*", 3) in (0, -3), "probe enable (events need a device: -3 without one)")
+buf = C.create_string_buffer(8)
+need = lib.vqa_probe_labels(buf, 8)
+ok(need >= 1 and len(buf.value) <= 7, "probe labels truncated safely")
+ms, cnt = (C.c_float * 4)(), C.c_int()
+ok(lib.vqa_probe_read_label(b"not.there", ms, 4, C.byref(cnt)) == 0 and cnt.value == 0, "probe read unknown label")
+ok(lib.vqa_probe_read(ms, 4, C.byref(cnt)) == 0 and cnt.value == 0, "probe read first label")
+ok(lib.vqa_probe_read(None, 4, C.byref(cnt)) == -1, "probe read null")
+ok(lib.vqa_probe_disable() == 0 and lib.vqa_probe_disable() == 0, "probe disable twice")
+ok(lib.vqa_roctx_enable(0) == 0, "roctx off")
+
+print("host ABI exercise: %d checks passed on %s" % (checks, _lib.lib_path()))
