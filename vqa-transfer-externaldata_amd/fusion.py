@@ -137,7 +137,10 @@ class FusionEngine:
         names = sorted(self.shapes)
         embed = self.sc["embed"]
         train = filter_train_vars(names, model_type)
-        self.train_names = [embed] + [n for n in train if n != embed]
+        # flat order = the order backward completes the gradients (vqa_fusion_backward_phases):
+        # [embedding | GRU candidate/* | GRU gates/* | everything else by name]
+        gru_first = sorted((n for n in train if n.startswith("encode_L/")), key=lambda n: ("/candidate/" not in n, n))
+        self.train_names = [embed] + gru_first + [n for n in train if n != embed and not n.startswith("encode_L/")]
         self.frozen_names = [n for n in names if n not in train]
 
         def carve(name_list):
