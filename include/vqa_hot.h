@@ -216,7 +216,9 @@ int vqa_gru_zero_finished(float* dxp, const int32_t* len, int T, int B, int H, v
  * and hides behind the other chain's matrix work.  Same tensors as vqa_gru_seq_fwd plus `sync`, a device scratch of
  * vqa_gru_persistent_sync_bytes() that the call zeroes itself; after the stream has run, a non-zero 32-bit word at
  * byte offset 128 of `sync` reports a barrier time-out (results invalid).  VQA_ERR_UNSUPPORTED when the shape or the
- * device does not qualify (vqa_gru_fwd_persistent_supported: H % 64 == 0, B >= 64, every workgroup co-resident). */
+ * device does not qualify (vqa_gru_fwd_persistent_supported: H % 512 == 0, B >= 64, and -- asked per device, for the
+ * variant and LDS size that would be launched -- every workgroup of the grid co-resident).  An opt-in experiment
+ * (DESIGN section 4): no model path uses it; a caller must check the error word after synchronising. */
 int vqa_gru_seq_fwd_persistent(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
                                float* r, float* u, float* c, float* rh, int T, int B, int H, unsigned* sync,
                                void* stream);

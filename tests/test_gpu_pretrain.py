@@ -313,3 +313,36 @@ def test_trainer_step_with_prefetched_batch_and_deferred_report_equals_the_plain
     ta.run_val_step(False)
     assert ta._prepared is not None
     ta.run_train_step(False)
+
+
+def test_two_prepared_batches_in_flight_without_a_device_sync():
+    """Model.prepare twice in a row (side-stream uploads, no synchronisation in between), then both batches built on the
+    compute stream: each gives the report of a plain build of the same batch (the prepared tensors are recorded on the
+    compute stream, so the caching allocator cannot recycle the first batch's blocks for the second)."""
+    import tempfile
+    from vqa_transfer_externaldata_amd import dataset_vlmap as DV, pretrain_trainer as PTT
+    R, D, L, Vq, n_ws, A, B = 36, 64, 6, 40, 12, 30, 8
+    data = DV.synthetic_dataset(40, Vq, n_ws, A, R=R, D=D, max_len=L, seed=5)
+    ds = {"train": DV.Dataset(split="train", data=data, seed=1), "val": DV.Dataset(split="val", data=data, seed=2)}
+    cfg = PTT.build_parser().parse_args(["--batch_size", str(B), "--features_on_device", "1", "--input_workers", "0",
+                                         "--input_prefetch", "0"])
+    cfg.data_cfg = ds["train"].get_config()
+    cfg.vocab = {"vocab": ["w%d" % i for i in range(Vq)], "dict": {"w%d" % i: i for i in range(Vq)}}
+    cfg.answer_dict, cfg.ws_dict = data["answer_dict"], data["ws_dict"]
+    cfg.synthetic, cfg.train_dir, cfg.dropout_off = 1, tempfile.mkdtemp(), True
+    t = PTT.Trainer(cfg, ds)
+    b1, b2 = t._next("train"), t._next("train")
+    want = []
+    for b in (b1, b2):
+        t.model.set_batch(b)
+        t.model.build()
+        want.append(dict(t.model.report))
+    p1 = t.model.prepare(b1)
+    p2 = t.model.prepare(b2)               # no torch.cuda.synchronize() between the two
+    got = []
+    for p in (p1, p2):
+        t.model.build(prepared=p)
+        got.append(dict(t.model.report))
+    del p1, p2
+    torch.cuda.synchronize()
+    assert got == want

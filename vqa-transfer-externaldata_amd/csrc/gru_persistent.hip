@@ -380,28 +380,57 @@ extern "C" int vqa_gru_persistent_set_census(unsigned* dev_words) {
 
 extern "C" int64_t vqa_gru_persistent_sync_bytes(void) { return 256 * sizeof(unsigned); }
 
-// 1 when the persistent form applies to this shape on this device (all workgroups co-resident), else 0
+// Co-residency of the variant that a launch would use, PER DEVICE (the grid barrier never completes unless every
+// workgroup of the grid is resident): blocks per CU from the occupancy query for that variant's thread count and LDS.
+// variant 0: <32>, two 8-wave workgroups per CU (the two-chain form and the 32-row XCD form need >= 2 resp. 1);
+// variant 1: <64>, one 16-wave workgroup per CU (VQA_GRU_PERSIST_XCD=2).
+namespace {
+struct PkResidency { int cus = 0, blocks32 = -1, blocks64 = -1; };
+const PkResidency& pk_residency() {
+    static PkResidency per_dev[64];
+    static bool known[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    PkResidency& r = per_dev[dev];
+    if (!known[dev]) {
+        known[dev] = true;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return r;
+        r.cus = prop.multiProcessorCount;
+        int n = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes()) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_fwd_persistent_kernel<32>, PK_NT, pk_lds_bytes()) == hipSuccess)
+            r.blocks32 = n;
+        n = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(64)) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_fwd_persistent_kernel<64>, 1024, pk_lds_bytes(64)) == hipSuccess)
+            r.blocks64 = n;
+    }
+    return r;
+}
+int pk_xcd_mode() {
+    static int xcd = -1;
+    if (xcd < 0) {
+        const char* e = getenv("VQA_GRU_PERSIST_XCD");
+        xcd = e ? atoi(e) : 0;
+    }
+    return xcd;
+}
+}  // namespace
+
+// 1 when the persistent form applies to this shape on this device (all workgroups of the variant that would be
+// launched co-resident), else 0
 extern "C" int vqa_gru_fwd_persistent_supported(int T, int B, int H) {
     if (g_persist == 0) return 0;
     if (T <= 0 || B < 64 || H < 512 || H % 512 != 0) return 0;      // k tiles: a multiple of the prefetch depth
-    static int blocks_per_cu = -1, cus = 0;
-    if (blocks_per_cu < 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cus = prop.multiProcessorCount;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<32>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes()) != hipSuccess)
-            return 0;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_persistent_kernel<64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(64)) != hipSuccess)
-            return 0;
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_fwd_persistent_kernel<32>, PK_NT, pk_lds_bytes()) != hipSuccess)
-            n = 0;
-        blocks_per_cu = n;
-    }
-    return (blocks_per_cu >= 2 && cus >= 64) ? 1 : 0;
+    const PkResidency& r = pk_residency();
+    if (r.cus < 64) return 0;
+    const int xcd = (pk_xcd_mode() && r.cus % 8 == 0) ? pk_xcd_mode() : 0;
+    if (xcd == 2) return r.blocks64 >= 1 ? 1 : 0;       // grid = #CUs workgroups of 1024 threads
+    if (xcd) return r.blocks32 >= 1 ? 1 : 0;            // grid = #CUs workgroups of 512 threads
+    return r.blocks32 >= 2 ? 1 : 0;                     // grid = 2 x #CUs: both chains' workgroups on every CU
 }
 
 // Whole forward recurrence in one launch.  Same contract as vqa_gru_seq_fwd (xp [T,B,3H] read only, hs [T+1,B,H]
@@ -426,11 +455,7 @@ extern "C" int vqa_gru_seq_fwd_persistent(const float* xp, const float* Wg_h, co
     a.xcd_mode = 0;
     a.err = sync + 32;
     {
-        static int xcd = -1;
-        if (xcd < 0) {
-            const char* e = getenv("VQA_GRU_PERSIST_XCD");
-            xcd = e ? atoi(e) : 0;
-        }
+        const int xcd = pk_xcd_mode();
         if (xcd && cus % 8 == 0) {       // experiment: eight XCD-local chains, one workgroup per CU
             const int bm = xcd == 2 ? 64 : PK_BM;      // 2: one 64-row tile per workgroup and phase (16 waves)
             a.xcd_mode = xcd == 2 ? 2 : 1;

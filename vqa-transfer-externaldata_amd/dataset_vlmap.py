@@ -210,7 +210,15 @@ def create_ops(batch_size, dataset, is_train=True, scope="vlmap_memft", shuffle=
             try:
                 g = 0
                 while True:
-                    b = qs[g % workers].get()
+                    w = g % workers
+                    while True:      # a producer killed from outside (OOM killer) never posts its sentinel: notice it
+                        try:
+                            b = qs[w].get(timeout=5.0)
+                            break
+                        except Exception:       # queue.Empty
+                            if not procs[w].is_alive() and qs[w].empty():
+                                raise RuntimeError("batch producer %d (pid %s) died with exit code %s without posting a "
+                                                   "batch or an error" % (w, procs[w].pid, procs[w].exitcode))
                     if b is None:
                         return
                     if isinstance(b, tuple) and b and b[0] == "__producer_error__":

@@ -124,7 +124,14 @@ class Model(object):
             db = self._device_batch()
         else:
             db, ev = prepared
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            # the tensors were allocated on the side stream: tell the caching allocator that the compute stream uses them
+            # too, so that their blocks are not handed out again (to the next prepare()) while this step still reads them
+            for v in db.values():
+                for t in (v.get("_dev", ()) if isinstance(v, dict) else (v,)):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
         if self._engine is None:
             cfg = self.data_cfg
             # one LayerNorm per shared fc_layer scope (TF 1.x: pretrain.py) unless the config asks for the
