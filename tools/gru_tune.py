@@ -109,6 +109,54 @@ if os.environ.get("GRAPH") == "1":
             tm(fwd), tm(gf.replay), tm(lambda: _lib.check(lib.vqa_gru_seq_bwd(*ba, None), "bwd")), tm(gb.replay)), flush=True)
     sys.exit(0)
 
+if os.environ.get("SPLIT2") == "1":
+    # Two half-batch chains (rows [0, B/2) and [B/2, B)) on two streams, the second one delayed: do one chain's kernel
+    # boundaries (drain, launch gap, first tile) hide behind the other chain's matrix work when the chains run in
+    # ANTI-phase?  (in phase -- no delay -- both compute at half rate and both wait together: no gain by construction)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    half = B // 2
+    clock_hz = 2.1e9     # torch.cuda._sleep counts device cycles; only the relative delays matter
+
+    def run(delay_us, cfg, n=10):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            _lib.check(lib.vqa_gemm_set_gru_config(cfg), "cfg")
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            gate = torch.cuda.Event()
+            torch.cuda._sleep(int(400e-6 * clock_hz))
+            gate.record()
+            s1.wait_event(gate); s2.wait_event(gate)
+            with torch.cuda.stream(s1):
+                t0.record()
+                _lib.check(lib.vqa_gru_seq_fwd_rows(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, 0, half,
+                                                    C.c_void_p(s1.cuda_stream)), "fwd_rows")
+                d1 = torch.cuda.Event(); d1.record()
+            with torch.cuda.stream(s2):
+                if delay_us > 0:
+                    torch.cuda._sleep(int(delay_us * 1e-6 * clock_hz))
+                _lib.check(lib.vqa_gru_seq_fwd_rows(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, half,
+                                                    B - half, C.c_void_p(s2.cuda_stream)), "fwd_rows")
+                s2.wait_event(d1)
+                t1.record()
+            torch.cuda.synchronize()
+            ts.append(t0.elapsed_time(t1) * 1e3)
+        return min(ts), sorted(ts)[len(ts) // 2]
+
+    fwd(); torch.cuda.synchronize()
+    ref = hs[T].clone()
+    _lib.check(lib.vqa_gemm_set_gru_config(-1), "cfg")
+    print("one chain, one stream (product path): %.1f us" % tm(fwd), flush=True)
+    for cfg in [int(x) for x in os.environ.get("SPLIT2_CFGS", "16,9,11,7,8").split(",")]:
+        for delay in [float(x) for x in os.environ.get("SPLIT2_DELAYS", "0,4,8,12,16,24").split(",")]:
+            hs[1:].zero_()
+            best, med = run(delay, cfg)
+            err = float((hs[T] - ref).abs().max())
+            print("two chains on two streams, cfg %2d, chain 2 delayed %4.1f us: both done after %.1f us (median %.1f)  max |h - ref| %.1e"
+                  % (cfg, delay, best, med, err), flush=True)
+    _lib.check(lib.vqa_gemm_set_gru_config(-1), "cfg")
+    sys.exit(0)
+
 cfgs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "11,16,17,18").split(",")]
 best = {k: [1e9, 1e9] for k in cfgs}
 ref = None
