@@ -326,7 +326,9 @@ typedef struct {
     int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec, 3 = standard_testmask (= 1 with
                               * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268),
                               * 4 = vlmap_answer_vqa_all2 (= 0 + the trainable TunedWordWeightAnswer head, summed logits,
-                              * two-term loss, mixed-mask argmax: vqa/model_vlmap_answer_vqa_all2.py:196-244) */
+                              * two-term loss, mixed-mask argmax: vqa/model_vlmap_answer_vqa_all2.py:196-244),
+                              * 5 = vlmap_answer_noc / _nocarch (two un-composed branches joint_v(pooled_linear_l) and
+                              * joint_l(l_linear_l) with their own heads, logits summed: vqa/model_vlmap_answer_noc.py:177-204) */
     float keep_att;          /* 0.8  vlmap/modules.py:82 */
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
@@ -354,8 +356,11 @@ typedef struct {
     vqa_fc_t head;                      /* WordWeightAnswer | reasoning/classifier [2H,A]  ([2H,W] for standard_word2vec) */
     float* answer_glove;                /* standard_word2vec only: constant [W,A] GloVe matrix of the answers
                                          * (vqa/model_standard_word2vec.py:185-188); NULL otherwise */
-    vqa_fc_t head2;                     /* vlmap_answer_vqa_all2 only: TunedWordWeightAnswer [2H,A], the trainable second
-                                         * head on `joint` (vqa/model_vlmap_answer_vqa_all2.py:216-220); NULL otherwise */
+    vqa_fc_t head2;                     /* vlmap_answer_vqa_all2: TunedWordWeightAnswer [2H,A], the trainable second head on
+                                         * `joint` (vqa/model_vlmap_answer_vqa_all2.py:216-220); vlmap_answer_noc:
+                                         * WordWeightAnswerL [2H,A] (`head` is then WordWeightAnswerV); NULL otherwise */
+    vqa_fc_t joint2;                    /* vlmap_answer_noc only: joint_l [H,2H] on l_linear_l (`joint_fc` is then joint_v on
+                                         * pooled_linear_l; vqa/model_vlmap_answer_noc.py:177-188); NULL otherwise */
 } vqa_params_t;
 
 typedef struct {
@@ -368,6 +373,7 @@ typedef struct {
     const float *train_mask, *obj_mask, *attr_mask, *exist_mask; /* [A] */
     const uint8_t* keep_att;            /* [B,R,H] 0/1 or NULL (no dropout) */
     const uint8_t* keep_joint;          /* [B,2H] 0/1 or NULL */
+    const uint8_t* keep_joint2;         /* vlmap_answer_noc only: keep-mask of l_joint [B,2H] (keep_joint is v_joint's) or NULL */
     const int32_t* live_rows;           /* HOST int[T] or NULL.  Non-NULL promises that the batch rows are sorted by
                                          * q_intseq_len, longest first, and live_rows[t] = #rows with len > t; the
                                          * recurrence then skips finished sequences (vqa_gru_seq_*_live). */

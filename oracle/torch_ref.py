@@ -82,6 +82,15 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     p = torch.bmm(att.unsqueeze(1), V).squeeze(1)
     pl = _fc_ln_relu(p, P, sc["pooled_linear_l"])
     ll = _fc_ln_relu(h, P, sc["q_linear_l"])
+    if model_type in O.NOC_FAMILY:        # vqa/model_vlmap_answer_noc.py:177-204, composed independently
+        m_jl = masks["joint_l"] if torch.is_tensor(masks["joint_l"]) else _t(masks["joint_l"], dtype)
+        vj = _fc_ln_relu(pl, P, sc["joint_v"]) * m_j / O.KEEP_JOINT
+        lj = _fc_ln_relu(ll, P, sc["joint_l"]) * m_jl / O.KEEP_JOINT
+        z = torch.addmm(P[sc["headV"] + "/fc/biases"], vj, P[sc["headV"] + "/fc/weights"]) + \
+            torch.addmm(P[sc["headL"] + "/fc/biases"], lj, P[sc["headL"] + "/fc/weights"])
+        loss = (F.binary_cross_entropy_with_logits(z, tgt, reduction="none") * _t(answer_masks["train"], dtype)).sum(-1).mean()
+        return loss, {"v_linear_v": v, "condition": h, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
+                      "pooled_linear_l": pl, "l_linear_l": ll, "v_joint": vj, "l_joint": lj, "logit": z, "embed": e}
     j = _fc_ln_relu(pl * ll, P, sc["joint_fc"]) * m_j / O.KEEP_JOINT
     z = F.linear(j, P[sc["head"] + "/fc/weights"].t(), P[sc["head"] + "/fc/biases"])
     if model_type == "standard_word2vec":

@@ -49,13 +49,22 @@ OUTPUT_GLOVE = "reasoning/output_glove:const"
 # plain 'classifier' head); standard_testmask (vqa/model_standard_testmask.py) is model_standard with the training
 # loss masked by the train-answer mask (:266-268) and an older, shorter report (:295-304)
 STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
-TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask")
+TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask", "vlmap_answer_noc", "vlmap_answer_nocarch")
 # vqa/model_vlmap_answer_vqa_all2.py: model_vlmap_answer (fixed transferred fusion MLP + WordWeightAnswer head, :128-196)
 # plus a TRAINABLE second head `TunedWordWeightAnswer` on the same `joint` (:216-220); logits are summed (:226-227), the
 # loss is untuned * train_mask + tuned (:240-241) and the prediction takes the tuned logit on training answers and the
 # fixed one on test answers (:243-244).  `tuned_q_linear_l` / `tuned_joint_fc` (:202-214) are built but feed nothing:
 # the tuned head reads `joint`, not `tuned_joint` (:216-217) -- reproduced: variables that never receive a gradient.
-VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2")
+# vqa/model_vlmap_answer_noc.py (= model_vlmap_answer_nocarch.py, the two files are identical): "no composition" --
+# instead of joint_fc(pooled_linear_l * l_linear_l) two separate branches, joint_v(pooled_linear_l) and joint_l(l_linear_l),
+# each FC + LN + ReLU + dropout 0.5 (:177-188) with its own transferred head WordWeightAnswerV / WordWeightAnswerL
+# (weights.hdf5 datasets v_class_* / l_class_*, :190-202); logit = v_logit + l_logit (:204); loss / report as in
+# model_vlmap_answer; frozen: q_linear_l, pooled_linear_l, joint_v, joint_l and both heads (:80-90), transferred: the four
+# layers (:92-103)
+NOC_FAMILY = ("vlmap_answer_noc", "vlmap_answer_nocarch")
+FROZEN_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV", "WordWeightAnswerL")
+TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l")
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2") + NOC_FAMILY
 # report keys of vqa/model_standard_testmask.py:295-304 in terms of the 13 keys of the current models
 TESTMASK_REPORT = {"answer_train_loss": "answer_train_loss", "answer_report_loss": "answer_report_loss",
                    "answer_accuracy": "answer_acc", "exist_answer_accuracy": "exist_acc",
@@ -113,6 +122,8 @@ def scope_names(model_type: str) -> dict:
         "head": head,
         # vlmap_answer_vqa_all2 only
         "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc",
+        # vlmap_answer_noc / nocarch only
+        "joint_v": "joint_v", "joint_l": "joint_l", "headV": "WordWeightAnswerV", "headL": "WordWeightAnswerL",
     }
 
 
@@ -121,7 +132,8 @@ def train_var_names(params: dict, model_type: str) -> list:
     names = sorted(n for n in params.keys() if not is_const(n))
     if model_type in STANDARD_FAMILY:
         return names
-    return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
+    frozen = FROZEN_TOP_SCOPES_NOC if model_type in NOC_FAMILY else FROZEN_TOP_SCOPES_VLMAP
+    return [n for n in names if n.split("/")[0] not in frozen]
 
 
 def transfer_var_names(params: dict, model_type: str) -> list:
@@ -129,7 +141,8 @@ def transfer_var_names(params: dict, model_type: str) -> list:
     names = sorted(n for n in params.keys() if not is_const(n))
     if model_type in STANDARD_FAMILY:
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
-    return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
+    keep = TRANSFER_TOP_SCOPES_NOC if model_type in NOC_FAMILY else TRANSFER_TOP_SCOPES_VLMAP
+    return [n for n in names if n.split("/")[0] in keep]
 
 
 # ----------------------------------------------------------------------------
@@ -169,6 +182,16 @@ def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=
     fc(sc["score"], H, 1, False)
     fc(sc["pooled_linear_l"], D, H, True)
     fc(sc["q_linear_l"], H, H, True)
+    if model_type in NOC_FAMILY:
+        fc(sc["joint_v"], H, 2 * H, True)
+        fc(sc["joint_l"], H, 2 * H, True)
+        for hd in (sc["headV"], sc["headL"]):
+            if head == "untrained":
+                p[hd + "/fc/weights"] = np.zeros((2 * H, A), dtype)
+                p[hd + "/fc/biases"] = np.full(A, -100.0, dtype)
+            else:
+                fc(hd, 2 * H, A, False)
+        return p
     fc(sc["joint_fc"], H, 2 * H, True)
     if model_type == "vlmap_answer_vqa_all2":
         fc(sc["tuned_q_linear_l"], H, H, True)
@@ -390,6 +413,22 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
     p = np.einsum("br,brd->bd", att, V)                                  # a7
     pl, t_pl = fc_ln_relu_forward(p, params, sc["pooled_linear_l"])      # a8
     ll, t_ll = fc_ln_relu_forward(h, params, sc["q_linear_l"])
+    if model_type in NOC_FAMILY:
+        vj0, t_vj = fc_ln_relu_forward(pl, params, sc["joint_v"])        # :177-181
+        lj0, t_lj = fc_ln_relu_forward(ll, params, sc["joint_l"])        # :183-188
+        vj = vj0 * masks["joint"] * dt(1.0 / KEEP_JOINT)
+        lj = lj0 * masks["joint_l"] * dt(1.0 / KEEP_JOINT)
+        zv = fc_forward(vj, params[sc["headV"] + "/fc/weights"], params[sc["headV"] + "/fc/biases"])
+        zl = fc_forward(lj, params[sc["headL"] + "/fc/weights"], params[sc["headL"] + "/fc/biases"])
+        z = zv + zl                                                      # :204
+        loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)
+        out["att_score"], out["logit"] = att, z
+        mid = {"num_V_ft": nb, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p, "pooled_linear_l": pl,
+               "l_linear_l": ll, "v_joint": vj, "l_joint": lj, "logit": z, "pred": out["pred"], "v_linear_v": v,
+               "condition": h, "V_ft": V}
+        tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att, feat=feat, p=p, pl=pl,
+                    t_pl=t_pl, ll=ll, t_ll=t_ll, vj=vj, lj=lj, t_vj=t_vj, t_lj=t_lj, z=z)
+        return loss, report, out, mid, tape
     jin = pl * ll
     j0, t_j = fc_ln_relu_forward(jin, params, sc["joint_fc"])            # a9
     j = j0 * masks["joint"] * dt(1.0 / KEEP_JOINT)
@@ -465,6 +504,16 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     dz = (sigmoid(z) - tgt) / dt(B)
     if model_type in TRAIN_MASKED_LOSS or model_type == "vlmap_answer_vqa_all2":
         dz = dz * answer_masks["train"]
+    if model_type in NOC_FAMILY:
+        for hd, jt in ((sc["headV"], "vj"), (sc["headL"], "lj")):
+            g[hd + "/fc/weights"] = tape[jt].T @ dz
+            g[hd + "/fc/biases"] = dz.sum(axis=0)
+        sc_keep = dt(1.0 / KEEP_JOINT)
+        dpl = _fc_ln_relu_backward(dz @ params[sc["headV"] + "/fc/weights"].T * masks["joint"] * sc_keep,
+                                   tape["t_vj"], params, sc["joint_v"], g)
+        dll = _fc_ln_relu_backward(dz @ params[sc["headL"] + "/fc/weights"].T * masks["joint_l"] * sc_keep,
+                                   tape["t_lj"], params, sc["joint_l"], g)
+        return _backward_below_joint(params, batch, masks, tape, sc, g, dpl, dll, dt)
     Wh = params[sc["head"] + "/fc/weights"]
     if model_type == "standard_word2vec":
         dz = dz @ params[sc["glove"]].T                     # gradient wrt joint2; the GloVe matrix is a constant
@@ -483,6 +532,12 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     djin = _fc_ln_relu_backward(dj0, tape["t_j"], params, sc["joint_fc"], g)
     dpl = djin * tape["ll"]
     dll = djin * tape["pl"]
+    return _backward_below_joint(params, batch, masks, tape, sc, g, dpl, dll, dt)
+
+
+def _backward_below_joint(params, batch, masks, tape, sc, g, dpl, dll, dt):
+    """everything upstream of pooled_linear_l / l_linear_l (shared by all model types)"""
+    z = tape["z"]
     dp = _fc_ln_relu_backward(dpl, tape["t_pl"], params, sc["pooled_linear_l"], g)
     dh = _fc_ln_relu_backward(dll, tape["t_ll"], params, sc["q_linear_l"], g)
     # attention pooling: p = sum_r att * V   (V is an input: no dV)
@@ -625,6 +680,9 @@ def make_table(rng, N, R, D, dtype=np.float32, full_boxes=True):
     return table, nbox
 
 
-def make_dropout_masks(rng, B, R, H, dtype=np.float32):
-    return {"att": (rng.random((B, R, H)) < KEEP_ATT).astype(dtype),
-            "joint": (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)}
+def make_dropout_masks(rng, B, R, H, dtype=np.float32, model_type=None):
+    m = {"att": (rng.random((B, R, H)) < KEEP_ATT).astype(dtype),
+         "joint": (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)}
+    if model_type in NOC_FAMILY:          # second dropout site: l_joint (`joint` is v_joint's mask)
+        m["joint_l"] = (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)
+    return m

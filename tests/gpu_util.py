@@ -18,7 +18,7 @@ def make_case(seed, model_type, B, R, T, N, dims, dtype=np.float32, full_boxes=F
     table, nbox = O.make_table(rng, N, R, dims["D"], dtype, full_boxes=full_boxes)
     batch = O.make_batch(rng, B, T, dims["Vq"], dims["A"], N, dtype, ragged=ragged)
     am = O.make_answer_masks(rng, dims["A"], num_train or int(dims["A"] * 0.75), dtype, exist_all=False)
-    masks = O.make_dropout_masks(rng, B, R, dims["H"], dtype)
+    masks = O.make_dropout_masks(rng, B, R, dims["H"], dtype, model_type=model_type)
     return p, table, nbox, batch, am, masks
 
 

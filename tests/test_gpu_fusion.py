@@ -21,8 +21,9 @@ MID_KEYS = ["v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft",
 
 def run_engine(eng, batch, masks, lr=None):
     ka, kj = dev(masks["att"].astype(np.uint8)), dev(masks["joint"].astype(np.uint8))
+    kj2 = dev(masks["joint_l"].astype(np.uint8)) if "joint_l" in masks else None        # vlmap_answer_noc's second dropout site
     db = dev_batch(batch)
-    eng.forward(db, ka, kj, want_dz=True)
+    eng.forward(db, ka, kj, want_dz=True, keep_joint2=kj2)
     eng.backward()
     if lr is not None:
         eng.optimizer_step(lr)
@@ -37,7 +38,7 @@ def grad_close(got, want, name, tol=5e-4):
 
 
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
-                                        "vlmap_answer_vqa_all2"])
+                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc"])
 @pytest.mark.parametrize("cfg", [("small", SMALL, 5, 6, 7, 9), ("med", MED, 32, 36, 14, 64),
                                  ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
 def test_forward_backward_match_oracle(model_type, cfg):
@@ -51,6 +52,10 @@ def test_forward_backward_match_oracle(model_type, cfg):
                                              model_type)
     grads, dx = O.backward(p64, to64(batch), to64(am), to64(masks), tape, model_type)
     shapes = {"v_linear_v": (B, R, dims["H"]), "att_score": (B, R), "logit": (B, dims["A"])}
+    if model_type in O.NOC_FAMILY:      # "joint" holds v_joint there; l_joint is the second branch
+        mid = dict(mid, joint=mid["v_joint"])
+        got = eng.tensor("l_joint").cpu().numpy().reshape(mid["l_joint"].shape)
+        assert np.abs(got - mid["l_joint"]).max() <= 2e-4 * max(1.0, np.abs(mid["l_joint"]).max())
     for k in MID_KEYS:
         got = eng.tensor(k).cpu().numpy().reshape(mid[k].shape)
         tol = 1e-3 if k == "logit" else 2e-4 * max(1.0, np.abs(mid[k]).max())

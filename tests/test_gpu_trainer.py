@@ -233,6 +233,41 @@ def test_vqa_all2_variant_trains_through_the_trainer_and_evaluates(tmp_path):
     assert len(res["qid2result"]) == 40 and res["avg_eval_report"]["answer_acc_num_point"] == 40
 
 
+@pytest.mark.parametrize("model_type", ["vlmap_answer_noc", "vlmap_answer_nocarch"])
+def test_noc_variant_loads_its_two_heads_and_trains(tmp_path, model_type):
+    """vqa/model_vlmap_answer_noc.py (= nocarch) through the Trainer: WordWeightAnswerV / L initialised from the v_class_* /
+    l_class_* datasets of a word-weight directory (export_noc_word_weights.py:72-75), frozen / transfer sets of :80-103,
+    a second dropout site, training moves only the layers below the frozen fusion MLP."""
+    import pickle
+    from vqa_transfer_externaldata_amd import hdf5_io, trainer
+    c, Vq, A = _config(tmp_path, model_type)
+    rng = np.random.default_rng(3)
+    wdir = tmp_path / "word_weights_noc"
+    os.makedirs(str(wdir))
+    src_answers = ["a%d" % i for i in range(0, A, 2)]                            # every other answer is known
+    ww = {k: rng.standard_normal((2048, len(src_answers)) if "weights" in k else (len(src_answers),)).astype(np.float32)
+          for k in ("v_class_weights", "v_class_biases", "l_class_weights", "l_class_biases")}
+    hdf5_io.write(str(wdir / "weights.hdf5"), ww)
+    with open(str(wdir / "answer_dict.pkl"), "wb") as f:
+        pickle.dump({"vocab": src_answers, "dict": {a: i for i, a in enumerate(src_answers)}}, f)
+    c.vlmap_word_weight_dir = str(wdir)
+    t = trainer.Trainer(c, datasets=_datasets(Vq, A), image_features=_features())
+    P = t.model.engine.params
+    np.testing.assert_array_equal(P["WordWeightAnswerV/fc/weights"][:, 2].cpu().numpy(), ww["v_class_weights"][:, 1])
+    np.testing.assert_array_equal(P["WordWeightAnswerL/fc/biases"][4].cpu().numpy(), ww["l_class_biases"][2])
+    assert float(P["WordWeightAnswerV/fc/biases"][1]) == -100.0 and not P["WordWeightAnswerL/fc/weights"][:, 1].any()
+    assert not any(v.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV",
+                                       "WordWeightAnswerL") for v in t.train_vars)
+    assert sorted({v.split("/")[0] for v in t.transfer_vars}) == ["joint_l", "joint_v", "pooled_linear_l", "q_linear_l"]
+    assert "joint" not in t.model.mid_result and t.model.mid_result["l_joint"].shape == (32, 2048)
+    frozen = {k: v.clone() for k, v in P.items() if k.split("/")[0] in ("joint_v", "joint_l", "WordWeightAnswerL")}
+    moving = P["v_linear_v/fc/weights"].clone()
+    t.train()
+    for k, v in frozen.items():
+        assert torch.equal(P[k], v), k
+    assert not torch.equal(P["v_linear_v/fc/weights"], moving)
+
+
 def test_eval_multiple_model_sweeps_every_checkpoint_of_every_run(tmp_path):
     """vqa/eval_multiple_model.py:40-130: runs under --root_train_dir named vqa_<model>_d_<qa split>_tf_record_memft...,
     runs without checkpoints dropped, a run pointing at another feature file skipped, one results.pkl per checkpoint"""

@@ -16,12 +16,12 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
     table, nbox = O.make_table(rng, N, R, DIMS["D"], dtype, full_boxes=full_boxes)
     batch = O.make_batch(rng, B, T, DIMS["Vq"], DIMS["A"], N, dtype)
     am = O.make_answer_masks(rng, DIMS["A"], 15, dtype, exist_all=False)
-    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], dtype)
+    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], dtype, model_type=model_type)
     return p, table, nbox, batch, am, masks
 
 
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
-                                        "vlmap_answer_vqa_all2"])
+                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -29,8 +29,9 @@ def test_forward_and_grads_match_torch_autograd(model_type):
     tloss, tmid, tgrads, tdx = TR.loss_and_grads(p, batch, table, nbox, am, masks, model_type)
     assert abs(loss - tloss) <= 1e-10 * max(1, abs(tloss))
     for k in ("v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "pooled_linear_l",
-              "l_linear_l", "joint", "logit"):
-        np.testing.assert_allclose(mid[k], tmid[k], rtol=1e-9, atol=1e-11, err_msg=k)
+              "l_linear_l", "joint", "v_joint", "l_joint", "logit"):
+        if k in mid or k in tmid:
+            np.testing.assert_allclose(mid[k], tmid[k], rtol=1e-9, atol=1e-11, err_msg=k)
     for k in p:
         if O.is_const(k):
             assert k not in grads and k not in O.train_var_names(p, model_type)    # a tf.constant: no gradient
@@ -73,6 +74,31 @@ def test_vqa_all2_known_answers():
     out2 = O.forward(p2, batch, table, nbox, am, masks, mt)[2]
     mixed = np.where(train > 0, z2, -100.0)
     np.testing.assert_array_equal(out2["pred"], np.argmax(mixed, axis=1))
+
+
+def test_noc_variant_known_answers():
+    """vqa/model_vlmap_answer_noc.py (= nocarch): two un-composed branches joint_v(pooled_linear_l), joint_l(l_linear_l), their
+    transferred heads, logit = v_logit + l_logit; frozen / transfer sets of :80-103."""
+    mt = "vlmap_answer_noc"
+    p, table, nbox, batch, am, masks = _case(31, mt)
+    assert "joint_fc/fc/weights" not in p and "WordWeightAnswer/fc/weights" not in p
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    zv = mid["v_joint"] @ p["WordWeightAnswerV/fc/weights"] + p["WordWeightAnswerV/fc/biases"]
+    zl = mid["l_joint"] @ p["WordWeightAnswerL/fc/weights"] + p["WordWeightAnswerL/fc/biases"]
+    np.testing.assert_allclose(mid["logit"], zv + zl, rtol=1e-12)
+    assert np.all(mid["v_joint"][masks["joint"] == 0] == 0) and np.all(mid["l_joint"][masks["joint_l"] == 0] == 0)
+    ell = O.sigmoid_ce(mid["logit"], batch["answer_target"])
+    assert report["answer_train_loss"] == pytest.approx((ell * am["train"]).sum(1).mean(), rel=1e-12)
+    names = O.train_var_names(p, mt)
+    assert not any(n.split("/")[0] in O.FROZEN_TOP_SCOPES_NOC for n in names) and "v_linear_v/fc/weights" in names
+    assert sorted({n.split("/")[0] for n in O.transfer_var_names(p, mt)}) == ["joint_l", "joint_v", "pooled_linear_l", "q_linear_l"]
+    # the identical twin file
+    l2 = O.forward(p, batch, table, nbox, am, masks, "vlmap_answer_nocarch")[0]
+    assert l2 == loss
+    # untrained heads: each -100 bias, summed -> -200 everywhere
+    pu = O.init_params(np.random.default_rng(1), mt, dtype=np.float64, head="untrained", **DIMS)
+    z = O.forward(pu, batch, table, nbox, am, masks, mt)[3]["logit"]
+    assert np.all(z == -200.0)
 
 
 def test_word2vec_head_known_answers():

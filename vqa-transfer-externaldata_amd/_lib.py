@@ -37,7 +37,7 @@ class Params(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("v_linear_v", Fc),
                 ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
                 ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
-                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc)]
+                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc), ("joint2", Fc)]
 
 
 class Batch(C.Structure):
@@ -45,7 +45,7 @@ class Batch(C.Structure):
                 ("q_intseq", C.c_void_p), ("q_intseq_len", C.c_void_p), ("answer_target", C.c_void_p),
                 ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
                 ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p),
-                ("live_rows", C.c_void_p)]
+                ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p)]
 
 
 class PtDims(C.Structure):

@@ -64,6 +64,10 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("pre_j", B * 2 * H); L.add("joint", B * 2 * H); L.add("mean_j", B); L.add("rstd_j", B);
     L.add("joint2", B * W);      // standard_word2vec: classifier output in the 300-d word space
     L.add("logit", B * A);
+    if (d.model_type == 5) {     // vlmap_answer_noc: the l_joint branch ("joint" is v_joint)
+        L.add("pre_jl", B * 2 * H); L.add("l_joint", B * 2 * H); L.add("mean_jl", B); L.add("rstd_jl", B);
+        L.add("d_ljoint", B * 2 * H); L.add("d_pre_jl", B * 2 * H);
+    }
     if (d.model_type == 4) {     // vlmap_answer_vqa_all2: the two heads' logits ("logit" = their sum) and the tuned head's dz
         L.add("logit_fixed", B * A); L.add("logit_tuned", B * A); L.add("dlogit_tuned", B * A);
     }
@@ -228,7 +232,7 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 4;
+           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 5;
 }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
@@ -415,12 +419,22 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                        "rstd_pl", nullptr, 1.f));
     TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
     // a9
+    if (dims->model_type == 5) {
+        // vlmap_answer_noc (vqa/model_vlmap_answer_noc.py:177-188): no composition -- joint_v on pooled_linear_l and joint_l
+        // on l_linear_l, each FC + LN + ReLU + dropout .5 ("joint" holds v_joint)
+        VQA_REQUIRE(P->joint2.w != nullptr && P->head2.w != nullptr, VQA_ERR_ARG);
+        TRY(fc_ln_relu_fwd(c, c.f("pooled_linear_l"), B, H, 2 * H, P->joint_fc, 1, "pre_j", "joint", "mean_j", "rstd_j",
+                           bt->keep_joint, dims->keep_joint));
+        TRY(fc_ln_relu_fwd(c, c.f("l_linear_l"), B, H, 2 * H, P->joint2, 1, "pre_jl", "l_joint", "mean_jl", "rstd_jl",
+                           bt->keep_joint2, dims->keep_joint));
+    } else {
     {
         ProbeScope ps("eltwise", c.st);
         TRY(vqa_mul(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), B * H, c.st));
     }
     TRY(fc_ln_relu_fwd(c, c.f("joint_in"), B, H, 2 * H, P->joint_fc, 1, "pre_j", "joint", "mean_j", "rstd_j",
                        bt->keep_joint, dims->keep_joint));
+    }
     // a10
     if (dims->model_type == 2) {
         // standard_word2vec (vqa/model_standard_word2vec.py:180-188): classifier FC into the 300-d word space, then
@@ -429,6 +443,12 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         ProbeScope ps("head.fwd_gemm", c.st);
         TRY(gemm(c, 0, 0, B, W, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)W, c.f("joint2"), (int)W, P->head.b));
         TRY(gemm(c, 0, 0, B, A, W, c.f("joint2"), (int)W, P->answer_glove, (int)A, c.f("logit"), (int)A));
+    } else if (dims->model_type == 5) {
+        // logit = WordWeightAnswerV(v_joint) + WordWeightAnswerL(l_joint)   (:190-204): the second GEMM adds onto the first
+        ProbeScope ps("head.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("l_joint"), (int)(2 * H), P->head2.w, (int)A, c.f("logit"), (int)A, P->head2.b,
+                 c.f("logit"), (int)A));
     } else if (dims->model_type == 4) {
         // vlmap_answer_vqa_all2 (vqa/model_vlmap_answer_vqa_all2.py:196-227): the fixed WordWeightAnswer head and the
         // trainable TunedWordWeightAnswer head, BOTH on `joint` (the reference's tuned head reads `joint`, :216-217)
@@ -512,6 +532,18 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     }
     }
     }
+    if (dims->model_type == 5) {
+        // vlmap_answer_noc: the two branches separately, straight into d_pl / d_ll (no product to differentiate)
+        if (G->head2.w != nullptr) {
+            TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("l_joint"), (int)(2 * H), c.f("dlogit"), (int)A, G->head2.w, (int)A));
+            TRY(colsum(c, c.f("dlogit"), B, A, (int)A, G->head2.b));
+        }
+        TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head2.w, (int)A, c.f("d_ljoint"), (int)(2 * H)));
+        TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("pooled_linear_l"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j",
+                           "mean_j", "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_pl"), false));
+        TRY(fc_ln_relu_bwd(c, c.f("d_ljoint"), c.f("l_linear_l"), B, H, 2 * H, P->joint2, &G->joint2, 1, "pre_jl", "mean_jl",
+                           "rstd_jl", bt->keep_joint2, dims->keep_joint, "d_pre_jl", c.f("d_ll"), false));
+    } else {
     // joint_fc (dropout mask folded into the LN/ReLU backward)
     TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("joint_in"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j", "mean_j",
                        "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_joint_in"), false));
@@ -519,6 +551,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         ProbeScope ps("eltwise", c.st);
         TRY(vqa_mul_bwd(c.f("d_joint_in"), c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("d_pl"), c.f("d_ll"), B * H,
                         c.st));
+    }
     }
     TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
                        "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));

@@ -39,12 +39,23 @@ _INT_TENSORS = {"num_V_ft", "pred"}
 # vqa/model_standard_word2vec.py, vqa/model_standard_testmask.py:64-68)
 STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
 # model_vlmap_answer and its variant with a second, trainable head on the fixed joint (vqa/model_vlmap_answer_vqa_all2.py)
-VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2")
+# "no composition" (vqa/model_vlmap_answer_noc.py = model_vlmap_answer_nocarch.py): joint_v / joint_l instead of joint_fc,
+# WordWeightAnswerV / WordWeightAnswerL instead of WordWeightAnswer
+NOC_FAMILY = ("vlmap_answer_noc", "vlmap_answer_nocarch")
+FROZEN_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV", "WordWeightAnswerL")
+TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l")
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2") + NOC_FAMILY
 
 
 def scope_names(model_type):
     """logical layer -> TF variable scope (vqa/model_vlmap_answer.py:126-185,
     vqa/model_standard.py:223-275)."""
+    if model_type in NOC_FAMILY:
+        return {"embed": "LearnGloVe/embed_map", "v_linear_v": "v_linear_v",
+                "gru_gates": "encode_L/rnn/gru_cell/gates", "gru_cand": "encode_L/rnn/gru_cell/candidate",
+                "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
+                "pooled_linear_l": "pooled_linear_l", "q_linear_l": "q_linear_l",
+                "joint_fc": "joint_v", "joint2": "joint_l", "head": "WordWeightAnswerV", "head2": "WordWeightAnswerL"}
     if model_type in VLMAP_FAMILY:
         pre, head = "", "WordWeightAnswer"
     elif model_type in STANDARD_FAMILY:
@@ -88,6 +99,9 @@ def variable_shapes(model_type, Vq, W, D, H, A):
         fc(sc["tuned_q_linear_l"], H, H, True)
         fc(sc["tuned_joint_fc"], H, 2 * H, True)
         fc(sc["head2"], 2 * H, A, False)
+    if model_type in NOC_FAMILY:
+        fc(sc["joint2"], H, 2 * H, True)
+        fc(sc["head2"], 2 * H, A, False)
     return s
 
 
@@ -95,14 +109,16 @@ def filter_train_vars(names, model_type):
     """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
     if model_type in STANDARD_FAMILY:
         return list(names)
-    return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_VLMAP]
+    frozen = FROZEN_TOP_SCOPES_NOC if model_type in NOC_FAMILY else FROZEN_TOP_SCOPES_VLMAP
+    return [n for n in names if n.split("/")[0] not in frozen]
 
 
 def filter_transfer_vars(names, model_type):
     """vqa/model_vlmap_answer.py:91-100 / vqa/model_standard.py:86-93."""
     if model_type in STANDARD_FAMILY:
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
-    return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_VLMAP]
+    keep = TRANSFER_TOP_SCOPES_NOC if model_type in NOC_FAMILY else TRANSFER_TOP_SCOPES_VLMAP
+    return [n for n in names if n.split("/")[0] in keep]
 
 
 def _pad4(n):
@@ -111,7 +127,7 @@ def _pad4(n):
 
 class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
-                     "vlmap_answer_vqa_all2": 4}
+                     "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
@@ -258,7 +274,8 @@ class FusionEngine:
             pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
             joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False),
             answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None,
-            head2=fc(sc["head2"], False) if self.model_type == "vlmap_answer_vqa_all2" else _lib.Fc())
+            head2=fc(sc["head2"], False) if self.model_type in ("vlmap_answer_vqa_all2",) + NOC_FAMILY else _lib.Fc(),
+            joint2=fc(sc["joint2"], True) if self.model_type in NOC_FAMILY else _lib.Fc())
 
     def resize(self, B, T, global_batch=None):
         """Re-target the engine to another batch size / padded question length (the reference pads
@@ -276,7 +293,7 @@ class FusionEngine:
         if need > self.workspace.numel():
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
-        for a in ("_keep_att", "_keep_joint"):
+        for a in ("_keep_att", "_keep_joint", "_keep_joint2"):
             if hasattr(self, a):
                 delattr(self, a)
 
@@ -302,7 +319,7 @@ class FusionEngine:
         self._table, self._nbox = table, nbox_table
         self._amask = answer_masks
 
-    def _batch_struct(self, batch, keep_att, keep_joint):
+    def _batch_struct(self, batch, keep_att, keep_joint, keep_joint2=None):
         d = self.dims
         assert batch["image_idx"].dtype == torch.int64 and batch["image_idx"].numel() == d.B
         assert batch["q_intseq"].dtype == torch.int32 and tuple(batch["q_intseq"].shape) == (d.B, d.T)
@@ -316,7 +333,9 @@ class FusionEngine:
         if live is not None:      # host int32[T]: rows sorted by length, longest first (input_ops_vqa.sort_by_length)
             live = np.ascontiguousarray(live, dtype=np.int32)
             assert live.shape == (d.T,) and (np.diff(live) <= 0).all() and 0 <= live[-1] and live[0] <= d.B
-        self._batch_keepalive = (batch, keep_att, keep_joint, live)
+        if keep_joint2 is not None:
+            assert keep_joint2.dtype == torch.uint8 and keep_joint2.numel() == d.B * 2 * d.H
+        self._batch_keepalive = (batch, keep_att, keep_joint, keep_joint2, live)
         am = self._amask
         return _lib.Batch(
             table=self._table.data_ptr(), nbox_table=self._nbox.data_ptr(),
@@ -326,10 +345,12 @@ class FusionEngine:
             exist_mask=am["exist"].data_ptr(),
             keep_att=keep_att.data_ptr() if keep_att is not None else None,
             keep_joint=keep_joint.data_ptr() if keep_joint is not None else None,
+            keep_joint2=keep_joint2.data_ptr() if keep_joint2 is not None else None,
             live_rows=live.ctypes.data if live is not None else None)
 
-    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True):
-        self._bs = self._batch_struct(batch, keep_att, keep_joint)
+    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None):
+        """keep_joint2: vlmap_answer_noc only -- the keep-mask of l_joint (keep_joint is v_joint's)"""
+        self._bs = self._batch_struct(batch, keep_att, keep_joint, keep_joint2)
         _lib.check(self.lib.vqa_fusion_forward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._bs),
                                                C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
                                                1 if want_dz else 0, self._stream()), "vqa_fusion_forward")
@@ -382,8 +403,8 @@ class FusionEngine:
                                           self.n_train, C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, lr_t,
                                           ADAM_B1, ADAM_B2, ADAM_EPS, self._stream()), "vqa_clip_adam")
 
-    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None):
-        self.forward(batch, keep_att, keep_joint, want_dz=True)
+    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None):
+        self.forward(batch, keep_att, keep_joint, want_dz=True, keep_joint2=keep_joint2)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(reducer=allreduce)          # bucketed, overlapped with the backward phases
         else:
@@ -440,3 +461,15 @@ class FusionEngine:
                                              off + Bg * d.R * d.H + row_offset * 2 * d.H, d.keep_joint,
                                              self._stream()), "vqa_dropout_mask")
         return self._keep_att, self._keep_joint
+
+    def make_keep_mask_joint2(self, seed, step, row_offset=0, global_rows=None):
+        """vlmap_answer_noc: the second dropout site's keep-mask (l_joint), from its own region of the same stream"""
+        d = self.dims
+        Bg = int(global_rows) if global_rows is not None else d.B
+        n_j = d.B * 2 * d.H
+        if not hasattr(self, "_keep_joint2"):
+            self._keep_joint2 = torch.empty(n_j, dtype=torch.uint8, device=self.device)
+        off = (1 << 40) + step * (Bg * 2 * d.H) + row_offset * 2 * d.H      # far beyond the two masks of make_keep_masks
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_joint2.data_ptr()), n_j, seed, off, d.keep_joint,
+                                             self._stream()), "vqa_dropout_mask")
+        return self._keep_joint2

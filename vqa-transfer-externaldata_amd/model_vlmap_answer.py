@@ -80,9 +80,11 @@ def answer_exist_mask(answer_dict, word_answer_dict=None):
     return mask
 
 
-def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_bias=-100.0):
+def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_bias=-100.0,
+                            weight_name="class_weights", bias_name="class_biases"):
     """modules.WordWeightAnswer (vlmap/modules.py:589-627): head initialised by answer-string
-    lookup into the exported class weights; missing answers get weight 0 and bias -100."""
+    lookup into the exported class weights (`weight_name` / `bias_name` datasets of weights.hdf5); missing answers get
+    weight 0 and bias -100."""
     dim = len(answer_dict["vocab"])
     weights = np.zeros([input_dim, dim], np.float32)
     biases = np.zeros([dim], np.float32) + default_bias
@@ -90,8 +92,8 @@ def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_b
         wd = word_weights["answer_dict"]["dict"]
         for i, a in enumerate(answer_dict["vocab"]):
             if a in wd:
-                weights[:, i] = word_weights["class_weights"][:, wd[a]]
-                biases[i] = word_weights["class_biases"][wd[a]]
+                weights[:, i] = word_weights[weight_name][:, wd[a]]
+                biases[i] = word_weights[bias_name][wd[a]]
     return weights, biases
 
 
@@ -101,14 +103,18 @@ def load_word_weight_dir(path):
     accepted as an alternative."""
     ad = _load_pickle(os.path.join(path, "answer_dict.pkl"))
     h5, npz = os.path.join(path, "weights.hdf5"), os.path.join(path, "weights.npz")
+    # class_* of export_word_weights.py; v_class_* / l_class_* of export_noc_word_weights.py:72-75 (model_vlmap_answer_noc)
+    wanted = ("class_weights", "class_biases", "v_class_weights", "v_class_biases", "l_class_weights", "l_class_biases")
     if os.path.exists(h5):
         with hdf5_io.File(h5) as f:
-            return {"answer_dict": ad, "class_weights": np.array(f["class_weights"]),
-                    "class_biases": np.array(f["class_biases"])}
-    if not os.path.exists(npz):
+            out = {k: np.array(f[k]) for k in wanted if k in f}
+    elif os.path.exists(npz):
+        z = np.load(npz)
+        out = {k: z[k] for k in wanted if k in z.files}
+    else:
         raise FileNotFoundError("neither weights.hdf5 nor weights.npz under %s" % path)
-    z = np.load(npz)
-    return {"answer_dict": ad, "class_weights": z["class_weights"], "class_biases": z["class_biases"]}
+    out["answer_dict"] = ad
+    return out
 
 
 def load_image_features(path):
@@ -142,7 +148,7 @@ class Model(object):
         self.device = torch.device(getattr(config, "device", "cuda:0"))
 
         self.word_weight_dir = getattr(config, "vlmap_word_weight_dir", None)
-        if self.word_weight_dir is None and self.MODEL_TYPE == "vlmap_answer":
+        if self.word_weight_dir is None and self.MODEL_TYPE in F.VLMAP_FAMILY:
             log.warning("word_weight_dir is None")
 
         self.losses, self.report, self.mid_result = {}, {}, {}
@@ -208,9 +214,14 @@ class Model(object):
                 p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
             else:
                 p[n] = np.zeros(s, np.float32)
-        if self.MODEL_TYPE == "vlmap_answer":      # the other heads keep their Xavier / zero initialisation
+        if self.MODEL_TYPE in ("vlmap_answer", "vlmap_answer_vqa_all2"):      # the other heads keep their Xavier / zero initialisation
             w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
             p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
+        elif self.MODEL_TYPE in F.NOC_FAMILY:      # WordWeightAnswerV / L from v_class_* / l_class_* (:190-202)
+            for hd, pre in ((sc["head"], "v_"), (sc["head2"], "l_")):
+                w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights,
+                                               weight_name=pre + "class_weights", bias_name=pre + "class_biases")
+                p[hd + "/fc/weights"], p[hd + "/fc/biases"] = w, b
         return p
 
     def _engine_kwargs(self):
@@ -280,6 +291,7 @@ class Model(object):
         else:
             self._engine.resize(B, T, gb)
         eng = self._engine
+        kj2 = None
         if getattr(self.config, "dropout_off", False):
             ka = kj = None
         else:   # tf.nn.dropout is applied unconditionally in the reference (also at eval time)
@@ -287,9 +299,12 @@ class Model(object):
             ka, kj = eng.make_keep_masks(int(getattr(self.config, "seed", 123)), self._step,
                                          row_offset=int(getattr(self.config, "shard_row_offset", 0) or 0),
                                          global_rows=gb)
+            if self.MODEL_TYPE in F.NOC_FAMILY:
+                kj2 = eng.make_keep_mask_joint2(int(getattr(self.config, "seed", 123)), self._step,
+                                                row_offset=int(getattr(self.config, "shard_row_offset", 0) or 0), global_rows=gb)
         self._step += 1
         self._db, self._keep = db, (ka, kj)
-        eng.forward(db, ka, kj, want_dz=self.is_train)
+        eng.forward(db, ka, kj, want_dz=self.is_train, keep_joint2=kj2)
 
         d = eng.dims
         A, R = d.A, d.R
