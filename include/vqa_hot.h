@@ -532,6 +532,10 @@ int vqa_probe_read_label(const char* label, float* ms_out, int capacity, int* n_
 int vqa_probe_labels(char* buf, int capacity);
 int vqa_probe_disable(void);
 int vqa_roctx_enable(int on);
+/* Enqueues a delay of `us` microseconds ON `stream` (one wave polling the 100 MHz real-time counter; 0 <= us <= 1e5).
+ * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
+ * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */
+int vqa_stream_delay_us(float us, void* stream);
 
 /* The same in dependency-ordered phases (bit mask): 1 = head..attention..v_linear_v / q_linear_v /
  * score gradients, 2 = GRU BPTT + embedding gradient + slice sum of squares, 4 = GRU gate weight / bias

@@ -117,6 +117,12 @@ Layout make_layout(const vqa_dims_t& d) {
     return L;
 }
 
+#define TRY(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != VQA_OK) return rc__; \
+    } while (0)
+
 struct Ctx {
     const vqa_dims_t& d;
     const Layout& L;
@@ -170,24 +176,74 @@ int side_max_blocks() {
     }
     return v;
 }
-// The recurrence is latency-bound (M = batch rows only); its two batch halves are independent
-// chains (LayerNorm and the GRU are per sample), so they run on two streams and fill each
-// other's launch / prologue / epilogue gaps.
-Side& gru_stream() {
-    static Side sd[64];
+// The recurrence is latency-bound (M = batch rows only): every one of its 2 T dependent step kernels pays ~7 us that
+// is not matrix work (drain, launch gap, kernel arguments, first tile, fused epilogue) against 7-14 us that is
+// (profiles/r3_gru_loop_variants.txt).  The rows of a batch are independent sequences, so the batch is cut into CHAINS
+// of rows that run on their own streams with small co-resident workgroups (32x32 tiles, 4 waves: several workgroups
+// of different chains share a CU) and -- the point -- in ANTI-PHASE: chain i starts i * delay later, so one chain's
+// boundary falls into the other chain's matrix work.  In phase (no delay) both chains compute at half rate and wait
+// together, and nothing is gained (profiles/r3_gru_split2.txt: one chain 558 us, two chains in phase 511-540, two chains
+// 8-16 us apart 491).  VQA_HOT_GRU_CHAINS (default 2; 1 = one chain on the caller's stream), VQA_HOT_GRU_CHAIN_DELAY_US
+// (default 10).
+struct Chains {
+    static constexpr int MAXC = 4;
+    hipStream_t s[MAXC] = {};
+    hipEvent_t fork = nullptr, join[MAXC] = {};
+    int n = 1;
+    float delay_us = 10.f;
+    bool tried = false;
+};
+Chains& gru_chains() {
+    static Chains ch[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    Side& x = sd[dev & 63];
+    Chains& x = ch[dev & 63];
     if (!x.tried) {
         x.tried = true;
-        const char* env = getenv("VQA_HOT_GRU_SPLIT");
-        if (env != nullptr && env[0] == '1') {
-            x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-        }
+        const char* e = getenv("VQA_HOT_GRU_CHAINS");
+        int want = e ? atoi(e) : 2;
+        if (want > Chains::MAXC) want = Chains::MAXC;
+        const char* d = getenv("VQA_HOT_GRU_CHAIN_DELAY_US");
+        if (d != nullptr) x.delay_us = (float)atof(d);
+        bool ok = want > 1 && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 1; ok && i < want; ++i)
+            ok = hipStreamCreateWithFlags(&x.s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&x.join[i], hipEventDisableTiming) == hipSuccess;
+        x.n = ok ? want : 1;
     }
     return x;
+}
+// rows [lo, hi) of chain i of n over B rows: boundaries on multiples of 32 (the step kernels' row tile)
+inline void chain_rows(int64_t B, int n, int i, int64_t* lo, int64_t* hi) {
+    const int64_t tiles = (B + 31) / 32;
+    const int64_t q = tiles / n, r = tiles % n;
+    const int64_t t0 = i * q + (i < r ? i : r), t1 = t0 + q + (i < r ? 1 : 0);
+    *lo = t0 * 32 < B ? t0 * 32 : B;
+    *hi = t1 * 32 < B ? t1 * 32 : B;
+}
+// runs fn(chain, row0, rows, stream) for every chain: chain 0 on the caller's stream, chain i > 0 on its own stream behind
+// a fork event and a delay of i * delay_us; the caller's stream waits for all of them at the end
+template <typename Fn>
+int run_chains(const Ctx& c, int64_t B, Fn fn) {
+    Chains& ch = gru_chains();
+    int n = ch.n;
+    while (n > 1 && B < 64 * (int64_t)n) --n;         // at least two row tiles per chain
+    if (n <= 1) return fn(0, (int64_t)0, B, c.st);
+    if (hipEventRecord(ch.fork, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+    for (int i = 1; i < n; ++i) {
+        int64_t lo, hi;
+        chain_rows(B, n, i, &lo, &hi);
+        if (hipStreamWaitEvent(ch.s[i], ch.fork, 0) != hipSuccess) return VQA_ERR_LAUNCH;
+        if (ch.delay_us > 0.f) TRY(vqa_stream_delay_us(ch.delay_us * (float)i, ch.s[i]));
+        TRY(fn(i, lo, hi - lo, ch.s[i]));
+        if (hipEventRecord(ch.join[i], ch.s[i]) != hipSuccess) return VQA_ERR_LAUNCH;
+    }
+    int64_t lo, hi;
+    chain_rows(B, n, 0, &lo, &hi);
+    TRY(fn(0, lo, hi - lo, c.st));
+    for (int i = 1; i < n; ++i)
+        if (hipStreamWaitEvent(c.st, ch.join[i], 0) != hipSuccess) return VQA_ERR_LAUNCH;
+    return VQA_OK;
 }
 // how V_ft = features[image_idx] is produced: 0 = a gather pass in front of v_linear_v's GEMM (default), 1 = fused
 // into that GEMM's operand load (VQA_FLAG_FUSED_GATHER or VQA_HOT_GATHER=fused).  Measured at bs 512
@@ -213,11 +269,6 @@ bool join_side(const Ctx& c, Side& sd) {
     return join_side_record(sd) && hipStreamWaitEvent(c.st, sd.join, 0) == hipSuccess;
 }
 
-#define TRY(x)                      \
-    do {                            \
-        int rc__ = (x);             \
-        if (rc__ != VQA_OK) return rc__; \
-    } while (0)
 
 int gemm(const Ctx& c, int tA, int tB, int64_t M, int64_t N, int64_t K, const float* A, int lda, const float* B,
          int ldb, float* C, int ldc, const float* bias = nullptr, const float* D = nullptr, int ldd = 0) {
@@ -386,20 +437,15 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     const float* Wc_h = P->gru_wc + W * H;
     {
         ProbeScope ps("gru.fwd", c.st);
-        Side& g2 = gru_stream();
-        const int64_t B0 = (B / 2 / 64) * 64;   // first half (multiple of the 64-row tile)
         if (bt->live_rows != nullptr) {          // rows sorted by length: skip finished sequences
             TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
                                      c.f("gru_c"), c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
-        } else if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
-            TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
-                                     c.f("gru_rh"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
-            TRY(vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
-                                     c.f("gru_rh"), (int)T, (int)B, (int)H, (int)B0, (int)(B - B0), g2.s));
-            if (!join_side(c, g2)) return VQA_ERR_LAUNCH;
-        } else {
-            TRY(vqa_gru_seq_fwd(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
-                                c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
+        } else {                                  // independent row chains in anti-phase (gru_chains)
+            float* gr = c.f("gru_r"); float* gu = c.f("gru_u"); float* gc = c.f("gru_c"); float* grh = c.f("gru_rh");
+            TRY(run_chains(c, B, [&](int, int64_t row0, int64_t rows, hipStream_t st) {
+                return vqa_gru_seq_fwd_rows(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, gr, gu, gc, grh, (int)T, (int)B, (int)H,
+                                            (int)row0, (int)rows, st);
+            }));
         }
     }
     const float* h = hs + T * B * H;
@@ -591,20 +637,16 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     const float* Wc_h = P->gru_wc + W * H;
     {
         ProbeScope ps("gru.bwd", c.st);
-        Side& g2 = gru_stream();
-        const int64_t B0 = (B / 2 / 64) * 64;
         if (bt->live_rows != nullptr) {
             TRY(vqa_gru_seq_bwd_live(dh, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
                                      c.f("gru_c"), dxp, c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
-        } else if (g2.ok && B0 > 0 && B0 < B && fork_side(c, g2)) {
-            TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
-                                     dxp, c.f("d_h1"), (int)T, (int)B, (int)H, 0, (int)B0, c.st));
-            TRY(vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"),
-                                     dxp, c.f("d_h1"), (int)T, (int)B, (int)H, (int)B0, (int)(B - B0), g2.s));
-            if (!join_side(c, g2)) return VQA_ERR_LAUNCH;
         } else {
-            TRY(vqa_gru_seq_bwd(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), dxp,
-                                c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
+            const float* gr = c.f("gru_r"); const float* gu = c.f("gru_u"); const float* gc = c.f("gru_c");
+            float* dh1 = c.f("d_h1");
+            TRY(run_chains(c, B, [&](int, int64_t row0, int64_t rows, hipStream_t st) {
+                return vqa_gru_seq_bwd_rows(dh, Wg_h, Wc_h, bt->q_intseq_len, hs, gr, gu, gc, dxp, dh1, (int)T, (int)B, (int)H,
+                                            (int)row0, (int)rows, st);
+            }));
         }
     }
     // embedding: un-aggregated slices dx [T,B,W], then scatter-add

@@ -7,7 +7,7 @@
 //   * opens a roctx range (roctxRangePushA / roctxRangePop) when ranges are on (vqa_roctx_enable(1) or VQA_HOT_ROCTX=1),
 //     so that `rocprofv3 --kernel-trace --marker-trace` groups the kernels by phase.  The roctx library is looked up at
 //     run time (rocprofiler-sdk's, then roctracer's); without it the ranges are silently off.
-// Host code only; no kernel lives here.
+// Host code, plus one one-wave kernel: the stream delay that staggers the recurrence's row chains.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -175,6 +175,22 @@ extern "C" int vqa_probe_labels(char* buf, int capacity) {
         buf[capacity - 1] = 0;
     }
     return (int)out.size() + 1;
+}
+
+// One wave that returns once `ticks` of the 100 MHz real-time counter have passed: a delay ON a stream (it holds one wave
+// slot and no other resource), used to start the row chains of the recurrence in anti-phase (csrc/fusion_model.hip).
+__global__ __launch_bounds__(64) void delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int vqa_stream_delay_us(float us, void* stream) {
+    VQA_REQUIRE(us >= 0.f && us <= 1e5f, VQA_ERR_ARG);
+    if (us == 0.f) return VQA_OK;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       (unsigned long long)(us * 100.f + 0.5f));
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
 }
 
 extern "C" int vqa_roctx_enable(int on) {
