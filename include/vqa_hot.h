@@ -532,6 +532,13 @@ int vqa_probe_read_label(const char* label, float* ms_out, int capacity, int* n_
 int vqa_probe_labels(char* buf, int capacity);
 int vqa_probe_disable(void);
 int vqa_roctx_enable(int on);
+/* EXPERIMENT (not on the default path): C[M,N] = A[M,K] * B[K,N] (+ bias) with every f32 operand split into three bf16
+ * pieces and six v_mfma_f32_32x32x16_bf16 products per a*b accumulated in f32 (f32-equivalent products at 6/16 of the f32
+ * MFMA's matrix time; csrc/gemm_bf16x3.hip).  Whole 128 x 128 x 32 tiles only (vqa_gemm_bf16x3_supported);
+ * VQA_ERR_UNSUPPORTED otherwise.  The replacement of layers.fully_connected stays vqa_gemm_f32 (exact f32 MFMA). */
+int vqa_gemm_bf16x3_supported(int M, int N, int K);
+int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                       const float* bias, void* stream);
 /* Enqueues a delay of `us` microseconds ON `stream` (one wave polling the 100 MHz real-time counter; 0 <= us <= 1e5).
  * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
  * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */

@@ -668,3 +668,24 @@ def test_persistent_gru_forward_equals_stepwise(T, B, H):
     assert lib.vqa_gru_fwd_persistent_supported(T, B, 300) == 0
     assert lib.vqa_gru_seq_fwd_persistent(P(xp), P(Wg), P(Wc), P(ln), P(outs[0][0]), P(outs[0][1]), P(outs[0][2]), P(outs[0][3]),
                                           P(outs[0][4]), T, B, 300, P(torch.zeros(64, dtype=torch.int32, device="cuda")), None) == -4
+
+
+def test_experimental_bf16x3_gemm_is_f32_equivalent():
+    """csrc/gemm_bf16x3.hip (experiment, not on the default path): three-way bf16 splits + six bf16 MFMA products per
+    a*b.  Its error against float64 must be of the order of the exact-f32 MFMA kernel's own (a few f32 ulps of the
+    accumulated magnitude), and shapes that are not whole tiles must be refused."""
+    from vqa_transfer_externaldata_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 256, 256, 2048
+    A = torch.randn(M, K, device="cuda", generator=g).relu_()
+    B = (torch.rand(K, N, device="cuda", generator=g) * 2 - 1) * 0.05
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = (A.double().cpu() @ B.double().cpu() + bias.double().cpu()).numpy()
+    e32 = np.abs(ops.gemm(A, B, bias=bias).double().cpu().numpy() - ref).max()
+    e3 = np.abs(ops.gemm_bf16x3(A, B, bias=bias).double().cpu().numpy() - ref).max()
+    scale = np.abs(ref).max()
+    assert e3 <= 4e-6 * scale and e3 <= 4 * e32 + 1e-6 * scale, (e3, e32, scale)
+    lib = _lib.load()
+    assert lib.vqa_gemm_bf16x3_supported(256, 256, 2048) == 1 and lib.vqa_gemm_bf16x3_supported(250, 256, 2048) == 0
+    with pytest.raises(_lib.VqaHotError):
+        ops.gemm_bf16x3(A[:250], B)

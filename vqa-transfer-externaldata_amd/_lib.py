@@ -159,6 +159,8 @@ SIGNATURES = {
     "vqa_probe_labels": (_I, [C.c_char_p, _I]),
     "vqa_roctx_enable": (_I, [_I]),
     "vqa_stream_delay_us": (_I, [_F, _P]),
+    "vqa_gemm_bf16x3_supported": (_I, [_I, _I, _I]),
+    "vqa_gemm_bf16x3_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
     "vqa_probe_disable": (_I, []),
     "vqa_fusion_workspace_bytes": (_L, [C.POINTER(Dims)]),
     "vqa_fusion_tensor": (_I, [C.POINTER(Dims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
