@@ -213,7 +213,7 @@ def test_vqa_all2_variant_trains_through_the_trainer_and_evaluates(tmp_path):
     transfer sets of vqa/model_vlmap_answer_vqa_all2.py:85-105, a loss that drops because the TunedWordWeightAnswer
     head trains (the fixed head stays at -100 without a word-weight directory), then the Evaler on a checkpoint."""
     from vqa_transfer_externaldata_amd import evaler, trainer
-    c, Vq, A = _config(tmp_path, "vlmap_answer_vqa_all2")
+    c, Vq, A = _config(tmp_path, "vlmap_answer_vqa_all2", learning_rate=1e-4)     # (2e-3 overshoots the fresh 2048-wide head)
     ds = _datasets(Vq, A)
     t = trainer.Trainer(c, datasets=ds, image_features=_features())
     assert not any(v.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer") for v in t.train_vars)
