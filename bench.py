@@ -173,7 +173,7 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=5):
 
 # v_linear_v forward GEMM: 128x64 tiles, 8 waves of 32x32 (cfg 20), NN layout, plain epilogue -> 144 x 16 = 2304 workgroups
 ROOFLINE_KERNEL = "gemm_f32_kernel<128,64,32,32,1,32,0,true,false,0,false,false,512,false>"
-PMC_TRAFFIC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
 def name_of(path):
