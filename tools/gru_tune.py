@@ -117,27 +117,45 @@ if os.environ.get("SPLIT2") == "1":
     half = B // 2
     clock_hz = 2.1e9     # torch.cuda._sleep counts device cycles; only the relative delays matter
 
+    NCH = int(os.environ.get("SPLIT_CHAINS", 2))
+    streams = [torch.cuda.Stream() for _ in range(NCH)]
+    tiles = (B + 31) // 32
+    bounds = [min(B, 32 * ((tiles * i) // NCH)) for i in range(NCH + 1)]
+    DIR = os.environ.get("SPLIT_DIR", "fwd")
+
+    def enqueue(row0, rows, st):
+        if DIR == "fwd":
+            _lib.check(lib.vqa_gru_seq_fwd_rows(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, row0, rows,
+                                                C.c_void_p(st.cuda_stream)), "fwd_rows")
+        else:
+            _lib.check(lib.vqa_gru_seq_bwd_rows(P(dhT), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(dxp), P(dhs), T, B, H,
+                                                row0, rows, C.c_void_p(st.cuda_stream)), "bwd_rows")
+
     def run(delay_us, cfg, n=10):
         ts = []
         for _ in range(n):
+            if DIR != "fwd":
+                dhT.copy_(dhT0)
             torch.cuda.synchronize()
             _lib.check(lib.vqa_gemm_set_gru_config(cfg), "cfg")
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             gate = torch.cuda.Event()
-            torch.cuda._sleep(int(400e-6 * clock_hz))
+            torch.cuda._sleep(int(600e-6 * clock_hz))           # hold every stream back until everything is enqueued
             gate.record()
-            s1.wait_event(gate); s2.wait_event(gate)
-            with torch.cuda.stream(s1):
-                t0.record()
-                _lib.check(lib.vqa_gru_seq_fwd_rows(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, 0, half,
-                                                    C.c_void_p(s1.cuda_stream)), "fwd_rows")
-                d1 = torch.cuda.Event(); d1.record()
-            with torch.cuda.stream(s2):
-                if delay_us > 0:
-                    torch.cuda._sleep(int(delay_us * 1e-6 * clock_hz))
-                _lib.check(lib.vqa_gru_seq_fwd_rows(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, half,
-                                                    B - half, C.c_void_p(s2.cuda_stream)), "fwd_rows")
-                s2.wait_event(d1)
+            done = []
+            for i, st in enumerate(streams):
+                st.wait_event(gate)
+                with torch.cuda.stream(st):
+                    if i == 0:
+                        t0.record()
+                    elif delay_us > 0:
+                        _lib.check(lib.vqa_stream_delay_us(delay_us * i, C.c_void_p(st.cuda_stream)), "delay")
+                    enqueue(bounds[i], bounds[i + 1] - bounds[i], st)
+                    if i > 0:
+                        e = torch.cuda.Event(); e.record(); done.append(e)
+            with torch.cuda.stream(streams[0]):
+                for e in done:
+                    streams[0].wait_event(e)
                 t1.record()
             torch.cuda.synchronize()
             ts.append(t0.elapsed_time(t1) * 1e3)
@@ -146,14 +164,14 @@ if os.environ.get("SPLIT2") == "1":
     fwd(); torch.cuda.synchronize()
     ref = hs[T].clone()
     _lib.check(lib.vqa_gemm_set_gru_config(-1), "cfg")
-    print("one chain, one stream (product path): %.1f us" % tm(fwd), flush=True)
+    print("one chain, one stream: %.1f us (%s)" % (tm(fwd if DIR == "fwd" else bwd), DIR), flush=True)
     for cfg in [int(x) for x in os.environ.get("SPLIT2_CFGS", "16,9,11,7,8").split(",")]:
         for delay in [float(x) for x in os.environ.get("SPLIT2_DELAYS", "0,4,8,12,16,24").split(",")]:
             hs[1:].zero_()
             best, med = run(delay, cfg)
             err = float((hs[T] - ref).abs().max())
-            print("two chains on two streams, cfg %2d, chain 2 delayed %4.1f us: both done after %.1f us (median %.1f)  max |h - ref| %.1e"
-                  % (cfg, delay, best, med, err), flush=True)
+            print("%d chains on %d streams (%s), cfg %2d, chain i delayed i x %4.1f us: all done after %.1f us (median %.1f)  max |h - ref| %.1e"
+                  % (NCH, NCH, DIR, cfg, delay, best, med, err), flush=True)
     _lib.check(lib.vqa_gemm_set_gru_config(-1), "cfg")
     sys.exit(0)
 
