@@ -282,10 +282,18 @@ int vqa_loss_fwd(const float* z, const float* target, const float* train_mask, c
  * TunedWordWeightAnswer logits): stats[.,LOSS_TRAIN] = sum_a ce(z_fixed)*train_mask + ce(z_tuned), [.,LOSS_REPORT] =
  * sum_a ce(z_fixed) + ce(z_tuned); pred = first argmax of z_fixed*(1-train_mask) + z_tuned*train_mask; the other
  * statistics as in vqa_loss_fwd on that prediction; dz_fixed = (sigmoid(z_fixed)-t)*train_mask*inv_batch, dz_tuned =
- * (sigmoid(z_tuned)-t)*inv_batch (both or neither NULL); z_sum (may be NULL) = z_fixed + z_tuned = output['logit']. */
+ * (sigmoid(z_tuned)-t)*inv_batch (both or neither NULL); z_sum (may be NULL) = z_fixed + z_tuned = output['logit'].
+ * sum_mode != 0: the form of vqa/model_vlmap_answer_vqa_all.py:234-244 -- the tuned term is ce(z_fixed + z_tuned) and both
+ * terms are train-masked in the training loss; pred = argmax(z_fixed + z_tuned); dz_fixed = d loss / d z_fixed (both terms),
+ * dz_tuned = the tuned term's. */
 int vqa_loss2_fwd(const float* z_fixed, const float* z_tuned, const float* target, const float* train_mask,
                   const float* obj_mask, const float* attr_mask, const float* exist_mask, float inv_batch, float* stats,
-                  int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int B, int A, void* stream);
+                  int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int sum_mode, int B, int A, void* stream);
+/* vqa/model_vlmap_answer_vqa_all.py:192-194: z_masked = z * exist + rowmin(z) * (1 - exist) (answers the word-weight
+ * directory does not know sit at the row minimum), rowmin [B]; and its backward in place on dz (tf.reduce_min's
+ * gradient goes to the minimum, split evenly over ties). */
+int vqa_rowmin_mask_fwd(const float* z, const float* exist_mask, float* z_masked, float* rowmin, int B, int A, void* stream);
+int vqa_rowmin_mask_bwd(float* dz, const float* z, const float* rowmin, const float* exist_mask, int B, int A, void* stream);
 /* n-way softmax cross-entropy with a validity mask + top-1 / top-k hits (n_way_classification_loss,
  * vlmap_memft/model_vlmap_bf_or_wordset_withatt_sp.py:675-706).  z [rows,A], label i32[rows], valid f32[rows];
  * stats [rows,4] = {ce*valid, top1*valid, topk*valid, valid}; dz = (softmax-onehot)*valid*inv_valid_sum[0]
@@ -327,6 +335,8 @@ typedef struct {
                               * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268),
                               * 4 = vlmap_answer_vqa_all2 (= 0 + the trainable TunedWordWeightAnswer head, summed logits,
                               * two-term loss, mixed-mask argmax: vqa/model_vlmap_answer_vqa_all2.py:196-244),
+                              * 6 = vlmap_answer_vqa_all (= 4 with unknown answers' fixed logits at the row minimum, the
+                              * tuned loss on the summed logits, both terms train-masked, argmax of the sum),
                               * 5 = vlmap_answer_noc / _nocarch (two un-composed branches joint_v(pooled_linear_l) and
                               * joint_l(l_linear_l) with their own heads, logits summed: vqa/model_vlmap_answer_noc.py:177-204) */
     float keep_att;          /* 0.8  vlmap/modules.py:82 */

@@ -95,6 +95,17 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     z = F.linear(j, P[sc["head"] + "/fc/weights"].t(), P[sc["head"] + "/fc/biases"])
     if model_type == "standard_word2vec":
         z = z @ P[sc["glove"]].detach()
+    if model_type == "vlmap_answer_vqa_all":        # vqa/model_vlmap_answer_vqa_all.py:188-244, composed independently
+        z2 = F.linear(j, P[sc["head2"] + "/fc/weights"].t(), P[sc["head2"] + "/fc/biases"])
+        train, exist = _t(answer_masks["train"], dtype), _t(answer_masks["exist"], dtype)
+        z1m = torch.where(exist > 0, z, z.amin(dim=1, keepdim=True).expand_as(z))
+        per_answer = (F.binary_cross_entropy_with_logits(z1m, tgt, reduction="none")
+                      + F.binary_cross_entropy_with_logits(z1m + z2, tgt, reduction="none")) * train
+        loss = per_answer.sum(-1).mean()
+        mid = {"v_linear_v": v, "condition": h, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
+               "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z1m + z2, "embed": e,
+               "pred": torch.argmax(z1m + z2, dim=-1)}
+        return loss, mid
     if model_type == "vlmap_answer_vqa_all2":       # vqa/model_vlmap_answer_vqa_all2.py:216-241, composed independently
         z2 = F.linear(j, P[sc["head2"] + "/fc/weights"].t(), P[sc["head2"] + "/fc/biases"])
         train = _t(answer_masks["train"], dtype)

@@ -64,7 +64,12 @@ TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask", "
 NOC_FAMILY = ("vlmap_answer_noc", "vlmap_answer_nocarch")
 FROZEN_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV", "WordWeightAnswerL")
 TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l")
-VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2") + NOC_FAMILY
+# vqa/model_vlmap_answer_vqa_all.py = _vqa_all2 except (diff of the two files): the fixed logits of answers the word-weight
+# directory does not know are replaced by the row minimum of the fixed logits (:192-194); the tuned loss is taken on the
+# SUM, ce(logit + tuned_logit) (:236-237); the training loss masks both terms, sum_a (untuned + tuned) * train_mask
+# (:241-242); pred = argmax(logit + tuned_logit) (:244)
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2") + NOC_FAMILY
+TWO_HEAD_FAMILY = ("vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")
 # report keys of vqa/model_standard_testmask.py:295-304 in terms of the 13 keys of the current models
 TESTMASK_REPORT = {"answer_train_loss": "answer_train_loss", "answer_report_loss": "answer_report_loss",
                    "answer_accuracy": "answer_acc", "exist_answer_accuracy": "exist_acc",
@@ -193,7 +198,7 @@ def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=
                 fc(hd, 2 * H, A, False)
         return p
     fc(sc["joint_fc"], H, 2 * H, True)
-    if model_type == "vlmap_answer_vqa_all2":
+    if model_type in TWO_HEAD_FAMILY:
         fc(sc["tuned_q_linear_l"], H, H, True)
         fc(sc["tuned_joint_fc"], H, 2 * H, True)
         fc(sc["head2"], 2 * H, A, False)                    # fc_layer(joint, num_answer, use_bias=True), Xavier / zero
@@ -369,6 +374,18 @@ def loss_and_report(z, tgt, answer_masks, model_type):
     return train_loss, report, out, ell
 
 
+def loss_and_report_all1(z1m, z2, tgt, answer_masks):
+    """vqa/model_vlmap_answer_vqa_all.py:228-339: z1m = fixed logits with unknown answers at the row minimum, z2 = tuned
+    logits; loss terms ce(z1m) and ce(z1m + z2), BOTH masked by the train-answer mask in the training loss; pred from the sum."""
+    train = answer_masks["train"]
+    ell = sigmoid_ce(z1m, tgt) + sigmoid_ce(z1m + z2, tgt)
+    _, report, out, _ = loss_and_report(z1m + z2, tgt, answer_masks, "standard")
+    train_loss = (ell * train).sum(axis=1).mean()
+    report["answer_train_loss"] = train_loss
+    report["answer_report_loss"] = ell.sum(axis=1).mean()
+    return train_loss, report, out
+
+
 def loss_and_report_all2(z1, z2, tgt, answer_masks):
     """vqa/model_vlmap_answer_vqa_all2.py:232-339: z1 = fixed WordWeightAnswer logits, z2 = TunedWordWeightAnswer logits.
     train loss = mean_B sum_A (ce(z1) * train_mask + ce(z2)); report loss = mean_B sum_A (ce(z1) + ce(z2));
@@ -439,10 +456,17 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
         z = j2 @ params[sc["glove"]]
     z1 = z2 = None
     extra_mid = {}
-    if model_type == "vlmap_answer_vqa_all2":
+    z1_raw = None
+    if model_type in TWO_HEAD_FAMILY:
         z1 = z
         z2 = fc_forward(j, params[sc["head2"] + "/fc/weights"], params[sc["head2"] + "/fc/biases"])   # reads `joint` (:216-217)
-        loss, report, out = loss_and_report_all2(z1, z2, batch["answer_target"], answer_masks)
+        if model_type == "vlmap_answer_vqa_all":
+            z1_raw = z1
+            ex = answer_masks["exist"]
+            z1 = z1 * ex + z1.min(axis=1, keepdims=True) * (dt(1) - ex)                # :192-194
+            loss, report, out = loss_and_report_all1(z1, z2, batch["answer_target"], answer_masks)
+        else:
+            loss, report, out = loss_and_report_all2(z1, z2, batch["answer_target"], answer_masks)
         z = z1 + z2                                                                    # output['logit'] (:226-227)
         # the dead branch (:202-214), for mid_result only: needs its own dropout mask when asked for
         tll, _ = fc_ln_relu_forward(h, params, sc["tuned_q_linear_l"])
@@ -460,7 +484,7 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
     mid.update(extra_mid)
     tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att,
                 feat=feat, p=p, pl=pl, t_pl=t_pl, ll=ll, t_ll=t_ll, jin=jin, j0=j0, t_j=t_j,
-                j=j, z=z, j2=j2, z1=z1, z2=z2)
+                j=j, z=z, j2=j2, z1=z1, z2=z2, z1_raw=z1_raw)
     return loss, report, out, mid, tape
 
 
@@ -499,11 +523,22 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     z = tape["z"]
     B = z.shape[0]
     tgt = batch["answer_target"]
-    if model_type == "vlmap_answer_vqa_all2":
+    if model_type in TWO_HEAD_FAMILY:
         z = tape["z1"]
     dz = (sigmoid(z) - tgt) / dt(B)
-    if model_type in TRAIN_MASKED_LOSS or model_type == "vlmap_answer_vqa_all2":
+    if model_type in TRAIN_MASKED_LOSS or model_type in TWO_HEAD_FAMILY:
         dz = dz * answer_masks["train"]
+    dz2 = None
+    if model_type == "vlmap_answer_vqa_all":
+        dz2 = (sigmoid(tape["z1"] + tape["z2"]) - tgt) / dt(B) * answer_masks["train"]      # the tuned term sees the SUM, masked
+        dz = dz + dz2                                                                       # d loss / d (masked fixed logits)
+        # back through logit * exist + min(logit) * (1 - exist): tf.reduce_min hands its gradient to the minimum, split
+        # evenly over ties
+        ex = answer_masks["exist"]
+        raw = tape["z1_raw"]
+        is_min = (raw == raw.min(axis=1, keepdims=True)).astype(raw.dtype)
+        to_min = (dz * (dt(1) - ex)).sum(axis=1, keepdims=True)
+        dz = dz * ex + is_min * (to_min / is_min.sum(axis=1, keepdims=True))
     if model_type in NOC_FAMILY:
         for hd, jt in ((sc["headV"], "vj"), (sc["headL"], "lj")):
             g[hd + "/fc/weights"] = tape[jt].T @ dz
@@ -520,8 +555,9 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     g[sc["head"] + "/fc/weights"] = tape["j"].T @ dz
     g[sc["head"] + "/fc/biases"] = dz.sum(axis=0)
     dj = dz @ Wh.T
-    if model_type == "vlmap_answer_vqa_all2":
-        dz2 = (sigmoid(tape["z2"]) - tgt) / dt(B)               # the tuned term of the loss is not masked (:240-241)
+    if model_type in TWO_HEAD_FAMILY:
+        if dz2 is None:
+            dz2 = (sigmoid(tape["z2"]) - tgt) / dt(B)           # _all2: the tuned term of the loss is not masked (:240-241)
         g[sc["head2"] + "/fc/weights"] = tape["j"].T @ dz2
         g[sc["head2"] + "/fc/biases"] = dz2.sum(axis=0)
         dj = dj + dz2 @ params[sc["head2"] + "/fc/weights"].T

@@ -38,7 +38,7 @@ def grad_close(got, want, name, tol=5e-4):
 
 
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
-                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc"])
+                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc", "vlmap_answer_vqa_all"])
 @pytest.mark.parametrize("cfg", [("small", SMALL, 5, 6, 7, 9), ("med", MED, 32, 36, 14, 64),
                                  ("cfg1_full_dims", FULL, 8, 36, 14, 24)])
 def test_forward_backward_match_oracle(model_type, cfg):
@@ -112,6 +112,32 @@ def test_vqa_all2_two_heads_and_dead_branch():
     got = eng.params["TunedWordWeightAnswer/fc/weights"].cpu().numpy()
     assert np.abs(got - p["TunedWordWeightAnswer/fc/weights"]).max() > 1e-4
     assert np.mean(np.abs(got - pp["TunedWordWeightAnswer/fc/weights"]) > 1e-4) < 0.02
+
+
+def test_vqa_all_row_minimum_substitution_on_the_gpu():
+    """model_type 6 (vqa/model_vlmap_answer_vqa_all.py:192-194, 234-244): unknown answers' fixed logits at the row minimum
+    (bit for bit the raw logits' minimum), the summed logits, their argmax, and the frozen head's bias gradient -- which
+    exists only through the minimum -- against the oracle."""
+    mt, dims, B, R, T, N = "vlmap_answer_vqa_all", MED, 24, 36, 14, 32
+    p, table, nbox, batch, am, masks = make_case(71, mt, B, R, T, N, dims)
+    eng = make_engine(mt, p, table, nbox, am, B, R, T, dims)
+    run_engine(eng, batch, masks)
+    raw = eng.tensor("logit_raw").view(B, -1).cpu().numpy()
+    fixed = eng.tensor("logit_fixed").view(B, -1).cpu().numpy()
+    ex = am["exist"]
+    assert (ex == 0).any()
+    np.testing.assert_array_equal(fixed, np.where(ex > 0, raw, raw.min(axis=1, keepdims=True)))
+    np.testing.assert_array_equal(eng.tensor("rowmin").cpu().numpy(), raw.min(axis=1))
+    z = eng.tensor("logit").view(B, -1).cpu().numpy()
+    np.testing.assert_array_equal(z, fixed + eng.tensor("logit_tuned").view(B, -1).cpu().numpy())
+    np.testing.assert_array_equal(eng.tensor("pred").cpu().numpy(), z.argmax(1))
+    loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am), to64(masks), mt)
+    np.testing.assert_array_equal(eng.tensor("pred").cpu().numpy(), out["pred"])
+    # d loss / d raw fixed logits after the in-place backward of the substitution
+    grads, _ = O.backward(to64(p), to64(batch), to64(am), to64(masks), tape, mt)
+    dl = eng.tensor("dlogit").view(B, -1).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(dl.sum(0), grads["WordWeightAnswer/fc/biases"], rtol=0,
+                               atol=5e-4 * np.abs(grads["WordWeightAnswer/fc/biases"]).max())
 
 
 def test_train_steps_match_oracle_f32():

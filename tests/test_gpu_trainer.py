@@ -208,12 +208,13 @@ def test_standard_testmask_trains_and_reports_its_nine_scalars(tmp_path):
     assert set(vreport) == keys and loss1 < loss0
 
 
-def test_vqa_all2_variant_trains_through_the_trainer_and_evaluates(tmp_path):
-    """`--model_type vlmap_answer_vqa_all2` (the variant run_vqa_all_non_standard.py:95 launches): Trainer loop, the frozen /
+@pytest.mark.parametrize("model_type", ["vlmap_answer_vqa_all2", "vlmap_answer_vqa_all"])
+def test_vqa_all2_variant_trains_through_the_trainer_and_evaluates(tmp_path, model_type):
+    """`--model_type vlmap_answer_vqa_all2` (the variant run_vqa_all_non_standard.py:95 launches) and its sibling _vqa_all: Trainer loop, the frozen /
     transfer sets of vqa/model_vlmap_answer_vqa_all2.py:85-105, a loss that drops because the TunedWordWeightAnswer
     head trains (the fixed head stays at -100 without a word-weight directory), then the Evaler on a checkpoint."""
     from vqa_transfer_externaldata_amd import evaler, trainer
-    c, Vq, A = _config(tmp_path, "vlmap_answer_vqa_all2", learning_rate=3e-4)     # (2e-3 overshoots the fresh 2048-wide head)
+    c, Vq, A = _config(tmp_path, model_type, learning_rate=3e-4)     # (2e-3 overshoots the fresh 2048-wide head)
     ds = _datasets(Vq, A)
     t = trainer.Trainer(c, datasets=ds, image_features=_features())
     assert not any(v.split("/")[0] in ("q_linear_l", "pooled_linear_l", "joint_fc", "WordWeightAnswer") for v in t.train_vars)

@@ -59,7 +59,8 @@ def test_log_message_format():
 
 def test_importer_registry():
     assert importer.get_model_types() == ["standard", "standard_testmask", "standard_word2vec", "vlmap_answer",
-                                          "vlmap_answer_noc", "vlmap_answer_nocarch", "vlmap_answer_vqa_all2"]
+                                          "vlmap_answer_noc", "vlmap_answer_nocarch", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2"]
+    assert importer.get_model_class("vlmap_answer_") is importer.get_model_class("vlmap_answer_vqa_all")      # vqa/importer.py:33
     assert importer.get_model_class("vlmap_answer_nocarch").__mro__[1] is importer.get_model_class("vlmap_answer_noc")
     assert importer.get_model_class("vlmap_answer_vqa_all2").MODEL_TYPE == "vlmap_answer_vqa_all2"
     with pytest.raises(ValueError, match="out of scope"):

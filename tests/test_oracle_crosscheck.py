@@ -21,7 +21,7 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
 
 
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
-                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc"])
+                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc", "vlmap_answer_vqa_all"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -74,6 +74,36 @@ def test_vqa_all2_known_answers():
     out2 = O.forward(p2, batch, table, nbox, am, masks, mt)[2]
     mixed = np.where(train > 0, z2, -100.0)
     np.testing.assert_array_equal(out2["pred"], np.argmax(mixed, axis=1))
+
+
+def test_vqa_all_row_min_substitution_and_masked_sum_loss():
+    """vqa/model_vlmap_answer_vqa_all.py: fixed logits of answers unknown to the word-weight directory sit at the row
+    minimum (:192-194), both loss terms are train-masked and the tuned one sees the sum (:234-242), pred = argmax of the sum."""
+    mt = "vlmap_answer_vqa_all"
+    p, table, nbox, batch, am, masks = _case(41, mt)
+    assert (am["exist"] == 0).any() and (am["exist"] == 1).any()
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    z1 = mid["joint"] @ p["WordWeightAnswer/fc/weights"] + p["WordWeightAnswer/fc/biases"]
+    z2 = mid["joint"] @ p["TunedWordWeightAnswer/fc/weights"] + p["TunedWordWeightAnswer/fc/biases"]
+    z1m = np.where(am["exist"] > 0, z1, z1.min(axis=1, keepdims=True))
+    np.testing.assert_allclose(mid["logit"], z1m + z2, rtol=1e-12)
+    tgt = batch["answer_target"]
+    ell = O.sigmoid_ce(z1m, tgt) + O.sigmoid_ce(z1m + z2, tgt)
+    assert report["answer_train_loss"] == pytest.approx((ell * am["train"]).sum(1).mean(), rel=1e-12)
+    assert report["answer_report_loss"] == pytest.approx(ell.sum(1).mean(), rel=1e-12)
+    np.testing.assert_array_equal(out["pred"], np.argmax(z1m + z2, axis=1))
+    # with every answer known the substitution is the identity
+    am1 = dict(am, exist=np.ones_like(am["exist"]))
+    l1 = O.forward(p, batch, table, nbox, am1, masks, mt)[3]["logit"]
+    np.testing.assert_allclose(l1, z1 + z2, rtol=1e-12)
+    # finite differences through the min (the FROZEN head's bias at the arg-min answer of row 0 moves every unknown answer)
+    grads, _ = O.backward(p, batch, am, masks, tape, mt)
+    a = int(np.argmin(z1[0]))
+    name, eps = "WordWeightAnswer/fc/biases", 1e-6
+    pp = {k: v.copy() for k, v in p.items()}
+    pp[name][a] += eps; lp = O.forward(pp, batch, table, nbox, am, masks, mt)[0]
+    pp[name][a] -= 2 * eps; lm = O.forward(pp, batch, table, nbox, am, masks, mt)[0]
+    assert abs((lp - lm) / (2 * eps) - grads[name][a]) <= 1e-6 + 1e-5 * abs(grads[name][a])
 
 
 def test_noc_variant_known_answers():

@@ -140,7 +140,9 @@ SIGNATURES = {
     "vqa_attn_pool_fwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_attn_pool_bwd_rep": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _P]),
-    "vqa_loss2_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vqa_loss2_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_rowmin_mask_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "vqa_rowmin_mask_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "vqa_report_reduce": (_I, [_P, _I, _P, _P]),
     "vqa_report_key": (C.c_char_p, [_I]),
     "vqa_sumsq": (_I, [_P, _L, _P, _P, _P, _L, _P]),

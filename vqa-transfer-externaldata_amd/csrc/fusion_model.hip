@@ -68,9 +68,10 @@ Layout make_layout(const vqa_dims_t& d) {
         L.add("pre_jl", B * 2 * H); L.add("l_joint", B * 2 * H); L.add("mean_jl", B); L.add("rstd_jl", B);
         L.add("d_ljoint", B * 2 * H); L.add("d_pre_jl", B * 2 * H);
     }
-    if (d.model_type == 4) {     // vlmap_answer_vqa_all2: the two heads' logits ("logit" = their sum) and the tuned head's dz
+    if (d.model_type == 4 || d.model_type == 6) {     // vlmap_answer_vqa_all2 / _vqa_all: the two heads' logits ("logit" = their sum), the tuned head's dz
         L.add("logit_fixed", B * A); L.add("logit_tuned", B * A); L.add("dlogit_tuned", B * A);
     }
+    if (d.model_type == 6) { L.add("logit_raw", B * A); L.add("rowmin", B); }      // before the row-minimum substitution
     L.add("stats", B * VQA_STAT_COUNT);
     L.add("pred", B);
     L.add("report", 16);
@@ -283,7 +284,7 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 5;
+           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 6;
 }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
@@ -495,12 +496,16 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit"), (int)A, P->head.b));
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("l_joint"), (int)(2 * H), P->head2.w, (int)A, c.f("logit"), (int)A, P->head2.b,
                  c.f("logit"), (int)A));
-    } else if (dims->model_type == 4) {
+    } else if (dims->model_type == 4 || dims->model_type == 6) {
         // vlmap_answer_vqa_all2 (vqa/model_vlmap_answer_vqa_all2.py:196-227): the fixed WordWeightAnswer head and the
-        // trainable TunedWordWeightAnswer head, BOTH on `joint` (the reference's tuned head reads `joint`, :216-217)
+        // trainable TunedWordWeightAnswer head, BOTH on `joint` (the reference's tuned head reads `joint`, :216-217);
+        // _vqa_all: the same with the fixed logits of unknown answers moved to the row minimum (:192-194)
         VQA_REQUIRE(P->head2.w != nullptr && P->head2.b != nullptr, VQA_ERR_ARG);
         ProbeScope ps("head.fwd_gemm", c.st);
-        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A, c.f("logit_fixed"), (int)A, P->head.b));
+        TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head.w, (int)A,
+                 c.f(dims->model_type == 6 ? "logit_raw" : "logit_fixed"), (int)A, P->head.b));
+        if (dims->model_type == 6)
+            TRY(vqa_rowmin_mask_fwd(c.f("logit_raw"), bt->exist_mask, c.f("logit_fixed"), c.f("rowmin"), (int)B, (int)A, c.st));
         TRY(gemm(c, 0, 0, B, A, 2 * H, c.f("joint"), (int)(2 * H), P->head2.w, (int)A, c.f("logit_tuned"), (int)A, P->head2.b));
     } else {
         ProbeScope ps("head.fwd_gemm", c.st);
@@ -508,11 +513,11 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     }
     // a11 (the train loss is masked by the train-answer mask in vlmap_answer and standard_word2vec, not in standard)
     ProbeScope ps("loss.fwd", c.st);
-    if (dims->model_type == 4)
+    if (dims->model_type == 4 || dims->model_type == 6)
         TRY(vqa_loss2_fwd(c.f("logit_fixed"), c.f("logit_tuned"), bt->answer_target, bt->train_mask, bt->obj_mask,
                           bt->attr_mask, bt->exist_mask, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
-                          want_dz ? c.f("dlogit") : nullptr, want_dz ? c.f("dlogit_tuned") : nullptr, c.f("logit"), (int)B,
-                          (int)A, c.st));
+                          want_dz ? c.f("dlogit") : nullptr, want_dz ? c.f("dlogit_tuned") : nullptr, c.f("logit"),
+                          dims->model_type == 6 ? 1 : 0, (int)B, (int)A, c.st));
     else
         TRY(vqa_loss_fwd(c.f("logit"), bt->answer_target, bt->train_mask, bt->obj_mask, bt->attr_mask, bt->exist_mask,
                          dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
@@ -561,13 +566,15 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         }
         TRY(gemm(c, 0, 1, B, 2 * H, W, c.f("d_joint2"), (int)W, P->head.w, (int)W, c.f("d_joint"), (int)(2 * H)));
     } else {
+    if (dims->model_type == 6)       // back through the row-minimum substitution, in place (dlogit was taken wrt the masked logits)
+        TRY(vqa_rowmin_mask_bwd(c.f("dlogit"), c.f("logit_raw"), c.f("rowmin"), bt->exist_mask, (int)B, (int)A, c.st));
     // head: logit = joint*W + b
     if (G->head.w != nullptr) {
         TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit"), (int)A, G->head.w, (int)A));
         TRY(colsum(c, c.f("dlogit"), B, A, (int)A, G->head.b));
     }
     TRY(gemm(c, 0, 1, B, 2 * H, A, c.f("dlogit"), (int)A, P->head.w, (int)A, c.f("d_joint"), (int)(2 * H)));
-    if (dims->model_type == 4) {     // the tuned head: its own weights train, and its dz joins d_joint (unmasked term of the loss)
+    if (dims->model_type == 4 || dims->model_type == 6) {     // the tuned head: its own weights train, and its dz joins d_joint (unmasked term of the loss)
         VQA_REQUIRE(P->head2.w != nullptr, VQA_ERR_ARG);
         if (G->head2.w != nullptr) {
             TRY(gemm(c, 1, 0, 2 * H, A, B, c.f("joint"), (int)(2 * H), c.f("dlogit_tuned"), (int)A, G->head2.w, (int)A));

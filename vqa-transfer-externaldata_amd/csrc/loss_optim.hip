@@ -21,10 +21,13 @@ __device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b) {
     return a;
 }
 
-// TWO: the two-headed form of vqa/model_vlmap_answer_vqa_all2.py:226-244 -- z = fixed head, z2 = tuned head:
+// TWO = 1: the two-headed form of vqa/model_vlmap_answer_vqa_all2.py:226-244 -- z = fixed head, z2 = tuned head:
 // loss = ce(z) * train_mask + ce(z2), report loss = ce(z) + ce(z2), pred = argmax(z * test_mask + z2 * train_mask),
 // dz = d ce(z) * train_mask, dz2 = d ce(z2) (unmasked), zsum = z + z2 (output['logit'])
-template <bool TWO>
+// TWO = 2: vqa/model_vlmap_answer_vqa_all.py:234-244 -- the tuned term sees the SUM and both terms are train-masked:
+// loss = (ce(z) + ce(z + z2)) * train_mask, report loss the same unmasked, pred = argmax(z + z2),
+// dz = (d ce(z) + d ce(z + z2)) * train_mask, dz2 = d ce(z + z2) * train_mask
+template <int TWO>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ z, const float* __restrict__ z2,
                                                        const float* __restrict__ tgt,
                                                        const float* __restrict__ train_m,
@@ -53,9 +56,21 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
         if (dz != nullptr) {
             float g = (sigmoidf_stable(x) - t) * inv_batch;
             if (use_train_mask || TWO) g *= tr;
-            dz[(int64_t)b * A + a] = g;
+            if (TWO != 2) dz[(int64_t)b * A + a] = g;
         }
-        if (TWO) {
+        if (TWO == 2) {
+            const float y = x + z2[(int64_t)b * A + a];
+            const float ell2 = fmaxf(y, 0.f) - y * t + log1pf(expf(-fabsf(y)));
+            l_all += ell + ell2;
+            l_train += (ell + ell2) * tr;
+            if (dz2 != nullptr) {
+                const float g2 = (sigmoidf_stable(y) - t) * inv_batch * tr;
+                dz2[(int64_t)b * A + a] = g2;
+                dz[(int64_t)b * A + a] = (sigmoidf_stable(x) - t) * inv_batch * tr + g2;
+            }
+            if (zsum != nullptr) zsum[(int64_t)b * A + a] = y;
+            x = y;                             // pred = argmax(logit + tuned_logit) (:244)
+        } else if (TWO == 1) {
             const float y = z2[(int64_t)b * A + a];
             const float ell2 = fmaxf(y, 0.f) - y * t + log1pf(expf(-fabsf(y)));
             l_all += ell + ell2;
@@ -377,23 +392,82 @@ extern "C" int vqa_loss_fwd(const float* z, const float* target, const float* tr
     VQA_REQUIRE(z && target && train_mask && obj_mask && attr_mask && exist_mask && stats && pred, VQA_ERR_ARG);
     VQA_REQUIRE(B >= 0 && A > 0, VQA_ERR_ARG);
     if (B == 0) return VQA_OK;
-    hipLaunchKernelGGL(loss_fwd_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, z, (const float*)nullptr, target,
+    hipLaunchKernelGGL(loss_fwd_kernel<0>, dim3(B), dim3(256), 0, (hipStream_t)stream, z, (const float*)nullptr, target,
                        train_mask, obj_mask, attr_mask, exist_mask, use_train_mask_in_loss, inv_batch, stats, pred, dz,
                        (float*)nullptr, (float*)nullptr, A);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
 
+// z1m[b, a] = exist[a] ? z[b, a] : min_a z[b, a] ; rowmin[b] = that minimum   (vqa/model_vlmap_answer_vqa_all.py:192-194)
+__global__ __launch_bounds__(256) void rowmin_mask_fwd_kernel(const float* __restrict__ z, const float* __restrict__ exist,
+                                                              float* __restrict__ zm, float* __restrict__ rowmin, int A) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* zb = z + (int64_t)b * A;
+    float m = INFINITY;
+    for (int a = threadIdx.x; a < A; a += 256) m = fminf(m, zb[a]);
+    m = -wave_max(-m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    for (int a = threadIdx.x; a < A; a += 256) zm[(int64_t)b * A + a] = exist[a] != 0.f ? zb[a] : m;
+    if (threadIdx.x == 0) rowmin[b] = m;
+}
+
+// back through it, in place: dz[b, a] = dz[b, a] * exist[a] + (z[b, a] == rowmin[b]) * (sum_a' dz[b, a'] * (1 - exist[a'])) / #ties
+// (tf.reduce_min hands its gradient to the minimum, split evenly over ties)
+__global__ __launch_bounds__(256) void rowmin_mask_bwd_kernel(float* __restrict__ dz, const float* __restrict__ z,
+                                                              const float* __restrict__ rowmin, const float* __restrict__ exist,
+                                                              int A) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float* db = dz + (int64_t)b * A;
+    const float* zb = z + (int64_t)b * A;
+    const float m = rowmin[b];
+    float s = 0.f, cnt = 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) {
+        s += db[a] * (1.f - exist[a]);
+        cnt += (zb[a] == m) ? 1.f : 0.f;
+    }
+    s = block_sum(s, red);
+    cnt = block_sum(cnt, red);
+    const float share = cnt > 0.f ? s / cnt : 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) db[a] = db[a] * exist[a] + ((zb[a] == m) ? share : 0.f);
+}
+
+extern "C" int vqa_rowmin_mask_fwd(const float* z, const float* exist_mask, float* z_masked, float* rowmin, int B, int A,
+                                   void* stream) {
+    VQA_REQUIRE(z && exist_mask && z_masked && rowmin && B >= 0 && A > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(rowmin_mask_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z, exist_mask, z_masked, rowmin, A);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_rowmin_mask_bwd(float* dz, const float* z, const float* rowmin, const float* exist_mask, int B, int A,
+                                   void* stream) {
+    VQA_REQUIRE(dz && z && rowmin && exist_mask && B >= 0 && A > 0, VQA_ERR_ARG);
+    if (B == 0) return VQA_OK;
+    hipLaunchKernelGGL(rowmin_mask_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dz, z, rowmin, exist_mask, A);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
 extern "C" int vqa_loss2_fwd(const float* z_fixed, const float* z_tuned, const float* target, const float* train_mask,
                              const float* obj_mask, const float* attr_mask, const float* exist_mask, float inv_batch,
-                             float* stats, int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int B, int A,
-                             void* stream) {
+                             float* stats, int32_t* pred, float* dz_fixed, float* dz_tuned, float* z_sum, int sum_mode,
+                             int B, int A, void* stream) {
     VQA_REQUIRE(z_fixed && z_tuned && target && train_mask && obj_mask && attr_mask && exist_mask && stats && pred,
                 VQA_ERR_ARG);
     VQA_REQUIRE(B >= 0 && A > 0 && (dz_fixed == nullptr) == (dz_tuned == nullptr), VQA_ERR_ARG);
     if (B == 0) return VQA_OK;
-    hipLaunchKernelGGL(loss_fwd_kernel<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, z_fixed, z_tuned, target,
-                       train_mask, obj_mask, attr_mask, exist_mask, 1, inv_batch, stats, pred, dz_fixed, dz_tuned, z_sum, A);
+    if (sum_mode)
+        hipLaunchKernelGGL(loss_fwd_kernel<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, z_fixed, z_tuned, target,
+                           train_mask, obj_mask, attr_mask, exist_mask, 1, inv_batch, stats, pred, dz_fixed, dz_tuned, z_sum, A);
+    else
+        hipLaunchKernelGGL(loss_fwd_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, z_fixed, z_tuned, target,
+                           train_mask, obj_mask, attr_mask, exist_mask, 1, inv_batch, stats, pred, dz_fixed, dz_tuned, z_sum, A);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

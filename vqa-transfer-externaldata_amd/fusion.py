@@ -44,7 +44,8 @@ STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
 NOC_FAMILY = ("vlmap_answer_noc", "vlmap_answer_nocarch")
 FROZEN_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV", "WordWeightAnswerL")
 TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l")
-VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all2") + NOC_FAMILY
+TWO_HEAD_FAMILY = ("vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")       # fixed head + trainable TunedWordWeightAnswer
+VLMAP_FAMILY = ("vlmap_answer",) + TWO_HEAD_FAMILY + NOC_FAMILY
 
 
 def scope_names(model_type):
@@ -95,7 +96,7 @@ def variable_shapes(model_type, Vq, W, D, H, A):
     fc(sc["joint_fc"], H, 2 * H, True)
     # standard_word2vec: the classifier maps into the 300-d word space (vqa/model_standard_word2vec.py:180-183)
     fc(sc["head"], 2 * H, W if model_type == "standard_word2vec" else A, False)
-    if model_type == "vlmap_answer_vqa_all2":
+    if model_type in TWO_HEAD_FAMILY:
         fc(sc["tuned_q_linear_l"], H, H, True)
         fc(sc["tuned_joint_fc"], H, 2 * H, True)
         fc(sc["head2"], 2 * H, A, False)
@@ -127,7 +128,7 @@ def _pad4(n):
 
 class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
-                     "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5}
+                     "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
@@ -274,7 +275,7 @@ class FusionEngine:
             pooled_linear_l=fc(sc["pooled_linear_l"], True), q_linear_l=fc(sc["q_linear_l"], True),
             joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False),
             answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None,
-            head2=fc(sc["head2"], False) if self.model_type in ("vlmap_answer_vqa_all2",) + NOC_FAMILY else _lib.Fc(),
+            head2=fc(sc["head2"], False) if self.model_type in TWO_HEAD_FAMILY + NOC_FAMILY else _lib.Fc(),
             joint2=fc(sc["joint2"], True) if self.model_type in NOC_FAMILY else _lib.Fc())
 
     def resize(self, B, T, global_batch=None):

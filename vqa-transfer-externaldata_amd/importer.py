@@ -1,13 +1,13 @@
 """String -> Model class registry, the counterpart of vqa/importer.py:1-52.
 
 The two models on the hot path and the first variants of section 8f-4
-(standard_word2vec, standard_testmask, vlmap_answer_vqa_all2, vlmap_answer_noc = vlmap_answer_nocarch) are built natively; the reference's other ablation variants are listed so that
+(standard_word2vec, standard_testmask, vlmap_answer_vqa_all, vlmap_answer_vqa_all2, vlmap_answer_noc = vlmap_answer_nocarch) are built natively; the reference's other ablation variants are listed so that
 a request for one fails with a precise message instead of an import error."""
 
 _NATIVE = ("standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc", "vlmap_answer_nocarch",
-           "vlmap_answer_vqa_all2")
+           "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")
 _REFERENCE_ONLY = (
-    "vqa", "vlmap_only", "vlmap_finetune", "vlmap_answer_vqa_all",
+    "vqa", "vlmap_only", "vlmap_finetune",
     "vlmap_answer2", "vlmap_answer_adapt",
     "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise")
 
@@ -29,6 +29,8 @@ def get_model_class(model_type="vlmap_answer"):
         from .model_vlmap_answer_noc import Model
     elif model_type == "vlmap_answer_nocarch":
         from .model_vlmap_answer_nocarch import Model
+    elif model_type in ("vlmap_answer_vqa_all", "vlmap_answer_"):        # the reference's importer accepts both spellings (:33)
+        from .model_vlmap_answer_vqa_all import Model
     elif model_type == "vlmap_answer_vqa_all2":
         from .model_vlmap_answer_vqa_all2 import Model
     elif model_type in _REFERENCE_ONLY:

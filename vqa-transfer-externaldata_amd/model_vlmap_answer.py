@@ -214,7 +214,7 @@ class Model(object):
                 p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
             else:
                 p[n] = np.zeros(s, np.float32)
-        if self.MODEL_TYPE in ("vlmap_answer", "vlmap_answer_vqa_all2"):      # the other heads keep their Xavier / zero initialisation
+        if self.MODEL_TYPE in ("vlmap_answer",) + F.TWO_HEAD_FAMILY:      # the other heads keep their Xavier / zero initialisation
             w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
             p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
         elif self.MODEL_TYPE in F.NOC_FAMILY:      # WordWeightAnswerV / L from v_class_* / l_class_* (:190-202)
