@@ -500,6 +500,18 @@ int vqa_pretrain_backward_phases(const vqa_pretrain_dims_t* dims, const vqa_pret
 int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co,
                     int stride, int pad_t, int pad_l, int Ho, int Wo, const float* scale, const float* shift,
                     const float* residual, int relu, float* y, void* stream);
+/* Backward of vqa_conv2d_nhwc (the reference's only consumer is the legacy CNN fine-tune,
+ * vlmap/model_vlmap.py:675-690 --ft_enc_I): with dy = d loss / d y and g = dy * (relu ? y > 0 : 1),
+ *   dx [B,Hi,Wi,Ci] = conv_transpose(g * scale, w), dw HWIO [kh,kw,Ci,Co] = im2col(x)^T (g * scale), dshift [Co] = sum g,
+ *   dresidual [B,Ho,Wo,Co] = g        (every output may be NULL; y is needed only when relu != 0; scale may be NULL).
+ * Both products run on vqa_gemm_f32 over chunks of images that fit `workspace` (vqa_conv2d_bwd_workspace_floats(...,
+ * chunk_images): pass B for one chunk, 1 for the minimum); the col2im step is a gather (no atomics: deterministic).
+ * Needs Ci % 4 == 0 and Co % 4 == 0 (conv1 of the extractor runs on 4-channel padded pixels, vqa_pad_c3c4_nhwc). */
+int64_t vqa_conv2d_bwd_workspace_floats(int B, int Ho, int Wo, int Ci, int kh, int kw, int Co, int chunk_images);
+int vqa_conv2d_nhwc_bwd(const float* x, int B, int Hi, int Wi, int Ci, const float* w, int kh, int kw, int Co, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, const float* scale, const float* y, int relu, const float* dy,
+                        float* dx, float* dw, float* dshift, float* dresidual, float* workspace, int64_t workspace_floats,
+                        void* stream);
 /* tuning: tile configuration of the implicit-GEMM path (-1 = chosen by shape, the default; 0 = 64x64 / 4 waves,
  * 1 = 128x64, 2 = 64x128, 3 = 128x128, all 8 waves; >= 0 also pins the 1x1 path to 64x64 unless vqa_gemm_set_config
  * forces another); process-wide, like vqa_gemm_set_config. */

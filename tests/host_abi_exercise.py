@@ -68,6 +68,17 @@ for M, N, K in ((1, 1, 1), (512, 3000, 2048), (18432, 1024, 2048), (7168, 300, 3
     for tA, tB in ((0, 0), (0, 1), (1, 0)):
         for sk in (0, 1, 3, 8):
             ok(lib.vqa_gemm_workspace_floats(tA, tB, M, N, K, sk) >= 0, "gemm workspace")
+ok(lib.vqa_conv2d_bwd_workspace_floats(128, 28, 28, 128, 3, 3, 128, 8) > lib.vqa_conv2d_bwd_workspace_floats(128, 28, 28, 128, 3, 3, 128, 1) > 0,
+   "conv bwd workspace grows with the chunk")
+ok(lib.vqa_conv2d_bwd_workspace_floats(0, 1, 1, 4, 1, 1, 4, 1) < 0, "conv bwd workspace bad dims")
+ok(lib.vqa_conv2d_nhwc_bwd(None, 1, 4, 4, 4, None, 1, 1, 4, 1, 0, 0, 4, 4, None, None, 0, None, None, None, None, None, None, 0, None) == -1,
+   "conv bwd null")
+ok(lib.vqa_conv2d_nhwc_bwd(C.c_void_p(4096), 1, 4, 4, 4, C.c_void_p(4096), 1, 1, 4, 1, 0, 0, 4, 4, None, None, 1, C.c_void_p(4096), None, None,
+                           None, None, C.c_void_p(4096), 1 << 20, None) == -1, "conv bwd relu without y")
+ok(lib.vqa_conv2d_nhwc_bwd(C.c_void_p(4096), 1, 4, 4, 3, C.c_void_p(4096), 1, 1, 4, 1, 0, 0, 4, 4, None, None, 0, C.c_void_p(4096), None, None,
+                           None, None, C.c_void_p(4096), 1 << 20, None) == -2, "conv bwd Ci % 4")
+ok(lib.vqa_conv2d_nhwc_bwd(C.c_void_p(4096), 4, 8, 8, 8, C.c_void_p(4096), 3, 3, 8, 1, 1, 1, 8, 8, None, None, 0, C.c_void_p(4096), None, None,
+                           None, None, C.c_void_p(4096), 16, None) == -5, "conv bwd workspace too small")
 ok(lib.vqa_colsum_workspace_floats(1, 1) >= 0 and lib.vqa_colsum_workspace_floats(25600, 2048) > 0, "colsum workspace")
 ok(lib.vqa_sumsq_workspace_floats(0) >= 0 and lib.vqa_sumsq_workspace_floats(1 << 30) > 0, "sumsq workspace")
 

@@ -161,6 +161,8 @@ SIGNATURES = {
     "vqa_probe_labels": (_I, [C.c_char_p, _I]),
     "vqa_roctx_enable": (_I, [_I]),
     "vqa_stream_delay_us": (_I, [_F, _P]),
+    "vqa_conv2d_bwd_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "vqa_conv2d_nhwc_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
     "vqa_gemm_bf16x3_supported": (_I, [_I, _I, _I]),
     "vqa_gemm_bf16x3_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
     "vqa_probe_disable": (_I, []),

@@ -130,6 +130,31 @@ def conv2d(x, cb, stride=1, pad=(0, 0), out_hw=None, residual=None, relu=True):
     return y
 
 
+def conv2d_backward(x, cb, y, dy, stride=1, pad=(0, 0), relu=True, need_dx=True, need_dw=True, chunk_images=None):
+    """Gradients of conv2d() (vqa_conv2d_nhwc_bwd; the reference's only consumer is the legacy CNN fine-tune,
+    vlmap/model_vlmap.py:675-690): returns (dx, dw [kh*kw*Ci, Co], dshift [Co], dresidual) for dy = d loss / d y.
+    chunk_images bounds the im2col scratch (default: as many images at once as 1 GiB of scratch holds)."""
+    lib = _lib.load()
+    B, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    K = cb.kh * cb.kw * Ci
+    if chunk_images is None:
+        chunk_images = max(1, min(B, int((1 << 28) // max(1, 2 * Ho * Wo * K))))
+    n = int(lib.vqa_conv2d_bwd_workspace_floats(B, Ho, Wo, Ci, cb.kh, cb.kw, Co, chunk_images))
+    if n <= 0:
+        raise _lib.VqaHotError("vqa_conv2d_bwd_workspace_floats rejected the shape")
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty(K, Co, dtype=torch.float32, device=x.device) if need_dw else None
+    dshift = torch.empty(Co, dtype=torch.float32, device=x.device)
+    dres = torch.empty_like(dy)
+    w = cb.w[:K]                                       # (conv1's rows beyond kh*kw*Ci are zero padding of the forward)
+    _lib.check(lib.vqa_conv2d_nhwc_bwd(_p(x), B, Hi, Wi, Ci, _p(w), cb.kh, cb.kw, Co, stride, pad[0], pad[1], Ho, Wo,
+                                       _p(cb.scale), _p(y), int(relu), _p(dy.contiguous()), _p(dx), _p(dw), _p(dshift),
+                                       _p(dres), _p(ws), ws.numel(), _st(x)), "vqa_conv2d_nhwc_bwd")
+    return dx, dw, dshift, dres
+
+
 def max_pool_3x3_s2_same(x):
     lib = _lib.load()
     B, H, W, Cc = x.shape
