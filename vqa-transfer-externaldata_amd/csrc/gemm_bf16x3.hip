@@ -45,29 +45,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_nn_kernel(const float* __re
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;           // the wave's 64 x 64 corner of the tile
 
     // A tile [128 rows][32 k]: thread -> (row = idx / 8, 4 consecutive k): one 16-byte load, 8 lanes cover a 128-byte row
-    // B tile [32 k][128 n]:    thread -> (column n = idx % 128, 8 consecutive k = group idx / 128): 8 dword loads, each
-    //                          coalesced over the 64 columns of a wave; the lane then owns 16 bytes of its column's LDS row
+    // B tile [32 k][128 n]:    thread -> a 4 (k) x 4 (n) block: four 16-byte loads from consecutive k rows (8 lanes cover
+    //                          128 contiguous bytes of a row), transposed in registers into 4 k-consecutive bf16 (8 bytes)
+    //                          for each of its 4 columns
     f32x4n ra[4];
-    float rb[2][8];
+    f32x4n rb[4];
     const float* pa[4];
-    const float* pb[2];
+    const float* pb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * NT;
         pa[i] = A + (int64_t)(m0 + idx / 8) * lda + (idx % 8) * 4;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * NT;
-        pb[i] = B + (int64_t)((idx / 128) * 8) * ldb + n0 + (idx % 128);
-    }
+    const int bk4 = (tid % 8) * 4, bn4 = (tid / 8) * 4;            // the block's first k and first column inside the tile
+    pb = B + (int64_t)bk4 * ldb + n0 + bn4;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4n*>(pa[i] + k0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rb[i][j] = pb[i][(int64_t)(k0 + j) * ldb];
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4n*>(pb + (int64_t)(k0 + i) * ldb);
     };
     auto stage = [&]() {
 #pragma unroll
@@ -86,19 +82,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_nn_kernel(const float* __re
             *reinterpret_cast<bf16x4*>(sA + 2 * PLANE + row * RS + kq) = l;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * NT;
-            const int col = idx % 128, kg = (idx / 128) * 8;
-            bf16x8 h, m, l;
+        for (int j = 0; j < 4; ++j) {                 // column bn4 + j: its four consecutive k
+            bf16x4 h, m, l;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int i = 0; i < 4; ++i) {
                 __bf16 a, b, c;
                 split3(rb[i][j], a, b, c);
-                h[j] = a; m[j] = b; l[j] = c;
+                h[i] = a; m[i] = b; l[i] = c;
             }
-            *reinterpret_cast<bf16x8*>(sB + col * RS + kg) = h;
-            *reinterpret_cast<bf16x8*>(sB + PLANE + col * RS + kg) = m;
-            *reinterpret_cast<bf16x8*>(sB + 2 * PLANE + col * RS + kg) = l;
+            *reinterpret_cast<bf16x4*>(sB + (bn4 + j) * RS + bk4) = h;
+            *reinterpret_cast<bf16x4*>(sB + PLANE + (bn4 + j) * RS + bk4) = m;
+            *reinterpret_cast<bf16x4*>(sB + 2 * PLANE + (bn4 + j) * RS + bk4) = l;
         }
     };
 
@@ -175,7 +169,7 @@ extern "C" int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, 
     VQA_REQUIRE(A && B && C, VQA_ERR_ARG);
     VQA_REQUIRE(vqa_gemm_bf16x3_supported(M, N, K) == 1, VQA_ERR_UNSUPPORTED);
     VQA_REQUIRE(lda >= K && ldb >= N && ldc >= N, VQA_ERR_ARG);
-    VQA_REQUIRE(lda % 4 == 0 && vqa_aligned16(A), VQA_ERR_ALIGN);
+    VQA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && vqa_aligned16(A) && vqa_aligned16(B), VQA_ERR_ALIGN);
     constexpr size_t lds_bytes = (size_t)2 * OPER * sizeof(__bf16);
     static bool attr = false;
     if (!attr) {
