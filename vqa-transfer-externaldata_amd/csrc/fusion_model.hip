@@ -184,14 +184,15 @@ int side_max_blocks() {
 // of different chains share a CU) and -- the point -- in ANTI-PHASE: chain i starts i * delay later, so one chain's
 // boundary falls into the other chain's matrix work.  In phase (no delay) both chains compute at half rate and wait
 // together, and nothing is gained (profiles/r3_gru_split2.txt: one chain 558 us, two chains in phase 511-540, two chains
-// 8-16 us apart 491).  VQA_HOT_GRU_CHAINS (default 2; 1 = one chain on the caller's stream), VQA_HOT_GRU_CHAIN_DELAY_US
-// (default 10).
+// 8-16 us apart 491).  Inside the step the second chain starts behind a cross-stream event anyway, and a small explicit
+// delay is enough (profiles/r3_gru_chains.txt: 0 / 3 us 3.592 ms per step, 6 / 10 us 3.602-3.604).
+// VQA_HOT_GRU_CHAINS (default 2; 1 = one chain on the caller's stream), VQA_HOT_GRU_CHAIN_DELAY_US (default 3).
 struct Chains {
     static constexpr int MAXC = 4;
     hipStream_t s[MAXC] = {};
     hipEvent_t fork = nullptr, join[MAXC] = {};
     int n = 1;
-    float delay_us = 10.f;
+    float delay_us = 3.f;
     bool tried = false;
 };
 Chains& gru_chains() {

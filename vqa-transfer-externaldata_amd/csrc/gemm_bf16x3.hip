@@ -9,7 +9,11 @@
 // C[M,N] = A[M,K] * B[K,N] (+ bias[N]), all f32 row-major in HBM; the split happens on the way into LDS (A: 151 MB, never
 // written back in split form).  Tile 128 x 128, BK 32, 256 threads = 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32);
 // operands live in LDS as three bf16 planes [row or column][k] with 80-byte rows (conflict-free ds_read_b128 of the 8
-// consecutive k a lane feeds to one MFMA); one LDS buffer, register prefetch of the next tile, two workgroups per CU.
+// consecutive k a lane feeds to one MFMA).  TWO LDS buffers (120 KB, one workgroup per CU): while the matrix pipe works
+// through tile t, the same waves split tile t + 1 (already in registers) into the other buffer -- the split's vector ALU
+// work (~260 instructions per wave and k tile) rides in the issue slots between the 48 MFMAs of a k tile
+// (sched_group_barrier pattern) -- and fetch tile t + 2; one barrier per k tile.  (The first version, one buffer and two
+// workgroups per CU, kept the matrix pipe 45 % busy: profiles/r3_pmc_bf16x3.txt.)
 #include "vqa_common.h"
 
 namespace {
@@ -32,7 +36,7 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r;
 }
 
-__global__ __launch_bounds__(NT, 2) void gemm_bf16x3_nn_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(NT, 1) void gemm_bf16x3_nn_kernel(const float* __restrict__ A, int lda,
                                                                const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                                int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                                int tiles_n) {
@@ -106,42 +110,69 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16x3_nn_kernel(const float* __re
 
     const int fr = lane & 31, fk = (lane >> 5) * 8;      // the lane's row / column inside a 32-wide MFMA tile, its 8 k
     const int nk = K / BK;
+    constexpr int BUF = 2 * OPER;                         // bf16 per LDS buffer (A planes | B planes)
+    auto stage_into = [&](int buf) {
+        sA = lds + buf * BUF;
+        sB = sA + OPER;
+        stage();
+    };
     fetch(0);
-    stage();
+    stage_into(0);
+    if (nk > 1) fetch(BK);                                // tile 1 waits in the registers
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) fetch((t + 1) * BK);
-        __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fa[2][2][3], fb[2][2][3];                      // [k step][tile][plane]: all 24 fragment reads of a tile up front
+    auto read_frags = [&](int t) {
+        const __bf16* cA = lds + (t & 1) * BUF;
+        const __bf16* cB = cA + OPER;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[2][3], fb[2][3];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    fa[x][p] = *reinterpret_cast<const bf16x8*>(sA + p * PLANE + (wm + x * 32 + fr) * RS + ks * 16 + fk);
-                    fb[x][p] = *reinterpret_cast<const bf16x8*>(sB + p * PLANE + (wn + x * 32 + fr) * RS + ks * 16 + fk);
+                    fa[ks][x][p] = *reinterpret_cast<const bf16x8*>(cA + p * PLANE + (wm + x * 32 + fr) * RS + ks * 16 + fk);
+                    fb[ks][x][p] = *reinterpret_cast<const bf16x8*>(cB + p * PLANE + (wn + x * 32 + fr) * RS + ks * 16 + fk);
                 }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     // smallest products first, the leading one last
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][2], fb[ks][b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][1], fb[ks][b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][0], fb[ks][b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][1], fb[ks][b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][0], fb[ks][b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][0], fb[ks][b][0], acc[a][b], 0, 0, 0);
                 }
+    };
+    int t = 0;
+    for (; t + 1 < nk; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(t);
+        stage_into((t + 1) & 1);       // tile t + 1: split and store into the other buffer -- ONE basic block with the MFMAs
+        mfmas();
+        // issue pattern of the block: 24 LDS reads first, then per MFMA five or six vector ALU instructions and, every
+        // second MFMA, one LDS store (masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x200 DS write)
+        __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nk) {
-            __syncthreads();          // every wave is done reading tile t
-            stage();                  // tile t + 1 (fetched above, behind the MFMAs)
-            __syncthreads();
-        }
+        if (t + 2 < nk) fetch((t + 2) * BK);              // its latency hides behind the next tile's MFMAs
+        __syncthreads();                                  // tile t + 1 is in LDS; tile t's buffer is free
     }
+    read_frags(t);                                        // last tile: nothing left to stage
+    mfmas();
     // C / D map of a 32 x 32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -170,7 +201,7 @@ extern "C" int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, 
     VQA_REQUIRE(vqa_gemm_bf16x3_supported(M, N, K) == 1, VQA_ERR_UNSUPPORTED);
     VQA_REQUIRE(lda >= K && ldb >= N && ldc >= N, VQA_ERR_ARG);
     VQA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && vqa_aligned16(A) && vqa_aligned16(B), VQA_ERR_ALIGN);
-    constexpr size_t lds_bytes = (size_t)2 * OPER * sizeof(__bf16);
+    constexpr size_t lds_bytes = (size_t)2 * 2 * OPER * sizeof(__bf16);      // two buffers of (A planes | B planes)
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_nn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
