@@ -1236,6 +1236,21 @@ extern "C" int vqa_gemm_set_gru_config(int cfg) {
     return VQA_OK;
 }
 
+// which callers route short-K problems to gemm_shortk.hip: bit 0 = vqa_gemm_f32 (NN, K <= 304), bit 1 = the extractor's
+// 1x1 convolutions (Ci <= 256).  VQA_HOT_SHORTK (default 3) or vqa_gemm_shortk_set_mode.
+int g_shortk_mode = -1;
+inline int shortk_mode() {
+    if (g_shortk_mode < 0) {
+        const char* e = getenv("VQA_HOT_SHORTK");
+        g_shortk_mode = e ? (atoi(e) & 3) : 3;
+    }
+    return g_shortk_mode;
+}
+extern "C" int vqa_gemm_shortk_set_mode(int mode) {
+    g_shortk_mode = mode < 0 ? -1 : (mode & 3);
+    return VQA_OK;
+}
+
 extern "C" int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                             int ldb, float* C, int ldc, const float* bias, const float* D, int ldd, int split_k,
                             float* workspace, int64_t workspace_floats, void* stream) {
@@ -1263,6 +1278,12 @@ extern "C" int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, cons
     VQA_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, VQA_ERR_ARG);
     VQA_REQUIRE(D == nullptr || ldd >= N, VQA_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
+
+    // K <= 304, NN: the kernel with A stationary in registers (gemm_shortk.hip) -- the GRU's packed x-projection
+    if (!transA && !transB && split_k <= 1 && max_blocks == 0 && g_force_cfg < 0 && (shortk_mode() & 1) &&
+        vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) && !(K > 256 && D != nullptr) && vqa_aligned16(A) &&
+        vqa_aligned16(B))
+        return vqa_gemm_shortk_nn(M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, D, ldd, 0, stream);
 
     int cfg, split = split_k;
     choose(transA, transB, M, N, K, cfg, split);
@@ -1519,6 +1540,11 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     GemmArgs a = make_args(M, Co, K, x, Ci, w, Co, y, Co, shift, residual, Co);
     a.scale = scale;
     a.relu = relu;
+    if (plain && (shortk_mode() & 2) && Ci >= 128 && Ci <= 256 && g_conv_cfg_plain < 0 && g_force_cfg < 0 &&
+        vqa_gemm_shortk_supported(M, Co, K, Ci, Co, Co) && vqa_aligned16(x) && vqa_aligned16(w) &&
+        (residual == nullptr || (int64_t)M * Co * 4 < 0xFFFFFFF0ll))
+        // 1x1 expansions and projections with Ci <= 256: the whole k extent of a row panel stays in registers
+        return vqa_gemm_shortk_nn(M, Co, K, x, Ci, w, Co, y, Co, shift, scale, residual, Co, relu, stream);
     if (plain) {
         // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M.  The block-1/2 expansions
         // (64 -> 256, 128 -> 512: a k loop of 2..4 tiles, then an epilogue that reads the residual and writes 4x the

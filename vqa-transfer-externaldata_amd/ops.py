@@ -156,6 +156,21 @@ def loss_fwd(z, target, masks, use_train_mask=True, inv_batch=None, want_dz=True
     return stats, pred, dz, dict(zip(keys, report[:13].cpu().tolist()))
 
 
+def gemm_shortk(A, B, bias=None, scale=None, residual=None, relu=False, out=None):
+    """C = [relu]((A @ B) * scale + bias + residual) for K <= 304 with A stationary in registers (csrc/gemm_shortk.hip).
+    gemm() and the extractor's convolutions route qualifying shapes here themselves; this is the direct entry."""
+    lib = _lib.load()
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(-1) == 1 and B.stride(-1) == 1
+    M, K = A.shape
+    N = B.shape[1]
+    assert B.shape[0] == K
+    Cm = out if out is not None else _f32(M, N, like=A)
+    _lib.check(lib.vqa_gemm_shortk_nn(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(Cm), Cm.stride(0), _p(bias),
+                                      _p(scale), _p(residual), residual.stride(0) if residual is not None else 0,
+                                      int(bool(relu)), _st(A)), "vqa_gemm_shortk_nn")
+    return Cm
+
+
 def gemm_bf16x3(A, B, bias=None, out=None):
     """EXPERIMENT: C = A @ B (+ bias) through three-way bf16 splits and six bf16 MFMA products per a*b (f32-equivalent
     products; csrc/gemm_bf16x3.hip).  Whole 128 x 128 x 32 tiles only; the product path uses gemm() (exact f32 MFMA)."""
