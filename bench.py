@@ -432,6 +432,36 @@ def step_groups(cfg):
     }
 
 
+def clock_pass(eng, lib, batches, rank, step_ms, steps=12):
+    """The shader clock the train step runs at: `steps` extra steps with the library's clock sampler (a few sleeping
+    single-wave workgroups on a side stream that count shader cycles per 0.5 ms of real time, csrc/probe.hip) beside them.
+    Separate from the timed region.  The f32 MFMA peak of the roofline (157.3 TFLOP/s) is 2.4 GHz x 256 CUs x 256
+    flop/cycle; under sustained matrix work the chip holds less, and every fraction below is ALSO given against the peak
+    at the measured clock."""
+    import numpy as np
+    import torch
+    from vqa_transfer_externaldata_amd import _lib
+    us, wgs = 500.0, 8
+    n = max(4, int(steps * step_ms * 1e3 / us))
+    out = torch.zeros(wgs, n, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    for i in range(2):
+        ka, kj = eng.make_keep_masks(seed=11 + rank, step=2000 + i)
+        eng.train_step(batches[i % len(batches)], ka, kj, 1e-3)
+    torch.cuda.synchronize()
+    _lib.check(lib.vqa_clock_sample(us, n, wgs, C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)), "vqa_clock_sample")
+    for i in range(steps + 2):
+        ka, kj = eng.make_keep_masks(seed=11 + rank, step=2002 + i)
+        eng.train_step(batches[i % len(batches)], ka, kj, 1e-3)
+    torch.cuda.synchronize()
+    g = out.cpu().numpy()[:, 1:-1]                 # (first and last period: ramps)
+    ghz = float(np.median(g))
+    return {"shader_ghz": ghz, "min": float(g.min()), "max": float(g.max()), "nominal_ghz": 2.4,
+            "f32_mfma_peak_at_clock": F32_MFMA_PEAK_TFLOPS * ghz / 2.4,
+            "how": "median over %d samples of %.1f ms on %d sampler waves (one per XCD) while %d train steps ran; "
+                   "cycles = s_memtime, time = s_memrealtime (100 MHz)" % (g.size, us / 1e3, wgs, steps)}
+
+
 def groups_pass(eng, lib, batches, cfg, rank, steps=10):
     """`steps` extra train steps with every launch group probed (HIP events on the step's stream around each group; the
     optimizer and the mask generator, which are separate C calls, through torch events on the same stream).  Run AFTER
@@ -572,9 +602,11 @@ def main():
     assert np.isfinite(loss), "training diverged"
     n_grad_floats = eng.grad_flat.numel()
 
-    groups, groups_step_us = (None, None)
+    groups, groups_step_us, clock = (None, None, None)
     if not args.no_groups:
         groups, groups_step_us = groups_pass(eng, lib, batches, cfg, rank)
+        if world == 1:
+            clock = clock_pass(eng, lib, batches, rank, dt / args.steps * 1e3)
     # the other legs run on EVERY rank (each is sharded like its config says); rank 0 prints
     legs = {}
     del eng
@@ -626,7 +658,10 @@ def main():
                                        "committed trace is lower by that ratio",
                          # what the WHOLE step achieves against the same peak, and where its time goes
                          "step": {"flops": STEP_GFLOP * 1e9, "ms": step_ms, "achieved": step_tflops,
-                                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / F32_MFMA_PEAK_TFLOPS},
+                                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": step_tflops / F32_MFMA_PEAK_TFLOPS,
+                                  "frac_at_clock": (step_tflops / clock["f32_mfma_peak_at_clock"]) if clock else None},
+                         "clock": clock,
+                         "frac_at_clock": (achieved / clock["f32_mfma_peak_at_clock"]) if clock else None,
                          "groups": groups,
                          "groups_note": ("per-group times from a separate pass of 10 steps with HIP events around every "
                                          "launch group (%.1f us per step in that pass, events included); `frac` of a group "

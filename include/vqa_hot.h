@@ -576,6 +576,11 @@ int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, const float
                        const float* bias, const float* scale, const float* D, int ldd, int relu, void* stream);
 int vqa_gemm_shortk_set_grid(int n);
 int vqa_gemm_shortk_set_mode(int mode);
+/* Shader-clock sampler: enqueues, on `stream`, n_workgroups single-wave workgroups that for n_samples periods of
+ * us_per_sample microseconds (100 MHz real-time counter) note the shader cycles that went by; ghz_out (device memory,
+ * [n_workgroups][n_samples]) receives cycles / time in GHz.  Launched on a side stream beside the work to be measured
+ * (bench.py: the clock the timed steps ran at; the published MFMA peak assumes 2.4 GHz).  At most 2 s in total. */
+int vqa_clock_sample(float us_per_sample, int n_samples, int n_workgroups, float* ghz_out, void* stream);
 /* Enqueues a delay of `us` microseconds ON `stream` (one wave polling the 100 MHz real-time counter; 0 <= us <= 1e5).
  * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
  * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */

@@ -33,11 +33,19 @@ for wg in [int(x) for x in os.environ.get("SK_WGS", "0,1,255,256,300,511").split
     d = lambda a, b: int((r[b] - r[a]) & 0xFFFFFFFF)
     print("workgroup %d: prologue %d cycles" % (wg, d(0, 1)))
     u = 0
-    while 2 + 4 * u + 4 < 64 and r[2 + 4 * u + 4] != 0:
+    while 2 + 4 * u + 4 < 61 and r[2 + 4 * u + 4] != 0:
         b0 = 2 + 4 * u
         print("   unit %2d: " % u + "  ".join("%s %6d" % (names[i], d(b0 + i, b0 + i + 1)) for i in range(4)) +
               "   | unit %6d" % d(b0, b0 + 4))
         u += 1
+cyc, ticks, t0r = s[:G, 61], s[:G, 62], s[:G, 63]
+import numpy as np
+print("whole kernel, per workgroup: core cycles median %d (max %d), 100 MHz ticks median %d (max %d) -> clock %.2f GHz" % (
+    np.median(cyc), cyc.max(), np.median(ticks), ticks.max(), float(np.median(cyc / np.maximum(ticks, 1))) * 0.1))
+st_rel = (t0r - t0r.min()) & 0xFFFFFFFF
+end_rel = (st_rel + ticks)
+print("first start -> last end: %.1f us; starts spread over %.1f us; second-half workgroups start %.1f us (median) after the first" % (
+    end_rel.max() / 100.0, st_rel.max() / 100.0, float(np.median(st_rel[G // 2:])) / 100.0))
 # spread of start and end over the workgroups (low words; relative to workgroup 0's start)
 t0 = s[:G, 0]
 print("start stamps (first 16 workgroups, relative):", [(int(x) - int(t0[0])) & 0xFFFFFFFF for x in t0[:16]])

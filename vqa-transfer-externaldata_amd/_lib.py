@@ -163,6 +163,7 @@ SIGNATURES = {
     "vqa_stream_delay_us": (_I, [_F, _P]),
     "vqa_conv2d_bwd_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "vqa_conv2d_nhwc_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "vqa_clock_sample": (_I, [_F, _I, _I, _P, _P]),
     "vqa_gemm_shortk_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "vqa_gemm_shortk_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P]),
     "vqa_gemm_shortk_set_grid": (_I, [_I]),

@@ -19,6 +19,7 @@
 // permutation, so every k is consumed exactly once.
 
 #include "vqa_common.h"
+#include "gemm_args.h"
 #include <cstdlib>
 
 #ifndef VQA_GEMM_STAGGER
@@ -28,35 +29,18 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#if defined(VQA_DBG_STAMPS)   // timing experiment (tools/dbg/gru_stamps.py): thread 0 of every workgroup of a fused GRU-step
+// launch records the 100 MHz real-time counter at five points; slot = epilogue kind
+__device__ unsigned long long* g_dbg_stamps = nullptr;
+#define DBG_STAMP(i) do { if (threadIdx.x == 0) dbg_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DBG_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 // A k-contiguous tile is staged as [row][BK + 4]: rows stay 16-B aligned and the 16 rows of a
 // ds_read_b128 lane group land on 16 distinct 16-B bank groups for BK = 16, 32 and 64.
-
-struct GemmArgs {
-    int M, N, K;
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc;
-    const float* bias;
-    const float* D; int ldd;
-    int k_per_split;      // multiple of 64 (>= every BK)
-    int64_t slab_stride;  // floats between split-k slabs of C (0 when split_k == 1)
-    int vecA, vecB;       // 16-byte global loads allowed for A / B
-    int tiles_m, tiles_n, nsplit;   // 1-D grid: workgroups walk the (split, m, n) tiles
-    int m_fastest;                  // tile order inside a split: m fastest (1) or n fastest (0)
-    unsigned a_bytes, b_bytes;      // operand extents for the buffer descriptors (0 => use the generic loader)
-    const float* scale;             // per-column scale (folded BatchNorm), applied to the accumulator
-    int relu;                       // ReLU after scale / bias / addend
-    // implicit-GEMM convolution (A = NHWC activations, row m = output pixel, k = (ky, kx, ci))
-    int Hi, Wi, Ci, Ho, Wo, cstride, pad_t, pad_l, kw;
-    int conv_taps;                  // kh * kw
-    int vec_epi;                    // plain epilogue may use 16-byte accesses
-    // row-gathered A (GATHER kernels): logical row m of the left operand is row g_idx[m / g_R] * g_R + m % g_R of the
-    // table at A (the feature gather V_ft = features[image_idx] fused into v_linear_v's operand load); g_out, when
-    // set, receives the gathered rows densely [M, K] as a by-product (written by the workgroups of column panel 0)
-    const int64_t* g_idx; int g_R; int64_t g_N; float* g_out; int g_ldo;
-};
 
 // XCD-aware tile order (MI355X: 8 XCDs, private L2s, workgroups dealt round-robin): workgroup ids
 // that share an XCD (same id % 8) get a CONTIGUOUS range of logical tiles, n fastest, so the tiles
@@ -66,24 +50,6 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     const int xcd = lin & 7, idx = lin >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
-
-// Fused epilogues of the GRU recurrence (tf.contrib.rnn.GRUCell, vlmap/modules.py:129-135):
-//  EPI_GATES  g = acc + D ; s = sigmoid(g) ; col <  H: r = s, rh = s*h_prev ; col >= H: u = s
-//  EPI_CAND   c = tanh(acc + D) ; h_new = (t < len) ? u*h_prev + (1-u)*c : h_prev
-//  EPI_BWD_RH drh = acc ; dr_pre = drh*h_prev*r*(1-r) -> o0[row*ldo + col] ; dh_acc += drh*r
-//  EPI_BWD_DH dh = acc + dh_acc (the gradient wrt h of step t-1) and, fused, the first half of
-//             step t-1's backward: dc_pre, du_pre, dh_acc' (see vqa_gru_bwd_a)
-enum { EPI_PLAIN = 0, EPI_GATES = 1, EPI_CAND = 2, EPI_BWD_RH = 3, EPI_BWD_DH = 4 };
-struct EpiArgs {
-    int H, t, ldo;
-    const int32_t* len;
-    const float* h_prev;   // [B,H]
-    const float* i0;       // GATES: -      CAND: u        BWD_RH: r        BWD_DH: u (step t-1)
-    const float* i1;       //                                               BWD_DH: c (step t-1)
-    float* o0;             // GATES: r      CAND: c        BWD_RH: dr_pre   BWD_DH: dc_pre (ld ldo)
-    float* o1;             // GATES: u      CAND: h_new    BWD_RH: dh_acc   BWD_DH: du_pre (ld ldo)
-    float* o2;             // GATES: rh                                      BWD_DH: dh_acc
-};
 
 int g_force_order = -1;  // tuning override of the tile order (vqa_gemm_set_order): 0 n-fastest, 1 m-fastest
 
@@ -305,6 +271,11 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
     // (Staggering the priorities of co-resident workgroups, to stop their waves convoying into the
     // same barrier, was measured and changes nothing: the MFMA arbiter does not follow s_setprio.)
     if (EPI != EPI_PLAIN) __builtin_amdgcn_s_setprio(3);
+#if defined(VQA_DBG_STAMPS)
+    unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (threadIdx.x == 0) dbg_t[5] = __builtin_amdgcn_s_memtime();
+#endif
+    DBG_STAMP(0);                                            // start
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wk = wave / (WAVES_M * WAVES_N);
     const int wm = (wave / WAVES_N) % WAVES_M, wn = wave % WAVES_N;
@@ -667,6 +638,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
         if (nt > 1) ld1(1);
         if (nt > 0) st0();
         __syncthreads();
+        DBG_STAMP(1);                                        // first tile in LDS
         int t = 0;
         // steady state, unrolled by 2 so every register index is static and free of conditionals:
         // entering a pair, L0 holds tile t and set 1 holds tile t+1 (in flight)
@@ -870,6 +842,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
         continue;   // next tile (the loop's last barrier already fenced the LDS tiles)
     }
 
+    DBG_STAMP(2);                                            // k loop done
     // Fused GRU epilogues: every wave parks its accumulator tile, TRANSPOSED, in its own 32 x 36 LDS patch
     // ([k group][sub-tile]; the operand tiles are dead after the loop's last barrier), so a lane owns 4 consecutive
     // columns of a row: side inputs and outputs move as 16-byte, line-contiguous accesses.  After one barrier
@@ -883,6 +856,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
     for (int r = 0; r < 16; ++r)
         stg[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * STG_LD + (lane & 31)] = acc[0][0][r];
     if (WGK > 1) __syncthreads();
+    DBG_STAMP(3);                                            // partial tiles exchanged
     if (e_act) {
         const int c4 = (lane & 7) * 4;
         const int gcol = n0 + wn * WN + c4;
@@ -958,6 +932,15 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
         }
     }
     }   // tile loop
+#if defined(VQA_DBG_STAMPS)
+    DBG_STAMP(4);                                            // epilogue issued
+    if (threadIdx.x == 0 && g_dbg_stamps != nullptr && blockIdx.x < 4096) {   // (plain kernels: slot 0, start / end only)
+        dbg_t[6] = __builtin_amdgcn_s_memtime();
+        if (EPI == EPI_PLAIN) dbg_t[4] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = g_dbg_stamps + ((size_t)EPI * 4096 + blockIdx.x) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = dbg_t[i];
+    }
+#endif
 }
 
 // C[m, n] = sum_z slab[z][m, n]   (slabs are dense M x N with ld = N)
@@ -1092,11 +1075,19 @@ int launch_by_id(int cfg, int tA, int tB, const GemmArgs& a_in, int split, hipSt
 }
 
 // fused GRU-step GEMMs: layout fixed by the epilogue (forward NN, backward NT)
+}  // namespace
+int vqa_gru_rs_launch(int epi, const GemmArgs& a, const EpiArgs& ep, hipStream_t st);   // gru_stream.hip
+namespace {
 template <int EPI>
 int launch_gru(int cfg, const GemmArgs& a_in, const EpiArgs& ep, hipStream_t st) {
     constexpr bool BKC = (EPI == EPI_BWD_RH || EPI == EPI_BWD_DH);
     GemmArgs a = a_in;
     if (!fast_ok(0, BKC ? 1 : 0, a)) return VQA_ERR_ALIGN;
+    if (cfg == 30) {   // register-streamed step kernels (gru_stream.hip); shapes they do not take fall back to the LDS-tiled form
+        const int rc = vqa_gru_rs_launch(EPI, a_in, ep, st);
+        if (rc != VQA_ERR_UNSUPPORTED) return rc;
+        cfg = 16;
+    }
     switch (cfg) {
         case 4: return launch_one<64, 64, 32, 32, 1, 64, false, true, BKC, EPI>(a, ep, 1, st);
         case 7: return launch_one<64, 32, 32, 32, 2, 64, false, true, BKC, EPI>(a, ep, 1, st);
@@ -1230,7 +1221,7 @@ extern "C" int vqa_gemm_set_config(int cfg) {
 }
 
 extern "C" int vqa_gemm_set_gru_config(int cfg) {
-    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 13) || (cfg >= 16 && cfg <= 18) || cfg == 20 || cfg == 21,
+    VQA_REQUIRE(cfg == -1 || cfg == 4 || (cfg >= 7 && cfg <= 13) || (cfg >= 16 && cfg <= 18) || cfg == 20 || cfg == 21 || cfg == 30,
                 VQA_ERR_ARG);
     g_gru_cfg = cfg;   // -1 restores the defaults
     return VQA_OK;
@@ -1257,6 +1248,13 @@ extern "C" int vqa_gemm_f32(int transA, int transB, int M, int N, int K, const f
     return vqa_gemm_f32_ex(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, D, ldd, split_k, workspace,
                            workspace_floats, g_max_blocks, stream);
 }
+
+#if defined(VQA_DBG_STAMPS)
+extern "C" int vqa_gemm_dbg_stamps(void* buf) {    // [5 kinds][4096 workgroups][8] u64, device memory
+    unsigned long long* b = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &b, sizeof(b)) == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int vqa_gemm_set_order(int order) {
     g_force_order = (order == 0 || order == 1) ? order : -1;

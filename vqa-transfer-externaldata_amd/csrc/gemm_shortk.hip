@@ -133,6 +133,7 @@ __global__ __launch_bounds__(SK_NT, 2) void shortk_nn_kernel(SkArgs p) {
 #if defined(SK_DBG_STAMPS)
     unsigned stampv = 0;
     int sidx = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
 #endif
     SK_STAMP();                                              // 0: start
     int panel = u_lo / p.n_tiles, nt = u_lo - panel * p.n_tiles;
@@ -260,6 +261,12 @@ __global__ __launch_bounds__(SK_NT, 2) void shortk_nn_kernel(SkArgs p) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv[r]), rsC, st_voff,
                                               st_soff + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldc * 4u, 0);
 #if defined(SK_DBG_STAMPS)
+    {   // lanes 61..63: whole-kernel core cycles and 100 MHz ticks (the clock the kernel ran at = cycles / ticks * 100 MHz)
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime(), ct1 = __builtin_amdgcn_s_memtime();
+        if (lane == 61) stampv = (unsigned)(ct1 - ct0);
+        if (lane == 62) stampv = (unsigned)(rt1 - rt0);
+        if (lane == 63) stampv = (unsigned)rt0;
+    }
     if (p.stamps != nullptr && wave == 0) p.stamps[blockIdx.x * 64 + lane] = stampv;
 #endif
 }
@@ -345,7 +352,8 @@ extern "C" int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, 
             if (cached[dev & 63] > 0) cus = cached[dev & 63];
         }
     }
-    int grid = g_sk_grid > 0 ? g_sk_grid : 2 * cus;
+    static const int env_grid = [] { const char* e = getenv("VQA_HOT_SHORTK_GRID"); return e ? atoi(e) : 0; }();   // tuning
+    int grid = g_sk_grid > 0 ? g_sk_grid : (env_grid > 0 ? env_grid : 2 * cus);
     if (grid > a.units) grid = a.units;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int kc = sk_chunks(K);

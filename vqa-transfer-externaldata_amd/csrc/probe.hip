@@ -193,6 +193,33 @@ extern "C" int vqa_stream_delay_us(float us, void* stream) {
     return VQA_OK;
 }
 
+// Shader-clock sampler: a few single-wave workgroups (dealt round-robin over the XCDs) that sleep beside whatever runs on the
+// other streams and, every `ticks` of the 100 MHz real-time counter, note how many shader cycles (s_memtime) went by.  The
+// f32 MFMA peak of the roofline assumes 2.4 GHz; under sustained matrix work the chip holds 2.05-2.2 GHz
+// (profiles/r3_gru_stamps.txt), and bench.py states the clock its step actually ran at.
+__global__ __launch_bounds__(64) void clock_sample_kernel(float* __restrict__ ghz, int n, unsigned long long ticks) {
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+        unsigned long long r1 = r0;
+        while (r1 - r0 < ticks) {
+            __builtin_amdgcn_s_sleep(64);
+            r1 = __builtin_amdgcn_s_memrealtime();
+        }
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) ghz[blockIdx.x * n + i] = (float)((double)(c1 - c0) / (double)(r1 - r0) * 0.1);
+    }
+}
+
+extern "C" int vqa_clock_sample(float us_per_sample, int n_samples, int n_workgroups, float* ghz_out, void* stream) {
+    VQA_REQUIRE(ghz_out != nullptr && us_per_sample >= 1.f && us_per_sample <= 1e5f && n_samples > 0 && n_samples <= 4096 &&
+                    n_workgroups > 0 && n_workgroups <= 64 && (double)us_per_sample * n_samples <= 2e6,
+                VQA_ERR_ARG);
+    hipLaunchKernelGGL(clock_sample_kernel, dim3(n_workgroups), dim3(64), 0, static_cast<hipStream_t>(stream), ghz_out,
+                       n_samples, (unsigned long long)(us_per_sample * 100.f + 0.5f));
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
 extern "C" int vqa_roctx_enable(int on) {
     r.on = on ? 1 : 0;
     return roctx_ready() == (on != 0) ? VQA_OK : VQA_ERR_UNSUPPORTED;
