@@ -561,6 +561,15 @@ int vqa_roctx_enable(int on);
 int vqa_gemm_bf16x3_supported(int M, int N, int K);
 int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                        const float* bias, void* stream);
+/* The same with a transposed left operand (transA = 1: A stored [K,M] -- dW = X^T dY) and split k (split_k ranges whose
+ * partial products meet in `workspace`, vqa_gemm_bf16x3_workspace_floats, and are summed in range order: deterministic).
+ * vqa_gemm_bf16x3_set_mode(1) (or VQA_HOT_BF16X3=1) makes vqa_gemm_f32 route its big whole-tile NN / TN products here
+ * (>= 2^32 multiply-adds, no addend): an opt-in numerics mode -- f32-equivalent products, not bit-identical sums -- that
+ * bench.py reports as a SEPARATE leg; 0 = off (default), -1 = back to the environment. */
+int64_t vqa_gemm_bf16x3_workspace_floats(int M, int N, int K, int split_k);
+int vqa_gemm_bf16x3(int transA, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, int split_k, float* workspace, int64_t workspace_floats, void* stream);
+int vqa_gemm_bf16x3_set_mode(int on);
 /* Short-K GEMM with the left operand stationary in registers (csrc/gemm_shortk.hip):
  *   C[M,N] = [relu]( (A[M,K] * B[K,N]) * scale[n] + bias[n] + D[M,N] )     row-major, bias / scale / D optional (NULL)
  * for K <= 304 -- the packed x-projection of the GRU (K = 300; replaces the x half of GRUCell's two matmuls,

@@ -170,6 +170,9 @@ SIGNATURES = {
     "vqa_gemm_shortk_set_mode": (_I, [_I]),
     "vqa_gemm_bf16x3_supported": (_I, [_I, _I, _I]),
     "vqa_gemm_bf16x3_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
+    "vqa_gemm_bf16x3_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "vqa_gemm_bf16x3": (_I, [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _L, _P]),
+    "vqa_gemm_bf16x3_set_mode": (_I, [_I]),
     "vqa_probe_disable": (_I, []),
     "vqa_fusion_workspace_bytes": (_L, [C.POINTER(Dims)]),
     "vqa_fusion_tensor": (_I, [C.POINTER(Dims), C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

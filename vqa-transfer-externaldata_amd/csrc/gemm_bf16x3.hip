@@ -14,6 +14,8 @@
 // work (~260 instructions per wave and k tile) rides in the issue slots between the 48 MFMAs of a k tile
 // (sched_group_barrier pattern) -- and fetch tile t + 2; one barrier per k tile.  (The first version, one buffer and two
 // workgroups per CU, kept the matrix pipe 45 % busy: profiles/r3_pmc_bf16x3.txt.)
+#include <algorithm>
+
 #include "vqa_common.h"
 
 namespace {
@@ -36,54 +38,78 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r;
 }
 
-__global__ __launch_bounds__(NT, 1) void gemm_bf16x3_nn_kernel(const float* __restrict__ A, int lda,
-                                                               const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                               int ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                               int tiles_n) {
+// A_KM: A is stored [K][M] (the transposed left operand of a weight gradient, dW = X^T dY); then both operands are k-major
+// and A's tile goes through the same 4 x 4 transposing loads as B's.  Split k: blockIdx.x = z * tiles + tile, slab z of
+// `C` (stride slab floats, leading dimension ldc) receives the partial product of k range z; bias rides in slab 0.
+template <bool A_KM>
+__global__ __launch_bounds__(NT, 1) void gemm_bf16x3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                            int ldb, float* __restrict__ C, int ldc,
+                                                            const float* __restrict__ bias, int M, int N, int K, int tiles_n,
+                                                            int tiles, int k_per_split, int64_t slab) {
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];      // [A planes | B planes]
     __bf16* sA = lds;
     __bf16* sB = lds + OPER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
+    const int z = blockIdx.x / tiles, tile = blockIdx.x - z * tiles;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;           // the wave's 64 x 64 corner of the tile
+    const int kbeg = z * k_per_split, kend = min(K, kbeg + k_per_split);
+    C += z * slab;
+    if (z > 0) bias = nullptr;
 
-    // A tile [128 rows][32 k]: thread -> (row = idx / 8, 4 consecutive k): one 16-byte load, 8 lanes cover a 128-byte row
-    // B tile [32 k][128 n]:    thread -> a 4 (k) x 4 (n) block: four 16-byte loads from consecutive k rows (8 lanes cover
-    //                          128 contiguous bytes of a row), transposed in registers into 4 k-consecutive bf16 (8 bytes)
-    //                          for each of its 4 columns
+    // A tile [128 rows][32 k], A row-major: thread -> (row = idx / 8, 4 consecutive k): one 16-byte load, 8 lanes cover a
+    //                          128-byte row
+    // B tile [32 k][128 n] (and A's when A_KM): thread -> a 4 (k) x 4 (n) block: four 16-byte loads from consecutive k rows
+    //                          (8 lanes cover 128 contiguous bytes of a row), transposed in registers into 4 k-consecutive
+    //                          bf16 (8 bytes) for each of its 4 columns
     f32x4n ra[4];
     f32x4n rb[4];
     const float* pa[4];
     const float* pb;
+    const int bk4 = (tid % 8) * 4, bn4 = (tid / 8) * 4;            // the block's first k and first column inside the tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * NT;
-        pa[i] = A + (int64_t)(m0 + idx / 8) * lda + (idx % 8) * 4;
+        pa[i] = A_KM ? A + (int64_t)(kbeg + bk4 + i) * lda + m0 + bn4 : A + (int64_t)(m0 + idx / 8) * lda + kbeg + (idx % 8) * 4;
     }
-    const int bk4 = (tid % 8) * 4, bn4 = (tid / 8) * 4;            // the block's first k and first column inside the tile
-    pb = B + (int64_t)bk4 * ldb + n0 + bn4;
+    pb = B + (int64_t)(kbeg + bk4) * ldb + n0 + bn4;
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4n*>(pa[i] + k0);
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4n*>(A_KM ? pa[i] + (int64_t)k0 * lda : pa[i] + k0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4n*>(pb + (int64_t)(k0 + i) * ldb);
     };
     auto stage = [&]() {
+        if (A_KM) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * NT;
-            const int row = idx / 8, kq = (idx % 8) * 4;
-            bf16x4 h, m, l;
+            for (int j = 0; j < 4; ++j) {                 // row (of the tile) bn4 + j: its four consecutive k
+                bf16x4 h, m, l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __bf16 a, b, c;
-                split3(ra[i][j], a, b, c);
-                h[j] = a; m[j] = b; l[j] = c;
+                for (int i = 0; i < 4; ++i) {
+                    __bf16 a, b, c;
+                    split3(ra[i][j], a, b, c);
+                    h[i] = a; m[i] = b; l[i] = c;
+                }
+                *reinterpret_cast<bf16x4*>(sA + (bn4 + j) * RS + bk4) = h;
+                *reinterpret_cast<bf16x4*>(sA + PLANE + (bn4 + j) * RS + bk4) = m;
+                *reinterpret_cast<bf16x4*>(sA + 2 * PLANE + (bn4 + j) * RS + bk4) = l;
             }
-            *reinterpret_cast<bf16x4*>(sA + row * RS + kq) = h;
-            *reinterpret_cast<bf16x4*>(sA + PLANE + row * RS + kq) = m;
-            *reinterpret_cast<bf16x4*>(sA + 2 * PLANE + row * RS + kq) = l;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx / 8, kq = (idx % 8) * 4;
+                bf16x4 h, m, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __bf16 a, b, c;
+                    split3(ra[i][j], a, b, c);
+                    h[j] = a; m[j] = b; l[j] = c;
+                }
+                *reinterpret_cast<bf16x4*>(sA + row * RS + kq) = h;
+                *reinterpret_cast<bf16x4*>(sA + PLANE + row * RS + kq) = m;
+                *reinterpret_cast<bf16x4*>(sA + 2 * PLANE + row * RS + kq) = l;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                 // column bn4 + j: its four consecutive k
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(NT, 1) void gemm_bf16x3_nn_kernel(const float* __re
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int fr = lane & 31, fk = (lane >> 5) * 8;      // the lane's row / column inside a 32-wide MFMA tile, its 8 k
-    const int nk = K / BK;
+    const int nk = (kend - kbeg) / BK;
     constexpr int BUF = 2 * OPER;                         // bf16 per LDS buffer (A planes | B planes)
     auto stage_into = [&](int buf) {
         sA = lds + buf * BUF;
@@ -195,23 +221,75 @@ extern "C" int vqa_gemm_bf16x3_supported(int M, int N, int K) {
     return (M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % BK == 0) ? 1 : 0;
 }
 
-extern "C" int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                                  const float* bias, void* stream) {
-    VQA_REQUIRE(A && B && C, VQA_ERR_ARG);
-    VQA_REQUIRE(vqa_gemm_bf16x3_supported(M, N, K) == 1, VQA_ERR_UNSUPPORTED);
-    VQA_REQUIRE(lda >= K && ldb >= N && ldc >= N, VQA_ERR_ARG);
-    VQA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && vqa_aligned16(A) && vqa_aligned16(B), VQA_ERR_ALIGN);
+namespace {
+// C[m, n] = sum_z slab[z][m, n]   (slabs dense M x N)
+__global__ __launch_bounds__(256) void bf16x3_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, int M, int N,
+                                                            int ldc, int S) {
+    const int64_t n4 = (int64_t)M * N / 4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4n v = reinterpret_cast<const f32x4n*>(slabs)[i];
+        for (int z = 1; z < S; ++z) v += reinterpret_cast<const f32x4n*>(slabs + (int64_t)z * M * N)[i];
+        const int64_t e = i * 4;
+        const int row = (int)(e / N), col = (int)(e % N);
+        *reinterpret_cast<f32x4n*>(C + (int64_t)row * ldc + col) = v;
+    }
+}
+
+template <bool A_KM>
+int bf16x3_go(const float* A, int lda, const float* B, int ldb, float* C, int ldc, const float* bias, int M, int N, int K,
+              int split, int kps, int64_t slab, hipStream_t st) {
     constexpr size_t lds_bytes = (size_t)2 * 2 * OPER * sizeof(__bf16);      // two buffers of (A planes | B planes)
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_nn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<A_KM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return VQA_ERR_LAUNCH;
         attr = true;
     }
-    const int tiles_n = N / BN;
-    hipLaunchKernelGGL(gemm_bf16x3_nn_kernel, dim3((unsigned)((M / BM) * tiles_n)), dim3(NT), lds_bytes,
-                       static_cast<hipStream_t>(stream), A, lda, B, ldb, C, ldc, bias, M, N, K, tiles_n);
+    const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
+    hipLaunchKernelGGL(gemm_bf16x3_kernel<A_KM>, dim3((unsigned)(tiles * split)), dim3(NT), lds_bytes, st, A, lda, B, ldb, C, ldc,
+                       bias, M, N, K, tiles_n, tiles, kps, slab);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
+}
+}  // namespace
+
+// floats of workspace vqa_gemm_bf16x3 needs for its split-k slabs (0: none)
+extern "C" int64_t vqa_gemm_bf16x3_workspace_floats(int M, int N, int K, int split_k) {
+    return split_k > 1 ? (int64_t)split_k * M * N : 0;
+}
+
+// C[M,N] = op(A) B (+ bias): transA = 0: A [M,K]; 1: A stored [K,M].  split_k <= 1: one pass; else k is cut into
+// split_k ranges (multiples of 32) whose partial products meet in `workspace` and are summed in slab order.
+extern "C" int vqa_gemm_bf16x3(int transA, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                               int ldc, const float* bias, int split_k, float* workspace, int64_t workspace_floats,
+                               void* stream) {
+    VQA_REQUIRE(A && B && C, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_gemm_bf16x3_supported(M, N, K) == 1, VQA_ERR_UNSUPPORTED);
+    VQA_REQUIRE(lda >= (transA ? M : K) && ldb >= N && ldc >= N, VQA_ERR_ARG);
+    VQA_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && vqa_aligned16(A) && vqa_aligned16(B), VQA_ERR_ALIGN);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int split = split_k > 1 ? split_k : 1;
+    int kps = ((K / split + BK - 1) / BK) * BK;
+    if (kps < BK) kps = BK;
+    split = (K + kps - 1) / kps;
+    if (split <= 1)
+        return transA ? bf16x3_go<true>(A, lda, B, ldb, C, ldc, bias, M, N, K, 1, K, 0, st)
+                      : bf16x3_go<false>(A, lda, B, ldb, C, ldc, bias, M, N, K, 1, K, 0, st);
+    VQA_REQUIRE(workspace != nullptr && workspace_floats >= (int64_t)split * M * N && ldc % 4 == 0 && vqa_aligned16(C) &&
+                    vqa_aligned16(workspace),
+                VQA_ERR_WORKSPACE);
+    const int rc = transA ? bf16x3_go<true>(A, lda, B, ldb, workspace, N, bias, M, N, K, split, kps, (int64_t)M * N, st)
+                          : bf16x3_go<false>(A, lda, B, ldb, workspace, N, bias, M, N, K, split, kps, (int64_t)M * N, st);
+    if (rc != VQA_OK) return rc;
+    const int64_t n4 = (int64_t)M * N / 4;
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(bf16x3_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, C, M, N, ldc, split);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_gemm_bf16x3_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                  const float* bias, void* stream) {
+    return vqa_gemm_bf16x3(0, M, N, K, A, lda, B, ldb, C, ldc, bias, 1, nullptr, 0, stream);
 }

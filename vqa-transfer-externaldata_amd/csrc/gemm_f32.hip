@@ -1237,6 +1237,18 @@ inline int shortk_mode() {
     }
     return g_shortk_mode;
 }
+int g_bf16x3_mode = -1;
+inline int bf16x3_mode() {
+    if (g_bf16x3_mode < 0) {
+        const char* e = getenv("VQA_HOT_BF16X3");
+        g_bf16x3_mode = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_bf16x3_mode;
+}
+extern "C" int vqa_gemm_bf16x3_set_mode(int on) {
+    g_bf16x3_mode = on < 0 ? -1 : (on ? 1 : 0);
+    return VQA_OK;
+}
 extern "C" int vqa_gemm_shortk_set_mode(int mode) {
     g_shortk_mode = mode < 0 ? -1 : (mode & 3);
     return VQA_OK;
@@ -1277,6 +1289,17 @@ extern "C" int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, cons
     VQA_REQUIRE(D == nullptr || ldd >= N, VQA_ERR_ARG);
     hipStream_t st = static_cast<hipStream_t>(stream);
 
+    // EXPERIMENT, off unless asked for (VQA_HOT_BF16X3=1 / vqa_gemm_bf16x3_set_mode): the big whole-tile products -- v_linear_v
+    // forward and weight gradient, the recurrent weight gradients -- on the bf16 matrix pipe through three-way operand
+    // splits (gemm_bf16x3.hip); the headline path is the exact f32 MFMA below
+    if (bf16x3_mode() && !transB && D == nullptr && max_blocks == 0 && g_force_cfg < 0 && vqa_gemm_bf16x3_supported(M, N, K) &&
+        (int64_t)M * N * K >= (1ll << 32) && lda % 4 == 0 && ldb % 4 == 0 && vqa_aligned16(A) && vqa_aligned16(B)) {
+        const int tiles = (M / 128) * (N / 128);
+        int sp = 1;
+        while (tiles * sp < 256 && K / (sp * 2) >= 512 && sp < 16) sp *= 2;
+        while (sp > 1 && (workspace == nullptr || workspace_floats < (int64_t)sp * M * N || ldc % 4 != 0 || !vqa_aligned16(C))) sp /= 2;
+        return vqa_gemm_bf16x3(transA, M, N, K, A, lda, B, ldb, C, ldc, bias, sp, workspace, workspace_floats, stream);
+    }
     // K <= 304, NN: the kernel with A stationary in registers (gemm_shortk.hip) -- the GRU's packed x-projection
     if (!transA && !transB && split_k <= 1 && max_blocks == 0 && g_force_cfg < 0 && (shortk_mode() & 1) &&
         vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) && !(K > 256 && D != nullptr) && vqa_aligned16(A) &&

@@ -171,6 +171,22 @@ def gemm_shortk(A, B, bias=None, scale=None, residual=None, relu=False, out=None
     return Cm
 
 
+def gemm_bf16x3_ex(A, B, transA=False, bias=None, split_k=1, out=None):
+    """EXPERIMENT: op(A) @ B (+ bias) on the bf16 matrix pipe through three-way splits; transA: A is [K, M]; split k with
+    a deterministic slab sum (csrc/gemm_bf16x3.hip)."""
+    lib = _lib.load()
+    assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.stride(-1) == 1 and B.stride(-1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[1]
+    assert B.shape[0] == K
+    Cm = out if out is not None else _f32(M, N, like=A)
+    nws = int(lib.vqa_gemm_bf16x3_workspace_floats(M, N, K, split_k))
+    ws = _f32(max(nws, 4), like=A)
+    _lib.check(lib.vqa_gemm_bf16x3(int(transA), M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(Cm), Cm.stride(0),
+                                   _p(bias), split_k, _p(ws), ws.numel(), _st(A)), "vqa_gemm_bf16x3")
+    return Cm
+
+
 def gemm_bf16x3(A, B, bias=None, out=None):
     """EXPERIMENT: C = A @ B (+ bias) through three-way bf16 splits and six bf16 MFMA products per a*b (f32-equivalent
     products; csrc/gemm_bf16x3.hip).  Whole 128 x 128 x 32 tiles only; the product path uses gemm() (exact f32 MFMA)."""
