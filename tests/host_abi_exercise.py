@@ -116,4 +116,36 @@ ok(lib.vqa_probe_read(None, 4, C.byref(cnt)) == -1, "probe read null")
 ok(lib.vqa_probe_disable() == 0 and lib.vqa_probe_disable() == 0, "probe disable twice")
 ok(lib.vqa_roctx_enable(0) == 0, "roctx off")
 
+# round-3 entry points: shape predicates and argument validation (everything that returns before a launch)
+for (M, N, K, lda, ldb, ldc, want) in ((7168, 3072, 300, 304, 3072, 3072, 1), (128, 64, 308, 308, 64, 64, 0), (128, 48, 64, 64, 48, 48, 0),
+                                       (128, 64, 62, 64, 64, 64, 0), (128, 64, 64, 66, 64, 64, 0), (0, 64, 64, 64, 64, 64, 0),
+                                       (128, 64, 64, 60, 64, 64, 0), (128, 64, 64, 64, 32, 64, 0), (128, 64, 64, 64, 64, 32, 0),
+                                       (1 << 30, 64, 64, 64, 64, 64, 0), (100, 32, 4, 4, 32, 32, 1)):
+    ok(lib.vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) == want, "shortk supported %r" % ((M, N, K, lda, ldb, ldc),))
+ok(lib.vqa_gemm_shortk_nn(128, 64, 64, None, 64, None, 64, None, 64, None, None, None, 0, 0, None) == -1, "shortk null operands")
+ok(lib.vqa_gemm_shortk_nn(128, 64, 308, C.c_void_p(4096), 308, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, None, 0, 0,
+                          None) == -4, "shortk K too large")
+ok(lib.vqa_gemm_shortk_nn(128, 64, 64, C.c_void_p(4100), 64, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, None, 0, 0,
+                          None) == -2, "shortk misaligned A")
+ok(lib.vqa_gemm_shortk_nn(128, 64, 64, C.c_void_p(4096), 64, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, C.c_void_p(4096),
+                          32, 0, None) == -1, "shortk residual rows too short")
+ok(lib.vqa_gemm_shortk_set_grid(-5) == 0 and lib.vqa_gemm_shortk_set_grid(0) == 0, "shortk grid override")
+ok(lib.vqa_gemm_shortk_set_mode(7) == 0 and lib.vqa_gemm_shortk_set_mode(-1) == 0, "shortk mode")
+for (M, N, K, want) in ((256, 256, 2048, 1), (250, 256, 2048, 0), (256, 200, 2048, 0), (256, 256, 2040, 0), (0, 128, 32, 0)):
+    ok(lib.vqa_gemm_bf16x3_supported(M, N, K) == want, "bf16x3 supported %r" % ((M, N, K),))
+ok(lib.vqa_gemm_bf16x3_workspace_floats(256, 128, 4096, 4) == 4 * 256 * 128 and lib.vqa_gemm_bf16x3_workspace_floats(256, 128, 4096, 1) == 0,
+   "bf16x3 workspace")
+ok(lib.vqa_gemm_bf16x3(0, 256, 256, 2048, None, 2048, None, 256, None, 256, None, 1, None, 0, None) == -1, "bf16x3 null operands")
+ok(lib.vqa_gemm_bf16x3(0, 250, 256, 2048, C.c_void_p(4096), 2048, C.c_void_p(4096), 256, C.c_void_p(4096), 256, None, 1, None, 0,
+                       None) == -4, "bf16x3 ragged tile")
+ok(lib.vqa_gemm_bf16x3(1, 256, 256, 2048, C.c_void_p(4096), 128, C.c_void_p(4096), 256, C.c_void_p(4096), 256, None, 1, None, 0,
+                       None) == -1, "bf16x3 transposed leading dimension")
+ok(lib.vqa_gemm_bf16x3(0, 256, 256, 2048, C.c_void_p(4096), 2048, C.c_void_p(4096), 256, C.c_void_p(4096), 256, None, 4, None, 0,
+                       None) == -5, "bf16x3 split k without a workspace")
+ok(lib.vqa_gemm_bf16x3_set_mode(0) == 0 and lib.vqa_gemm_bf16x3_set_mode(-1) == 0, "bf16x3 mode")
+ok(lib.vqa_clock_sample(500.0, 8, 8, None, None) == -1 and lib.vqa_clock_sample(0.5, 8, 8, C.c_void_p(4096), None) == -1 and
+   lib.vqa_clock_sample(500.0, 0, 8, C.c_void_p(4096), None) == -1 and lib.vqa_clock_sample(500.0, 8, 65, C.c_void_p(4096), None) == -1 and
+   lib.vqa_clock_sample(1e5, 4096, 8, C.c_void_p(4096), None) == -1, "clock sampler arguments")
+ok(lib.vqa_gemm_set_gru_config(30) == 0 and lib.vqa_gemm_set_gru_config(19) == -1 and lib.vqa_gemm_set_gru_config(-1) == 0, "gru config ids")
+
 print("host ABI exercise: %d checks passed on %s" % (checks, _lib.lib_path()))
