@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${PROF_TAG:-prof_final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-vfeat --no-e2e --no-pretrain --no-groups"
+B="python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-vfeat --no-e2e --no-pretrain --no-groups --no-bf16x3"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- $B > $O/trace.log 2>&1
 python3 $R/tools/trace_summary.py $O/trace/t_kernel_trace.csv 13 > $O/trace_summary.txt 2>&1 || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o f --output-format csv -- $B > $O/fetch.log 2>&1

@@ -1561,10 +1561,11 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     GemmArgs a = make_args(M, Co, K, x, Ci, w, Co, y, Co, shift, residual, Co);
     a.scale = scale;
     a.relu = relu;
-    if (plain && (shortk_mode() & 2) && Ci >= 128 && Ci <= 256 && g_conv_cfg_plain < 0 && g_force_cfg < 0 &&
+    if (plain && (shortk_mode() & 2) && Ci >= 128 && Ci <= 256 && Co >= 2 * Ci && g_conv_cfg_plain < 0 && g_force_cfg < 0 &&
         vqa_gemm_shortk_supported(M, Co, K, Ci, Co, Co) && vqa_aligned16(x) && vqa_aligned16(w) &&
         (residual == nullptr || (int64_t)M * Co * 4 < 0xFFFFFFF0ll))
-        // 1x1 expansions and projections with Ci <= 256: the whole k extent of a row panel stays in registers
+        // 1x1 expansions with Ci 128..256 (Co >= 2 Ci: enough column tiles per row panel to pay for loading the panel into
+        // registers -- the 256 -> 64 reduction has two and loses, 595 against 481 us): the whole k extent stays in registers
         return vqa_gemm_shortk_nn(M, Co, K, x, Ci, w, Co, y, Co, shift, scale, residual, Co, relu, stream);
     if (plain) {
         // 64x64 tiles: the bottleneck 1x1 convolutions have short K (64..1024) and modest M.  The block-1/2 expansions
