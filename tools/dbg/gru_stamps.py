@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from vqa_transfer_externaldata_amd import _lib  # noqa: E402
 
-_lib._LIB_PATH = os.path.join(ROOT, "tools", "dbg", os.environ.get("GSTAMPS_LIB", "libvqahot_GSTAMPS.so"))
+_lib._LIB_PATH = os.path.join(ROOT, "tools", "dbg", "libvqahot_GSTAMPS.so")
 lib = _lib.load()
 T, B, H = 14, int(os.environ.get("GRU_B", 512)), 1024
 g = torch.Generator(device="cuda").manual_seed(0)

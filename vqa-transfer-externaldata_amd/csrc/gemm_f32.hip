@@ -355,14 +355,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
     const int e_row0 = wk * RPG + e_lr;                       // row inside the 32x32 sub-tile (+ 8 i)
     float4 e_d[NI], e_x0[NI], e_x1[NI], e_x2[NI];
     int e_lim[NI];
-    // WHEN they are requested matters: vector-memory data returns in issue order, so requests in front of the first
-    // operand tile's make that tile wait for the slowest of them (0.8 us of a gates launch, in-kernel stamps).  The
-    // two-tile-prefetch loop (every fused GRU launch) therefore issues them right BEHIND its first two tiles.
-#if defined(VQA_DBG_NOSIDE)   // timing experiment: no side-input requests at all (results garbage)
-    auto side_inputs = [&]() { if (false) {
-#else
-    auto side_inputs = [&]() { if (EPI != EPI_PLAIN && e_act) {
-#endif
+    if (EPI != EPI_PLAIN && e_act) {
         const int gcol = n0 + wn * WN + (lane & 7) * 4;
         const int grow0 = m0 + wm * WM + e_row0;
 #pragma unroll
@@ -390,12 +383,7 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
                 e_lim[i] = ep.len[grow];
             }
         }
-    } };
-#if defined(VQA_SIDE_FIRST)   // A/B build: the round-2 order (side inputs in front of the first tile)
-    side_inputs();
-#else
-    if (DEEP == 0) side_inputs();
-#endif
+    }
     float* L0 = smem;
     float* L1 = smem + (A_FL + B_FL);
 
@@ -648,9 +636,6 @@ __global__ __launch_bounds__(NT, (CONV && NT == 256) ? 4 : 1) void gemm_f32_kern
         auto st1 = [&]() { sa1.store(L1); sb1.store(L1 + A_FL); };
         if (nt > 0) ld0(0);
         if (nt > 1) ld1(1);
-#if !defined(VQA_SIDE_FIRST)
-        side_inputs();
-#endif
         if (nt > 0) st0();
         __syncthreads();
         DBG_STAMP(1);                                        // first tile in LDS
