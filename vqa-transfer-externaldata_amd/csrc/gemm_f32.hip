@@ -20,6 +20,7 @@
 
 #include "vqa_common.h"
 #include "gemm_args.h"
+#include <cstdio>
 #include <cstdlib>
 
 #ifndef VQA_GEMM_STAGGER
@@ -1168,6 +1169,15 @@ inline int tall_small_cfg() {      // VQA_HOT_TALL_SMALL_CFG: tuning override (-
     return v < NUM_CFG ? v : 12;
 }
 
+inline int tune_pair(const char* env, int cfg, int split) {     // "cfg:split" from the environment, packed cfg << 8 | split
+    const char* e = getenv(env);
+    if (e != nullptr) {
+        int c = 0, s = 0;
+        if (sscanf(e, "%d:%d", &c, &s) == 2 && c >= 0 && c < NUM_CFG && s >= 0 && s <= 16) { cfg = c; split = s; }
+    }
+    return (cfg << 8) | split;
+}
+
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
     if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
@@ -1179,12 +1189,26 @@ void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
         if (N >= 512 && cdiv(M, 128) * cdiv(N, 64) < 1024 && tall_small_cfg() >= 0) cfg = tall_small_cfg();
     }
     else { cfg = (!tB && N > 2048) ? 13 : 23; target = 256; }
-    if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) cfg = g_force_cfg;
+    // The two long-k products around the packed x-projection (W = 300): dx = dxp Wx^T (tall, 300 columns, k = 3H) and
+    // dWx = x^T dxp (300 rows, k = T B).  Their loss is tile quantisation (7 x 2^10 rows against 256 CUs); a k split
+    // evens the rounds out: dx 129.6 -> 119.4 us (64x64 tiles, split 4), dWx 122.8 -> 114.2 us (64x128, split 4)
+    // (profiles/r3_k300_tune.txt).  VQA_HOT_DX_TUNE / VQA_HOT_DWX_TUNE = "cfg:split" override (0:0 = the old choice).
+    int want_split = 0;
+    if (!tA && tB && M >= 4096 && N <= 320 && K >= 2048) {
+        static const int t = tune_pair("VQA_HOT_DX_TUNE", 3, 4);
+        if (t >> 8) { cfg = t >> 8; want_split = t & 255; }
+    } else if (tA && M <= 320 && N >= 2048 && K >= 4096) {
+        static const int t = tune_pair("VQA_HOT_DWX_TUNE", 21, 4);
+        if (t >> 8) { cfg = t >> 8; want_split = t & 255; }
+    }
+    if (g_force_cfg >= 0 && g_force_cfg < NUM_CFG) { cfg = g_force_cfg; want_split = 0; }
     const int64_t blocks = cdiv(M, kCfg[cfg].BM) * cdiv(N, kCfg[cfg].BN);
     if (split <= 0) {
         split = 1;
         if ((N % 4) == 0) {
-            while (blocks * split < target && K / (split * 2) >= 256 && split < 16) split *= 2;
+            if (want_split > 0) split = want_split;
+            else
+                while (blocks * split < target && K / (split * 2) >= 256 && split < 16) split *= 2;
         }
     }
 }
