@@ -1180,7 +1180,13 @@ inline int tune_pair(const char* env, int cfg, int split) {     // "cfg:split" f
 
 void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
     int64_t target;
-    if (tA) { cfg = ((int64_t)M * N >= (1 << 20)) ? 19 : 3; target = 512; }
+    if (tA) {
+        // weight gradients: 128x128 tiles of 16-deep k tiles for the long ones; up to k = 4096 the 128x64 tile of 32-deep k
+        // tiles is 5 % (1024 x 2048 x 2560) to 23 % (the answer head's 2048 x 3000 x 512) faster (profiles/r3_tn_tune.txt)
+        static const int tn_short = env_cfg("VQA_HOT_TN_SHORT_CFG", 20);
+        cfg = ((int64_t)M * N >= (1 << 20)) ? (K <= 4096 ? tn_short : 19) : 3;
+        target = 512;
+    }
     else if (M >= 2048) {
         cfg = (N >= 512) ? (K >= 2048 ? g_tall_cfg : 22) : 13;
         target = 256;
