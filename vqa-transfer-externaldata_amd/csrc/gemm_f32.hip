@@ -1184,7 +1184,9 @@ void choose(int tA, int tB, int M, int N, int K, int& cfg, int& split) {
         // weight gradients: 128x128 tiles of 16-deep k tiles for the long ones; up to k = 4096 the 128x64 tile of 32-deep k
         // tiles is 5 % (1024 x 2048 x 2560) to 23 % (the answer head's 2048 x 3000 x 512) faster (profiles/r3_tn_tune.txt)
         static const int tn_short = env_cfg("VQA_HOT_TN_SHORT_CFG", 20);
-        cfg = ((int64_t)M * N >= (1 << 20)) ? (K <= 4096 ? tn_short : 19) : 3;
+        static const int tn_mid = env_cfg("VQA_HOT_TN_MID_CFG", 20);   // (k < 20000, at most 128 tiles of 128x128: v_linear_v and recurrent dW, -5 and -9 us)
+        const bool mid = K < 20000 && cdiv(M, 128) * cdiv(N, 128) <= 128;
+        cfg = ((int64_t)M * N >= (1 << 20)) ? (K <= 4096 ? tn_short : (mid ? tn_mid : 19)) : 3;
         target = 512;
     }
     else if (M >= 2048) {
