@@ -221,6 +221,9 @@ def _vfeat_setup(device, batch):
     return model, {"image": img, "normal_box": box}
 
 
+NO_BF16X3 = False      # --no-bf16x3: skip the experiment legs
+
+
 def _dist_max(x, device):
     """max over the ranks of a host float (1 rank: itself)"""
     import torch
@@ -390,6 +393,22 @@ def pretrain_bench(device, steps=10, warmup=3, world=1, rank=0):
            "workload": "cfg-5 pre-training step (vlmap_bf_or_wordset_withatt_sp): fwd + bwd + clip + Adam, global batch 512 "
                        "images x 5 entries x {object, attribute}, 4000 answers, captions of 1..10 tokens encoded as one "
                        "length-sorted batch (BASELINE configs[4], stage 1)"}
+    if world == 1 and not NO_BF16X3:
+        # the same step with the opt-in bf16 x 3 mode on the big whole-tile products (an EXPERIMENT, see experiment_bf16x3)
+        from vqa_transfer_externaldata_amd import _lib
+        lib = _lib.load()
+        _lib.check(lib.vqa_gemm_bf16x3_set_mode(1), "vqa_gemm_bf16x3_set_mode")
+        try:
+            for i in range(2):
+                step(i)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(steps):
+                step(2 + i)
+            torch.cuda.synchronize()
+            out["experiment_bf16x3_ms_per_step"] = (time.perf_counter() - tb) / steps * 1e3
+        finally:
+            _lib.check(lib.vqa_gemm_bf16x3_set_mode(0), "vqa_gemm_bf16x3_set_mode")
     if reducer is not None:
         ex = reducer.exposed_ms()
         out.update(ranks=world, images_per_rank=B, scaling="strong",
@@ -522,6 +541,8 @@ def groups_pass(eng, lib, batches, cfg, rank, steps=10):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    global NO_BF16X3
+    NO_BF16X3 = bool(args.no_bf16x3)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
 
