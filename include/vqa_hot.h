@@ -584,6 +584,7 @@ int vqa_gemm_shortk_supported(int M, int N, int K, int lda, int ldb, int ldc);
 int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                        const float* bias, const float* scale, const float* D, int ldd, int relu, void* stream);
 int vqa_gemm_shortk_set_grid(int n);
+int vqa_gemm_shortk_set_waves(int n);   /* tuning: 4 (two workgroups per CU) or 8 (one) waves per workgroup; 0 = default */
 int vqa_gemm_shortk_set_mode(int mode);
 /* Shader-clock sampler: enqueues, on `stream`, n_workgroups single-wave workgroups that for n_samples periods of
  * us_per_sample microseconds (100 MHz real-time counter) note the shader cycles that went by; ghz_out (device memory,

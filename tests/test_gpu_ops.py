@@ -727,6 +727,15 @@ def test_shortk_gemm_matches_float64(M, N, K, lda):
             assert torch.equal(ops.gemm_shortk(A, B, bias=bias), ref), grid
     finally:
         _lib.check(lib.vqa_gemm_shortk_set_grid(0), "grid")
+    # the other workgroup shape (8 waves, one workgroup per CU / 4 waves, two per CU) computes the same bits
+    try:
+        for waves in (4, 8):
+            _lib.check(lib.vqa_gemm_shortk_set_waves(waves), "waves")
+            assert torch.equal(ops.gemm_shortk(A, B, bias=bias), ref), waves
+            got = ops.gemm_shortk(A, B, bias=bias, scale=scale, residual=res, relu=True)
+            close(got, want, **tol)
+    finally:
+        _lib.check(lib.vqa_gemm_shortk_set_waves(0), "waves")
     # the general kernel agrees to rounding (different summation order)
     close(ops.gemm(A, B, bias=bias), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
 

@@ -35,6 +35,8 @@ shapes = [("xp  (GRU x-projection)", 7168, 3072, 300, 304, False),
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].split()[0] in sys.argv[1].split(",")]
 grids = [int(x) for x in os.environ.get("SK_GRIDS", "0,256,768,1024").split(",")]
+if os.environ.get("SK_WAVES"):
+    _lib.check(_lib.load().vqa_gemm_shortk_set_waves(int(os.environ["SK_WAVES"])), "waves")
 lib = _lib.load()
 for name, M, N, K, lda, epi in shapes:
     Afull = torch.randn(M, lda, device="cuda", generator=g)

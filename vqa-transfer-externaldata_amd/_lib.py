@@ -167,6 +167,7 @@ SIGNATURES = {
     "vqa_gemm_shortk_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "vqa_gemm_shortk_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P]),
     "vqa_gemm_shortk_set_grid": (_I, [_I]),
+    "vqa_gemm_shortk_set_waves": (_I, [_I]),
     "vqa_gemm_shortk_set_mode": (_I, [_I]),
     "vqa_gemm_bf16x3_supported": (_I, [_I, _I, _I]),
     "vqa_gemm_bf16x3_nn": (_I, [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P]),

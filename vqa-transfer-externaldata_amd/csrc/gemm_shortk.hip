@@ -33,8 +33,11 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int SK_NT = 256;             // 4 waves, 32 rows each
-constexpr int SK_BM = 128;
+// WV waves per workgroup, 32 rows each (template parameter): 4 = two workgroups per CU (default), 8 = ONE workgroup per CU
+// whose two waves per SIMD share the B tile (half the DMA traffic) and start together -- written because in the
+// two-workgroup form the second workgroup's A loads starve behind the first one's MFMA chains for ~40 k cycles
+// (profiles/r3_shortk_stamps.txt).  In situ the two forms tie (x-projection 119.6 against 121.5 us, extractor 2134 against
+// 2139 imgs/s, profiles/r3_shortk_ab.txt); VQA_HOT_SHORTK_WAVES / vqa_gemm_shortk_set_waves select.
 constexpr unsigned SK_OOB = 0xFFFFFFF0u;
 
 
@@ -68,10 +71,11 @@ __device__ __forceinline__ int sk_xcd_remap(int lin, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int KC, bool RES>
-__global__ __launch_bounds__(SK_NT, 2) void shortk_nn_kernel(SkArgs p) {
+template <int KC, bool RES, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void shortk_nn_kernel(SkArgs p) {
+    constexpr int SK_NT = 64 * WV, SK_BM = 32 * WV, RPR = 8 * WV;       // threads, rows of a panel, B rows per DMA round
     constexpr int KP = 8 * KC, TILE = KP * 32;
-    constexpr int NSTG = (KP + 31) / 32;                    // DMA wave-instructions per B tile and wave
+    constexpr int NSTG = (KP + RPR - 1) / RPR;              // DMA wave-instructions per B tile and wave
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x [KP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, s = lane >> 5;
@@ -112,16 +116,16 @@ __global__ __launch_bounds__(SK_NT, 2) void shortk_nn_kernel(SkArgs p) {
     // descriptor (nothing is fetched for them); they are zeroed here once as well.
     // A last round of fewer than 32 rows (KP % 32 != 0) is fetched by ALL waves, the spare ones doubling the others'
     // rows (same bytes to the same place): no branch, the unit loop stays one basic block.
-    constexpr int LASTW = (KP % 32 == 0) ? 4 : (KP % 32) / 8;           // waves the last round needs
+    constexpr int LASTW = (KP % RPR == 0) ? WV : (KP % RPR) / 8;        // waves the last round needs
     const int wl = wave % LASTW;
     const int brow = 8 * wave + (lane >> 3), brow_l = 8 * wl + (lane >> 3);
     const unsigned b_voff = ((unsigned)(brow ^ ((brow >> 2) & 1)) * (unsigned)p.ldb + (unsigned)(lane & 7) * 4u) * 4u;
     const unsigned b_voff_l = ((unsigned)(brow_l ^ ((brow_l >> 2) & 1)) * (unsigned)p.ldb + (unsigned)(lane & 7) * 4u) * 4u;
-    const unsigned b_step = 32u * (unsigned)p.ldb * 4u;
+    const unsigned b_step = (unsigned)RPR * (unsigned)p.ldb * 4u;
     auto dma_round = [&](int i, int nt, float* buf) {
-        const bool last = (KP % 32 != 0) && (i + 1 == NSTG);
+        const bool last = (KP % RPR != 0) && (i + 1 == NSTG);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsB, (__attribute__((address_space(3))) void*)(buf + (8 * (last ? wl : wave) + 32 * i) * 32), 16,
+            rsB, (__attribute__((address_space(3))) void*)(buf + (8 * (last ? wl : wave) + RPR * i) * 32), 16,
             last ? b_voff_l : b_voff, (unsigned)nt * 128u + (unsigned)i * b_step, 0, 0);
     };
     auto fetch_b = [&](int nt, float* buf) {
@@ -271,19 +275,19 @@ __global__ __launch_bounds__(SK_NT, 2) void shortk_nn_kernel(SkArgs p) {
 #endif
 }
 
-template <int KC, bool RES>
+template <int KC, bool RES, int WV>
 int sk_launch(const SkArgs& a, int grid, hipStream_t st) {
     constexpr int lds = 2 * 8 * KC * 32 * (int)sizeof(float);
     static bool raised[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return VQA_ERR_LAUNCH;
     if (lds > 65536 && !raised[dev & 63]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(shortk_nn_kernel<KC, RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(shortk_nn_kernel<KC, RES, WV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return VQA_ERR_LAUNCH;
         raised[dev & 63] = true;
     }
-    hipLaunchKernelGGL((shortk_nn_kernel<KC, RES>), dim3(grid), dim3(SK_NT), lds, st, a);
+    hipLaunchKernelGGL((shortk_nn_kernel<KC, RES, WV>), dim3(grid), dim3(64 * WV), lds, st, a);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
@@ -297,7 +301,9 @@ inline int sk_chunks(int K) {   // template instance (k chunks of 8) that holds 
 }
 
 unsigned* g_sk_stamps = nullptr;
-int g_sk_grid = 0;   // tuning override of the number of workgroups (vqa_gemm_shortk_set_grid); 0 = two per CU
+int g_sk_grid = 0;   // tuning override of the number of workgroups (vqa_gemm_shortk_set_grid); 0 = all resident at once
+int g_sk_waves = 0;  // tuning override of the waves per workgroup (vqa_gemm_shortk_set_waves): 4 or 8
+constexpr int SK_DEFAULT_WAVES = 4;
 
 }  // namespace
 
@@ -309,6 +315,11 @@ extern "C" int vqa_gemm_shortk_supported(int M, int N, int K, int lda, int ldb, 
         (int64_t)K * ldb * 4 >= (int64_t)0xFFFFFFF0u)
         return 0;
     return 1;
+}
+
+extern "C" int vqa_gemm_shortk_set_waves(int n) {
+    g_sk_waves = (n == 4 || n == 8) ? n : 0;
+    return VQA_OK;
 }
 
 extern "C" int vqa_gemm_shortk_set_grid(int n) {
@@ -334,7 +345,10 @@ extern "C" int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, 
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.scale = scale; a.D = D;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldd = ldd; a.relu = relu;
     a.n_tiles = N / 32;
-    const int64_t units = (int64_t)((M + SK_BM - 1) / SK_BM) * a.n_tiles;
+    static const int env_waves = [] { const char* e = getenv("VQA_HOT_SHORTK_WAVES"); return e ? atoi(e) : 0; }();   // tuning: 4 / 8
+    const int waves = g_sk_waves > 0 ? g_sk_waves : (env_waves == 4 || env_waves == 8 ? env_waves : SK_DEFAULT_WAVES);
+    const int bm = 32 * waves;
+    const int64_t units = (int64_t)((M + bm - 1) / bm) * a.n_tiles;
     VQA_REQUIRE(units < (1ll << 30), VQA_ERR_ARG);
     a.units = (int)units;
     a.a_bytes = (unsigned)((int64_t)M * lda * 4);
@@ -353,14 +367,15 @@ extern "C" int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, 
         }
     }
     static const int env_grid = [] { const char* e = getenv("VQA_HOT_SHORTK_GRID"); return e ? atoi(e) : 0; }();   // tuning
-    int grid = g_sk_grid > 0 ? g_sk_grid : (env_grid > 0 ? env_grid : 2 * cus);
+    int grid = g_sk_grid > 0 ? g_sk_grid : (env_grid > 0 ? env_grid : (waves == 8 ? cus : 2 * cus));
     if (grid > a.units) grid = a.units;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int kc = sk_chunks(K);
     const bool res = D != nullptr;
-#define SK_GO(KC_)                                                                      \
-    case KC_:                                                                           \
-        return res ? sk_launch<KC_, true>(a, grid, st) : sk_launch<KC_, false>(a, grid, st);
+#define SK_GO(KC_)                                                                                            \
+    case KC_:                                                                                                 \
+        if (waves == 8) return res ? sk_launch<KC_, true, 8>(a, grid, st) : sk_launch<KC_, false, 8>(a, grid, st); \
+        return res ? sk_launch<KC_, true, 4>(a, grid, st) : sk_launch<KC_, false, 4>(a, grid, st);
     switch (kc) {
         SK_GO(8)
         SK_GO(16)
