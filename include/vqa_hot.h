@@ -572,11 +572,11 @@ int vqa_gemm_bf16x3(int transA, int M, int N, int K, const float* A, int lda, co
 int vqa_gemm_bf16x3_set_mode(int on);
 /* Short-K GEMM with the left operand stationary in registers (csrc/gemm_shortk.hip):
  *   C[M,N] = [relu]( (A[M,K] * B[K,N]) * scale[n] + bias[n] + D[M,N] )     row-major, bias / scale / D optional (NULL)
- * for K <= 304 -- the packed x-projection of the GRU (K = 300; replaces the x half of GRUCell's two matmuls,
+ * for K <= 512 -- the packed x-projection of the GRU (K = 300; replaces the x half of GRUCell's two matmuls,
  * vlmap/modules.py:124-140) and the extractor's 1x1 expansion convolutions (K = Ci = 64 / 128 / 256) with their folded
- * BatchNorm, residual and ReLU.  Exact f32 MFMA (v_mfma_f32_32x32x2_f32), k summed in ascending order per output.
- * vqa_gemm_shortk_supported: 1 when the shape qualifies (K <= 304, K % 4 == 0, N % 32 == 0, lda / ldb % 4 == 0, operands
- * below 4 GB); vqa_gemm_f32 and vqa_conv2d_nhwc route qualifying calls here themselves (VQA_HOT_SHORTK=0 turns that off).
+ * BatchNorm, residual and ReLU (K = Ci = 128 / 256 / 512).  Exact f32 MFMA (v_mfma_f32_32x32x2_f32), k summed in ascending order per output.
+ * vqa_gemm_shortk_supported: 1 when the shape qualifies (K <= 512, K % 4 == 0, N % 32 == 0, lda / ldb % 4 == 0, operands
+ * below 4 GB); vqa_gemm_f32 (K <= 304, M >= 1024) and vqa_conv2d_nhwc (Ci 128..256, Co >= 2 Ci) route their calls here themselves (VQA_HOT_SHORTK=0 turns that off).
  * vqa_gemm_shortk_set_grid: tuning override of the workgroup count (0 = two per CU).
  * vqa_gemm_shortk_set_mode: which callers route to it -- bit 0 vqa_gemm_f32, bit 1 the 1x1 convolutions of
  * vqa_conv2d_nhwc (Ci 128..256); -1 = back to VQA_HOT_SHORTK / the default 3. */

@@ -117,13 +117,13 @@ ok(lib.vqa_probe_disable() == 0 and lib.vqa_probe_disable() == 0, "probe disable
 ok(lib.vqa_roctx_enable(0) == 0, "roctx off")
 
 # round-3 entry points: shape predicates and argument validation (everything that returns before a launch)
-for (M, N, K, lda, ldb, ldc, want) in ((7168, 3072, 300, 304, 3072, 3072, 1), (128, 64, 308, 308, 64, 64, 0), (128, 48, 64, 64, 48, 48, 0),
+for (M, N, K, lda, ldb, ldc, want) in ((7168, 3072, 300, 304, 3072, 3072, 1), (128, 64, 308, 308, 64, 64, 1), (128, 64, 516, 516, 64, 64, 0), (128, 48, 64, 64, 48, 48, 0),
                                        (128, 64, 62, 64, 64, 64, 0), (128, 64, 64, 66, 64, 64, 0), (0, 64, 64, 64, 64, 64, 0),
                                        (128, 64, 64, 60, 64, 64, 0), (128, 64, 64, 64, 32, 64, 0), (128, 64, 64, 64, 64, 32, 0),
                                        (1 << 30, 64, 64, 64, 64, 64, 0), (100, 32, 4, 4, 32, 32, 1)):
     ok(lib.vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) == want, "shortk supported %r" % ((M, N, K, lda, ldb, ldc),))
 ok(lib.vqa_gemm_shortk_nn(128, 64, 64, None, 64, None, 64, None, 64, None, None, None, 0, 0, None) == -1, "shortk null operands")
-ok(lib.vqa_gemm_shortk_nn(128, 64, 308, C.c_void_p(4096), 308, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, None, 0, 0,
+ok(lib.vqa_gemm_shortk_nn(128, 64, 516, C.c_void_p(4096), 516, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, None, 0, 0,
                           None) == -4, "shortk K too large")
 ok(lib.vqa_gemm_shortk_nn(128, 64, 64, C.c_void_p(4100), 64, C.c_void_p(4096), 64, C.c_void_p(4096), 64, None, None, None, 0, 0,
                           None) == -2, "shortk misaligned A")

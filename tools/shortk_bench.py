@@ -29,6 +29,7 @@ def tm(f, n=12):
 
 
 shapes = [("xp  (GRU x-projection)", 7168, 3072, 300, 304, False),
+          ("conv5 expand 512->2048", 25088, 2048, 512, 512, True),
           ("conv4 expand 256->1024", 100352, 1024, 256, 256, True),
           ("conv3 expand 128->512", 401408, 512, 128, 128, True),
           ("conv2 expand 64->256", 401408 * 2, 256, 64, 64, True)]

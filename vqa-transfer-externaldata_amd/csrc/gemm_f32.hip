@@ -1334,7 +1334,7 @@ extern "C" int vqa_gemm_f32_ex(int transA, int transB, int M, int N, int K, cons
     }
     // K <= 304, NN: the kernel with A stationary in registers (gemm_shortk.hip) -- the GRU's packed x-projection
     if (!transA && !transB && split_k <= 1 && max_blocks == 0 && g_force_cfg < 0 && (shortk_mode() & 1) &&
-        vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) && !(K > 256 && D != nullptr) && vqa_aligned16(A) &&
+        M >= 1024 && K <= 304 && vqa_gemm_shortk_supported(M, N, K, lda, ldb, ldc) && !(K > 256 && D != nullptr) && vqa_aligned16(A) &&
         vqa_aligned16(B))
         return vqa_gemm_shortk_nn(M, N, K, A, lda, B, ldb, C, ldc, bias, nullptr, D, ldd, 0, stream);
 
@@ -1596,7 +1596,8 @@ extern "C" int vqa_conv2d_nhwc(const float* x, int B, int Hi, int Wi, int Ci, co
     if (plain && (shortk_mode() & 2) && Ci >= 128 && Ci <= 256 && Co >= 2 * Ci && g_conv_cfg_plain < 0 && g_force_cfg < 0 &&
         vqa_gemm_shortk_supported(M, Co, K, Ci, Co, Co) && vqa_aligned16(x) && vqa_aligned16(w) &&
         (residual == nullptr || (int64_t)M * Co * 4 < 0xFFFFFFF0ll))
-        // 1x1 expansions with Ci 128..256 (Co >= 2 Ci: enough column tiles per row panel to pay for loading the panel into
+        // 1x1 expansions with Ci 128..256 (the K = 512 instance ties with the 64x64 tile on the conv5 expansions: 456 against
+        // 442 us, not routed; Co >= 2 Ci: enough column tiles per row panel to pay for loading the panel into
         // registers -- the 256 -> 64 reduction has two and loses, 595 against 481 us): the whole k extent stays in registers
         return vqa_gemm_shortk_nn(M, Co, K, x, Ci, w, Co, y, Co, shift, scale, residual, Co, relu, stream);
     if (plain) {

@@ -1,4 +1,4 @@
-// Short-K GEMM for gfx950 with the LEFT operand stationary in registers:  C[M, N] = A[M, K] B[K, N] (+ epilogue), K <= 304.
+// Short-K GEMM for gfx950 with the LEFT operand stationary in registers:  C[M, N] = A[M, K] B[K, N] (+ epilogue), K <= 512.
 //
 // Who calls it: the packed x-projection of the GRU (x_tm [T*B, 300] times wx_cat [300, 3H]; vlmap/modules.py:124-140 feeds
 // the cell one embedded token per step, the projection of all steps is one GEMM here) and the extractor's 1x1 expansion
@@ -72,7 +72,7 @@ __device__ __forceinline__ int sk_xcd_remap(int lin, int total) {
 }
 
 template <int KC, bool RES, int WV>
-__global__ __launch_bounds__(64 * WV, WV == 4 ? 2 : 1) void shortk_nn_kernel(SkArgs p) {
+__global__ __launch_bounds__(64 * WV, (WV == 4 && KC <= 38) ? 2 : 1) void shortk_nn_kernel(SkArgs p) {
     constexpr int SK_NT = 64 * WV, SK_BM = 32 * WV, RPR = 8 * WV;       // threads, rows of a panel, B rows per DMA round
     constexpr int KP = 8 * KC, TILE = KP * 32;
     constexpr int NSTG = (KP + RPR - 1) / RPR;              // DMA wave-instructions per B tile and wave
@@ -297,6 +297,7 @@ inline int sk_chunks(int K) {   // template instance (k chunks of 8) that holds 
     if (K <= 128) return 16;
     if (K <= 256) return 32;
     if (K <= 304) return 38;
+    if (K <= 512) return 64;       // one workgroup per CU (256 A registers per wave, 128 KB of LDS); four waves only
     return 0;
 }
 
@@ -347,7 +348,7 @@ extern "C" int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, 
     a.n_tiles = N / 32;
     static const int env_waves = [] { const char* e = getenv("VQA_HOT_SHORTK_WAVES"); return e ? atoi(e) : 0; }();   // tuning: 4 / 8
     const int waves = g_sk_waves > 0 ? g_sk_waves : (env_waves == 4 || env_waves == 8 ? env_waves : SK_DEFAULT_WAVES);
-    const int bm = 32 * waves;
+    const int bm = 32 * (K > 304 ? 4 : waves);
     const int64_t units = (int64_t)((M + bm - 1) / bm) * a.n_tiles;
     VQA_REQUIRE(units < (1ll << 30), VQA_ERR_ARG);
     a.units = (int)units;
@@ -367,20 +368,21 @@ extern "C" int vqa_gemm_shortk_nn(int M, int N, int K, const float* A, int lda, 
         }
     }
     static const int env_grid = [] { const char* e = getenv("VQA_HOT_SHORTK_GRID"); return e ? atoi(e) : 0; }();   // tuning
-    int grid = g_sk_grid > 0 ? g_sk_grid : (env_grid > 0 ? env_grid : (waves == 8 ? cus : 2 * cus));
+    int grid = g_sk_grid > 0 ? g_sk_grid : (env_grid > 0 ? env_grid : ((waves == 8 || K > 304) ? cus : 2 * cus));
     if (grid > a.units) grid = a.units;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int kc = sk_chunks(K);
     const bool res = D != nullptr;
 #define SK_GO(KC_)                                                                                            \
     case KC_:                                                                                                 \
-        if (waves == 8) return res ? sk_launch<KC_, true, 8>(a, grid, st) : sk_launch<KC_, false, 8>(a, grid, st); \
+        if (waves == 8 && K <= 304) return res ? sk_launch<KC_, true, 8>(a, grid, st) : sk_launch<KC_, false, 8>(a, grid, st); \
         return res ? sk_launch<KC_, true, 4>(a, grid, st) : sk_launch<KC_, false, 4>(a, grid, st);
     switch (kc) {
         SK_GO(8)
         SK_GO(16)
         SK_GO(32)
         SK_GO(38)
+        case 64: return res ? sk_launch<64, true, 4>(a, grid, st) : sk_launch<64, false, 4>(a, grid, st);
     }
 #undef SK_GO
     return VQA_ERR_UNSUPPORTED;
