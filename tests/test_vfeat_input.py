@@ -99,3 +99,36 @@ def test_ring_buffers_give_the_same_batches_when_consumed_in_order(tmp_path):
         seen.add(got["image"].__array_interface__["data"][0])
         n += 1
     assert n == len(want) == 3 and [len(w["id"]) for w in want] == [4, 4, 3] and len(seen) <= 4
+
+
+def test_decoding_processes_give_the_same_batches_as_the_thread_pool(tmp_path):
+    """processes=N: forked decoders writing into a shared-memory ring -- same batches, same order, byte pixels and float
+    pixels; a failing image surfaces as an error in the consumer instead of a hang."""
+    from PIL import Image
+    rng = np.random.default_rng(6)
+    d = tmp_path / "img" / "VG_100K"
+    d.mkdir(parents=True)
+    paths, boxes = [], {}
+    for i in range(13):
+        Image.fromarray(rng.integers(0, 255, size=(30 + i, 44, 3), dtype=np.uint8)).save(str(d / ("%d.png" % i)))
+        paths.append("VG_100K/%d.png" % i)
+        boxes["VG_100K-%d.png" % i] = rng.uniform(1, 20, size=(2 + i % 5, 4)).astype(np.float32)
+    ds = DV.create_dataset(paths, str(tmp_path / "img"), None, boxes=boxes)
+    for dt in (np.float32, np.uint8):
+        want = [{k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+                for b in IO.create(ds, 4, is_train=False, shuffle=False, num_parallel_calls=2, prefetch=2, reuse_buffers=True,
+                                   image_dtype=dt)]
+        n = 0
+        for got, w in zip(IO.create(ds, 4, is_train=False, shuffle=False, prefetch=2, reuse_buffers=True, image_dtype=dt,
+                                    processes=3), want):
+            for k in ("id", "image", "box", "normal_box", "num_box", "image_id_len"):
+                np.testing.assert_array_equal(got[k], w[k], err_msg=k)
+            assert got["image_id"] == w["image_id"] and got["image"].dtype == dt
+            n += 1
+        assert n == len(want) == 4
+    with pytest.raises(ValueError):
+        IO.create(ds, 4, is_train=False, shuffle=False, reuse_buffers=False, processes=2)
+    bad = DV.create_dataset(paths[:3] + ["VG_100K/missing.png"], str(tmp_path / "img"), None,
+                            boxes=dict(boxes, **{"VG_100K-missing.png": boxes["VG_100K-0.png"]}))
+    with pytest.raises(RuntimeError, match="decoding failed"):
+        list(IO.create(bad, 2, is_train=False, shuffle=False, prefetch=2, reuse_buffers=True, processes=2))

@@ -18,7 +18,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 576
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 workers = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 rng = np.random.default_rng(0)
-model = VF.VfeatResnetModel(VF.init_random_params(rng, VF.BLOCKS_R101_FULL), VF.BLOCKS_R101_FULL)
+model = None if os.environ.get("LOADER_PROCESSES") else VF.VfeatResnetModel(VF.init_random_params(rng, VF.BLOCKS_R101_FULL),
+                                                                            VF.BLOCKS_R101_FULL)
 with tempfile.TemporaryDirectory() as d:
     os.makedirs(os.path.join(d, "VG_100K"))
     paths, boxes = [], {}
@@ -35,6 +36,22 @@ with tempfile.TemporaryDirectory() as d:
     paths = paths * int(os.environ.get("REPEAT", "6"))            # steady state: the files are read several times
     n = len(paths)
     ds = DV.create_dataset(paths, d, None, is_train=False, boxes=boxes)
+    if os.environ.get("LOADER_PROCESSES"):       # forked decoders: every pipeline is created BEFORE the GPU is touched
+        nproc = int(os.environ["LOADER_PROCESSES"])
+        pipes = [("%d decoding processes, shared pinned ring, byte pixels" % nproc,
+                  IO.create(ds, B, is_train=False, shuffle=False, prefetch=3, reuse_buffers=True, pinned=True, image_dtype=np.uint8,
+                            processes=nproc)) for _ in range(2)]
+        model = VF.VfeatResnetModel(VF.init_random_params(rng, VF.BLOCKS_R101_FULL), VF.BLOCKS_R101_FULL)
+        for mode, batches in pipes:
+            ex = VF.Extractor(model, id2idx, ds.get_config().max_roi_num)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = ex.extract(device_batches(batches, "cuda:0"))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print("%-24s %d JPEGs 640x480 -> 540x540 -> resnet_v1_101 b1-4 + 36-box crop: %.2f s = %.0f images/s (batch %d)" % (
+                mode, n, dt, n / dt, B), flush=True)
+        sys.exit(0)
     for mode, kw in (("fresh pageable batches", dict(reuse_buffers=False)),
                      ("ring of pageable blocks", dict(reuse_buffers=True)),
                      ("ring of pinned blocks", dict(reuse_buffers=True, pinned=True)),

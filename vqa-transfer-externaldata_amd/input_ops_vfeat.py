@@ -4,13 +4,103 @@ ids (optionally shuffled) -> dataset.get_data on 8 parallel workers -> padded ba
 A batch is a dict of NumPy arrays: id i32[B], image f32[B,540,540,3], box / normal_box f32[B,maxn,4] zero padded to
 the batch's longest box list (tf.data padded_batch), num_box i32[B], image_id list[str], image_id_len i32[B].
 Decoding + resizing runs in a thread pool (PIL releases the GIL inside its C loops) `prefetch` batches ahead of the
-consumer, so the GPU's conv stack does not wait for JPEG decoding; the last batch may be short."""
+consumer, so the GPU's conv stack does not wait for JPEG decoding; the last batch may be short.
+
+`processes=N` (not in the reference): the same map on N forked worker PROCESSES that write their pixels into a ring of batch
+blocks in shared memory -- no GIL between decoders.  The workers are forked inside create(), so call it BEFORE the process
+touches the GPU (vfeat_extractor.run does when --loader_processes is given); the ring is page-locked afterwards
+(cudaHostRegister) when `pinned` is set."""
 from __future__ import annotations
 
 import collections
+import mmap
+import multiprocessing
+import queue as _queue
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+
+
+def _decode_worker(dataset, ring, tasks, results):
+    """worker process: (seq, slot, j, id) -> pixels into ring[slot][j], the rest of the item back through `results`"""
+    while True:
+        t = tasks.get()
+        if t is None:
+            return
+        seq, slot, j, idx = t
+        try:
+            item = dataset.get_data(idx, ring[slot][j])
+            results.put((seq, j, {k: v for k, v in item.items() if k != "image"}, None))
+        except BaseException as e:      # the parent re-raises
+            results.put((seq, j, None, "%s: %s" % (type(e).__name__, e)))
+
+
+def _create_mp(dataset, chunks, batch_size, shape, image_dtype, prefetch, processes, pinned):
+    n_ring = max(1, prefetch) + 2
+    block = int(np.prod((batch_size,) + shape)) * np.dtype(image_dtype).itemsize
+    shm = mmap.mmap(-1, n_ring * block)                       # anonymous shared mapping: inherited by the forked workers
+    ring = [np.frombuffer(shm, dtype=image_dtype, count=block // np.dtype(image_dtype).itemsize, offset=i * block)
+            .reshape((batch_size,) + shape) for i in range(n_ring)]
+    ctx = multiprocessing.get_context("fork")
+    tasks, results = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_decode_worker, args=(dataset, ring, tasks, results), daemon=True) for _ in range(processes)]
+    for p in procs:
+        p.start()
+
+    def gen():
+        registered = False
+        try:
+            if pinned:      # page-lock the shared ring now that the consumer runs (the GPU runtime is up by then)
+                import ctypes
+                import torch
+                if torch.cuda.is_available():
+                    addr = ctypes.addressof(ctypes.c_char.from_buffer(shm))
+                    registered = int(torch.cuda.cudart().cudaHostRegister(addr, n_ring * block, 0)) == 0
+            pending, done = collections.deque(), {}
+            it, seq, slot = iter(chunks), [0], [0]
+
+            def submit():
+                c = next(it, None)
+                if c is None:
+                    return
+                s_, k = seq[0], slot[0] % n_ring
+                seq[0] += 1
+                slot[0] += 1
+                for j, idx in enumerate(c):
+                    tasks.put((s_, k, j, idx))
+                pending.append((s_, c, k))
+                done[s_] = {}
+            for _ in range(max(1, prefetch)):
+                submit()
+            while pending:
+                s_, c, k = pending[0]
+                while len(done[s_]) < len(c):
+                    try:
+                        rs, j, item, err = results.get(timeout=5.0)
+                    except _queue.Empty:
+                        if not all(p.is_alive() for p in procs):
+                            raise RuntimeError("an image decoding worker process died")
+                        continue
+                    if err is not None:
+                        raise RuntimeError("image decoding failed in a worker: " + err)
+                    done[rs][j] = item
+                pending.popleft()
+                items = [done[s_][j] for j in range(len(c))]
+                del done[s_]
+                submit()
+                yield _collate(c, items, ring[k][:len(c)])
+        finally:
+            for _ in procs:
+                tasks.put(None)
+            for p in procs:
+                p.join(timeout=5.0)
+                if p.is_alive():
+                    p.terminate()
+            if registered:
+                import ctypes
+                import torch
+                torch.cuda.cudart().cudaHostUnregister(ctypes.addressof(ctypes.c_char.from_buffer(shm)))
+    return gen()
 
 
 def _collate(ids, items, images=None):
@@ -30,7 +120,7 @@ def _collate(ids, items, images=None):
 
 
 def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=True, seed=123, num_parallel_calls=8,
-           prefetch=10, repeat=1000, reuse_buffers=False, pinned=False, image_dtype=np.float32):
+           prefetch=10, repeat=1000, reuse_buffers=False, pinned=False, image_dtype=np.float32, processes=0):
     """reuse_buffers (not in the reference): the image blocks of the batches come from a ring of `prefetch + 2`
     preallocated [B,H,W,3] buffers, so a batch's `image` is only valid until the second next batch is requested (its
     slot is refilled then) -- for consumers that upload each batch before asking for the next (the extractor).
@@ -48,6 +138,11 @@ def create(dataset, batch_size, is_train=False, scope="vfeat_input", shuffle=Tru
     ring_keepalive = []
     direct = bool(getattr(dataset, "supports_image_out", False))
     shape = (int(getattr(dataset, "height", 0)), int(getattr(dataset, "width", 0)), 3)
+    if processes and processes > 0:
+        if not (direct and reuse_buffers) or is_train:
+            raise ValueError("processes > 0 needs a dataset that writes into a caller-owned image slot, reuse_buffers=True "
+                             "and one pass over the ids (is_train=False)")
+        return _create_mp(dataset, chunks, batch_size, shape, image_dtype, prefetch, int(processes), pinned)
     ring = []
     if direct and reuse_buffers:
         n_ring = max(1, prefetch) + 2

@@ -66,6 +66,8 @@ def build_parser():
     parser.add_argument("--pretrained_param_path", type=str, default=None, required=True)
     parser.add_argument("--batch_size", type=int, default=96, help=" ")
     parser.add_argument("--model_type", type=str, default="vfeat", help=" ", choices=["vfeat", "resnet"])
+    # not in the reference: JPEG decoding on forked worker processes instead of the thread pool (0 = threads)
+    parser.add_argument("--loader_processes", type=int, default=0, help="image decoding worker processes (0: thread pool)")
     return parser
 
 
@@ -97,12 +99,19 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device=None, rank=None
     if dataset is None:
         dataset = dataset_vfeat.create_dataset(paths[lo:hi] if world > 1 else paths, config.image_dir,
                                                config.densecap_dir, is_train=False)
+    nproc = int(getattr(config, "loader_processes", 0) or 0)
+
+    def make_batches():
+        return input_ops_vfeat.create(dataset, config.batch_size, is_train=False, scope="batch_ops", shuffle=False,
+                                      num_parallel_calls=int(getattr(config, "num_parallel_calls", 8) or 8),
+                                      prefetch=3, reuse_buffers=True,      # each batch is uploaded before the next is drawn
+                                      pinned=True if nproc > 0 else torch.cuda.is_available(), image_dtype=np.uint8,
+                                      processes=nproc)
+    batches = make_batches() if nproc > 0 else None      # decoding processes are forked BEFORE the GPU is initialised
     params = load_params(config.pretrained_param_path, config.model_type, blocks)
     model = get_model_class(config.model_type)(params, blocks, device=device)
-    batches = input_ops_vfeat.create(dataset, config.batch_size, is_train=False, scope="batch_ops", shuffle=False,
-                                     num_parallel_calls=int(getattr(config, "num_parallel_calls", 8) or 8),
-                                     prefetch=3, reuse_buffers=True,       # each batch is uploaded before the next is drawn
-                                     pinned=torch.cuda.is_available(), image_dtype=np.uint8)
+    if batches is None:
+        batches = make_batches()
     ex = vfeat.Extractor(model, image_info["image_id2idx"], dataset.get_config().max_roi_num,
                          config.pretrained_param_path)
     if world == 1:
