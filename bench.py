@@ -564,6 +564,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    if os.environ.get("VQA_BENCH_DRY_RUN"):
+        # rehearsal of the launch path on a box without (enough) GPUs: everything up to the first GPU call -- argument
+        # parsing, the self-spawned torch.distributed.run, rendezvous on 127.0.0.1, rank / shard bookkeeping -- then out
+        from vqa_transfer_externaldata_amd import dp as PAR
+        lo, hi = PAR.shard_bounds(CFG["B"] * world, rank, world)
+        mine = torch.tensor([float(hi - lo), float(rank)])
+        if world > 1:
+            dist.all_reduce(mine)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "backend": backend, "global_batch": int(mine[0]),
+                              "rank_sum": int(mine[1]), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

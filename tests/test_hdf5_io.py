@@ -328,6 +328,53 @@ def test_sharded_extraction_parts_merge_into_the_single_run_table(tmp_path):
         assert f["data_info"]["pretrained_param_path"][()] == "w.ckpt"
 
 
+def test_sharded_extraction_with_more_ranks_than_images_and_partial_files(tmp_path):
+    """world > images: ranks with an empty shard write no part and merge_parts skips them; tables are streamed into
+    `<path>.partial` and only a finished one carries the final name"""
+    import torch
+    from vqa_transfer_externaldata_amd import vfeat as VF, vfeat_extractor as VX
+
+    class FakeModel:
+        def __init__(self, fail_at=None):
+            self.calls, self.fail_at = 0, fail_at
+
+        def build(self, batch):
+            self.calls += 1
+            if self.fail_at is not None and self.calls > self.fail_at:
+                raise RuntimeError("GPU went away")
+            return batch["image"].mean(dim=(1, 2))[:, None, :].repeat(1, batch["normal_box"].shape[1], 2)
+
+    rng = np.random.default_rng(4)
+    N, R, world = 2, 3, 4
+    ids = ["i%d.jpg" % i for i in range(N)]
+    id2idx = {k: i for i, k in enumerate(ids)}
+    img = torch.from_numpy(rng.random((N, 4, 4, 3)).astype(np.float32))
+    nbx = torch.from_numpy(np.sort(rng.random((N, R, 4)).astype(np.float32), -1))
+
+    def batches(lo, hi):
+        for a in range(lo, hi):
+            yield {"image": img[a:a + 1], "normal_box": nbx[a:a + 1], "num_box": [R], "image_id": ids[a:a + 1]}
+
+    single = str(tmp_path / "single.hdf5")
+    VF.Extractor(FakeModel(), id2idx, R).extract(batches(0, N), single)
+    assert os.path.exists(single) and not os.path.exists(single + ".partial")
+    sharded = str(tmp_path / "sharded.hdf5")
+    for r in range(world):
+        lo, hi = VX.shard_of(N, r, world)
+        out = VF.Extractor(FakeModel(), id2idx, R).extract(batches(lo, hi), sharded, part=(r, world), n_part_rows=hi - lo)
+        assert os.path.exists(VF.Extractor.part_path(sharded, r, world)) == (hi > lo)
+        assert len(out["image_idx"]) == hi - lo
+    VF.Extractor.merge_parts(sharded, world, N)
+    a, b = H.load_tree(single), H.load_tree(sharded)
+    for k in ("image_features", "normal_boxes", "spatial_features", "num_boxes"):
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=k)
+    # a run that dies half-way leaves only the .partial file
+    dead = str(tmp_path / "dead.hdf5")
+    with pytest.raises(RuntimeError, match="went away"):
+        VF.Extractor(FakeModel(fail_at=1), id2idx, R).extract(batches(0, N), dead)
+    assert not os.path.exists(dead)
+
+
 def _random_tree(rng, depth=0):
     dts = [np.float32, np.float64, np.int32, np.int64, np.uint8, np.int8, np.int16, np.uint16, np.uint32]
     tree = {}

@@ -199,16 +199,19 @@ def test_trainer_shards_the_global_batch_by_image_and_keeps_the_global_denominat
     batch = PO.make_batch(rng, 7, 5, 6, 8, 4, 20, 9, 11)
     batch["image_idx"] = np.arange(7, dtype=np.int64) * 3
     want = tuple(float(np.clip(batch[k + "_blank_fill/num"], 0, 5).sum()) for k in ("obj", "attr"))
-    seen = []
-    for rank in range(3):
-        me = SimpleNamespace(world=3, rank=rank, config=SimpleNamespace(data_cfg=SimpleNamespace(n_obj_bf=5)))
-        sh = PTT.Trainer._shard(me, batch)
-        assert sh["_dp"]["global_rows"] == 7 and sh["_dp"]["global_valid"] == want
-        lo = sh["_dp"]["row_offset"]
-        n = len(sh["image_idx"])
-        for k, v in batch.items():
-            np.testing.assert_array_equal(sh[k], v[lo:lo + n], err_msg=k)
-        seen.extend(sh["image_idx"].tolist())
-    assert seen == batch["image_idx"].tolist()
+    for world in (3, 7, 8):                  # 8 ranks over 7 images: the last rank's shard is empty and says so
+        seen, sizes = [], []
+        for rank in range(world):
+            me = SimpleNamespace(world=world, rank=rank, config=SimpleNamespace(data_cfg=SimpleNamespace(n_obj_bf=5)))
+            sh = PTT.Trainer._shard(me, batch)
+            assert sh["_dp"]["global_rows"] == 7 and sh["_dp"]["global_valid"] == want
+            lo = sh["_dp"]["row_offset"]
+            n = len(sh["image_idx"])
+            for k, v in batch.items():
+                np.testing.assert_array_equal(sh[k], v[lo:lo + n], err_msg=k)
+            seen.extend(sh["image_idx"].tolist())
+            sizes.append(n)
+        assert seen == batch["image_idx"].tolist() and max(sizes) - min(sizes) <= 1
+        assert sum(sh_valid for sh_valid in sizes) == 7
     one = SimpleNamespace(world=1, rank=0, config=None)
     assert PTT.Trainer._shard(one, batch) is batch

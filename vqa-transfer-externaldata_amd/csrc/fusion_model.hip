@@ -232,20 +232,26 @@ int run_chains(const Ctx& c, int64_t B, Fn fn) {
     while (n > 1 && B < 64 * (int64_t)n) --n;         // at least two row tiles per chain
     if (n <= 1) return fn(0, (int64_t)0, B, c.st);
     if (hipEventRecord(ch.fork, c.st) != hipSuccess) return VQA_ERR_LAUNCH;
-    for (int i = 1; i < n; ++i) {
+    // Whatever fails after the fork, the caller's stream is still ordered behind every side stream that may have work
+    // in flight before the error code goes back: the caller owns the workspace and may free or reuse it on return.
+    int rc = VQA_OK, launched = 0;
+    for (int i = 1; i < n && rc == VQA_OK; ++i) {
         int64_t lo, hi;
         chain_rows(B, n, i, &lo, &hi);
-        if (hipStreamWaitEvent(ch.s[i], ch.fork, 0) != hipSuccess) return VQA_ERR_LAUNCH;
-        if (ch.delay_us > 0.f) TRY(vqa_stream_delay_us(ch.delay_us * (float)i, ch.s[i]));
-        TRY(fn(i, lo, hi - lo, ch.s[i]));
-        if (hipEventRecord(ch.join[i], ch.s[i]) != hipSuccess) return VQA_ERR_LAUNCH;
+        if (hipStreamWaitEvent(ch.s[i], ch.fork, 0) != hipSuccess) { rc = VQA_ERR_LAUNCH; break; }
+        launched = i;
+        if (ch.delay_us > 0.f) rc = vqa_stream_delay_us(ch.delay_us * (float)i, ch.s[i]);
+        if (rc == VQA_OK) rc = fn(i, lo, hi - lo, ch.s[i]);
     }
-    int64_t lo, hi;
-    chain_rows(B, n, 0, &lo, &hi);
-    TRY(fn(0, lo, hi - lo, c.st));
-    for (int i = 1; i < n; ++i)
-        if (hipStreamWaitEvent(c.st, ch.join[i], 0) != hipSuccess) return VQA_ERR_LAUNCH;
-    return VQA_OK;
+    if (rc == VQA_OK) {
+        int64_t lo, hi;
+        chain_rows(B, n, 0, &lo, &hi);
+        rc = fn(0, lo, hi - lo, c.st);
+    }
+    for (int i = 1; i <= launched; ++i)
+        if (hipEventRecord(ch.join[i], ch.s[i]) != hipSuccess || hipStreamWaitEvent(c.st, ch.join[i], 0) != hipSuccess)
+            rc = rc == VQA_OK ? VQA_ERR_LAUNCH : rc;
+    return rc;
 }
 // how V_ft = features[image_idx] is produced: 0 = a gather pass in front of v_linear_v's GEMM (default), 1 = fused
 // into that GEMM's operand load (VQA_FLAG_FUSED_GATHER or VQA_HOT_GATHER=fused).  Measured at bs 512

@@ -31,6 +31,9 @@ def shard_batch(batch, rank, world):
     """Slices every per-sample entry of the reference batch dict
     (vqa/datasets/input_ops_vqa_tf_record_memft.py:47-71) along axis 0."""
     n = len(batch["image_idx"])
+    if n < world:
+        raise ValueError("global batch of %d samples is smaller than the world size %d: a rank without samples cannot "
+                         "run the step" % (n, world))
     lo, hi = shard_bounds(n, rank, world)
     return {k: v[lo:hi] for k, v in batch.items()}, n
 

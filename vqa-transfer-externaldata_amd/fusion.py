@@ -126,6 +126,45 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def flat_layout(model_type, shapes):
+    """Where every variable sits in the flat buffers (pure host arithmetic, no GPU): train_flat / grad_flat order =
+    the order backward completes the gradients (vqa_fusion_backward_phases):
+    [embedding | GRU candidate/* | GRU gates/* | everything else by name] (+ 4 tail floats in grad_flat), every
+    variable padded to a multiple of 4 floats.  `buckets` are the slices of grad_flat FusionEngine.backward hands to a
+    bucketed reducer, in the order it starts them."""
+    sc = scope_names(model_type)
+    names = sorted(shapes)
+    embed = sc["embed"]
+    train = filter_train_vars(names, model_type)
+    gru_first = sorted((n for n in train if n.startswith("encode_L/")), key=lambda n: ("/candidate/" not in n, n))
+    train_names = [embed] + gru_first + [n for n in train if n != embed and not n.startswith("encode_L/")]
+    frozen_names = [n for n in names if n not in train]
+
+    def carve(name_list):
+        off, table = 0, {}
+        for n in name_list:
+            cnt = int(np.prod(shapes[n]))
+            table[n] = (off, cnt)
+            off += _pad4(cnt)
+        return table, off
+
+    train_tab, n_train = carve(train_names)
+    frozen_tab, n_frozen = carve(frozen_names)
+    embed_floats = _pad4(int(np.prod(shapes[embed])))
+    # the GRU tensors must sit right after the table, and inside them [candidate/* | gates/*]: the gate half is reduced
+    # while the candidate half is computed
+    gru = [n for n in train_names if n.startswith("encode_L/")]
+    assert train_names[1:1 + len(gru)] == gru, "flat layout: encode_L/* must follow the embedding"
+    gru_end = embed_floats + sum(_pad4(int(np.prod(shapes[n]))) for n in gru)
+    cand = [n for n in gru if "/candidate/" in n]
+    assert gru[:len(cand)] == cand, "flat layout: candidate/* precede gates/*"
+    gru_mid = embed_floats + sum(_pad4(int(np.prod(shapes[n]))) for n in cand)
+    e, m, g, n = embed_floats, gru_mid, gru_end, n_train
+    return dict(train_names=train_names, frozen_names=frozen_names, train_tab=train_tab, n_train=n_train,
+                frozen_tab=frozen_tab, n_frozen=n_frozen, embed_floats=e, gru_mid=m, gru_end=g,
+                buckets=[(g, n), (0, e), (n, n + 4), (m, g), (e, m)])
+
+
 class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
                      "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6}
@@ -151,35 +190,12 @@ class FusionEngine:
                               flags=(_lib.FLAG_DETERMINISTIC if deterministic else 0) |
                                     (_lib.FLAG_FUSED_GATHER if fused_gather else 0))
         self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
-        names = sorted(self.shapes)
-        embed = self.sc["embed"]
-        train = filter_train_vars(names, model_type)
-        # flat order = the order backward completes the gradients (vqa_fusion_backward_phases):
-        # [embedding | GRU candidate/* | GRU gates/* | everything else by name]
-        gru_first = sorted((n for n in train if n.startswith("encode_L/")), key=lambda n: ("/candidate/" not in n, n))
-        self.train_names = [embed] + gru_first + [n for n in train if n != embed and not n.startswith("encode_L/")]
-        self.frozen_names = [n for n in names if n not in train]
-
-        def carve(name_list):
-            off, table = 0, {}
-            for n in name_list:
-                cnt = int(np.prod(self.shapes[n]))
-                table[n] = (off, cnt)
-                off += _pad4(cnt)
-            return table, off
-
-        self._train_tab, self.n_train = carve(self.train_names)
-        self._frozen_tab, self.n_frozen = carve(self.frozen_names)
-        self.embed_floats = _pad4(int(np.prod(self.shapes[embed])))
-        # gradient buckets in the order backward completes them (see vqa_fusion_backward_phases):
-        # [embed | GRU (encode_L/*) | everything else]; the GRU tensors must sit right after the table
-        gru = [n for n in self.train_names if n.startswith("encode_L/")]
-        assert self.train_names[1:1 + len(gru)] == gru, "flat layout: encode_L/* must follow the embedding"
-        self.gru_end = self.embed_floats + sum(_pad4(int(np.prod(self.shapes[n]))) for n in gru)
-        # ... and inside it [candidate/* | gates/*]: the gate half is reduced while the candidate half is computed
-        cand = [n for n in gru if "/candidate/" in n]
-        assert gru[:len(cand)] == cand, "flat layout: candidate/* precede gates/*"
-        self.gru_mid = self.embed_floats + sum(_pad4(int(np.prod(self.shapes[n]))) for n in cand)
+        lay = flat_layout(model_type, self.shapes)
+        self.train_names, self.frozen_names = lay["train_names"], lay["frozen_names"]
+        self._train_tab, self.n_train = lay["train_tab"], lay["n_train"]
+        self._frozen_tab, self.n_frozen = lay["frozen_tab"], lay["n_frozen"]
+        self.embed_floats, self.gru_mid, self.gru_end = lay["embed_floats"], lay["gru_mid"], lay["gru_end"]
+        self._buckets = lay["buckets"]
         f32 = dict(dtype=torch.float32, device=self.device)
         self.train_flat = torch.zeros(self.n_train, **f32)
         self.frozen_flat = torch.zeros(max(self.n_frozen, 4), **f32)
@@ -374,16 +390,17 @@ class FusionEngine:
         if reducer is None:
             self._backward_phases(15)
             return
-        e, m, g, n = self.embed_floats, self.gru_mid, self.gru_end, self.n_train
+        gf = self.grad_flat
+        rest, emb, tail, gates, cand = (gf[lo:hi] for lo, hi in self._buckets)       # flat_layout: disjoint, cover grad_flat
         self._backward_phases(1)
-        reducer.start(self.grad_flat[g:n])
+        reducer.start(rest)
         self._backward_phases(2)
-        reducer.start(self.grad_flat[:e])
-        reducer.start(self.grad_flat[n:])
+        reducer.start(emb)
+        reducer.start(tail)
         self._backward_phases(4)
-        reducer.start(self.grad_flat[m:g])        # GRU gates (10.8 MB) reduce under the candidate GEMMs
+        reducer.start(gates)                      # GRU gates (10.8 MB) reduce under the candidate GEMMs
         self._backward_phases(8)
-        reducer.start(self.grad_flat[e:m])        # GRU candidate (5.4 MB): the only exposed reduction
+        reducer.start(cand)                       # GRU candidate (5.4 MB): the only exposed reduction
         reducer.finish()
 
     def optimizer_step(self, lr):

@@ -36,6 +36,10 @@ def _decode_worker(dataset, ring, tasks, results):
 
 
 def _create_mp(dataset, chunks, batch_size, shape, image_dtype, prefetch, processes, pinned):
+    import torch
+    if torch.cuda.is_initialized():
+        raise RuntimeError("decoding processes must be forked before this process initialises the GPU runtime "
+                           "(create the input pipeline before the first torch.cuda call)")
     n_ring = max(1, prefetch) + 2
     block = int(np.prod((batch_size,) + shape)) * np.dtype(image_dtype).itemsize
     shm = mmap.mmap(-1, n_ring * block)                       # anonymous shared mapping: inherited by the forked workers

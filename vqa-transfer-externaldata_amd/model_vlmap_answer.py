@@ -228,9 +228,25 @@ class Model(object):
         """extra FusionEngine arguments of a model variant (none for the two base models)"""
         return {}
 
+    _UPLOAD_CHUNK_BYTES = 256 << 20
+
     def _to_dev(self, a, dtype):
-        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(device=self.device, dtype=dtype).contiguous()
+        if torch.is_tensor(a):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        a = np.asarray(a) if not isinstance(a, np.ndarray) else a
+        if a.flags.writeable:
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+        # read-only arrays (the np.memmap views of a feature file, load_image_features): torch must not alias them.
+        # Uploaded in bounded slices -- each slice is copied on read, so a 36 GB table never sits in host RAM twice
+        out = torch.empty(a.shape, dtype=dtype, device=self.device)
+        if a.ndim == 0 or a.size == 0:
+            if a.size:
+                out.copy_(torch.from_numpy(np.array(a)))
+            return out
+        rows = max(1, int(self._UPLOAD_CHUNK_BYTES // max(a.nbytes // a.shape[0], 1)))
+        for lo in range(0, a.shape[0], rows):
+            out[lo:lo + rows].copy_(torch.from_numpy(np.array(a[lo:lo + rows])))
+        return out
 
     def _make_engine(self, B, T):
         Vq = len(self.vocab["vocab"])

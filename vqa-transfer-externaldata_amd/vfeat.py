@@ -356,7 +356,10 @@ class Extractor:
                 tree["image_idx"] = hdf5_io.Empty((rows_total,), np.int32)
                 tree["first_num_box"] = np.array(n, np.int32)
                 path = self.part_path(save_path, *part)
-            mm = hdf5_io.create(path, tree)
+            # streamed into `<path>.partial`, renamed when the last row is on disk: a run that dies half-way never leaves
+            # something a trainer could take for a finished table
+            state["final_path"] = path
+            mm = hdf5_io.create(path + ".partial", tree)
             state["feats"], state["boxes"], state["spat"] = mm["/image_features"], mm["/normal_boxes"], mm["/spatial_features"]
             state["idx_mm"] = mm.get("/image_idx")
 
@@ -402,6 +405,11 @@ class Extractor:
         if stream and feats is not None:
             for m in (feats, boxes, spat):
                 m.flush()
+            os.replace(state["final_path"] + ".partial", state["final_path"])      # the mappings follow the inode
+        if feats is None:
+            if part is None:
+                raise ValueError("no images to extract")
+            return {"image_idx": part_idx, "num_boxes": num_boxes}      # an empty shard (world > images): no part file
         out = {"image_features": feats, "normal_boxes": boxes, "spatial_features": spat, "num_boxes": num_boxes,
                "max_box_num": np.int32(self.max_roi_num), "vfeat_dim": np.int32(feats.shape[2])}
         if part is not None:
@@ -416,14 +424,18 @@ class Extractor:
         the parts (memmap to memmap, one part at a time).  num_boxes follows the reference: every entry = the count of the
         FIRST image of the run (:118-121), i.e. of rank 0's first image."""
         from . import hdf5_io
-        parts = [hdf5_io.File(Extractor.part_path(save_path, r, world)) for r in range(world)]
+        # a rank whose shard is empty (world > images) writes no part
+        present = [r for r in range(world) if os.path.exists(Extractor.part_path(save_path, r, world))]
+        if not present:
+            raise FileNotFoundError("no part files of %s" % save_path)
+        parts = [hdf5_io.File(Extractor.part_path(save_path, r, world)) for r in present]
         first = parts[0]
         _, R, D = first["image_features"].shape
         di = first["data_info"]
         ppp = di["pretrained_param_path"][()]
         ppp = ppp.decode() if isinstance(ppp, bytes) else str(ppp)
         n0 = int(np.asarray(first["first_num_box"].read()))
-        mm = hdf5_io.create(save_path, {
+        mm = hdf5_io.create(save_path + ".partial", {
             "image_features": hdf5_io.Empty((n_images, R, D)), "normal_boxes": hdf5_io.Empty((n_images, R, 4)),
             "spatial_features": hdf5_io.Empty((n_images, R, 6)), "num_boxes": np.zeros([n_images], np.int32) + n0,
             "data_info": {"pretrained_param_path": ppp, "max_box_num": np.array(R, np.int32), "vfeat_dim": np.array(D, np.int32)}})
@@ -438,7 +450,8 @@ class Extractor:
                     dst[idx[lo:lo + 256][sel]] = np.asarray(src[lo:lo + 256])[sel]
         for m in mm.values():
             m.flush()
-        for r, f in enumerate(parts):
+        os.replace(save_path + ".partial", save_path)
+        for r, f in zip(present, parts):
             f.close()
             if remove:
                 os.remove(Extractor.part_path(save_path, r, world))

@@ -85,8 +85,6 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device=None, rank=None
     reference's single table (the one loop of vqa/vfeat_extractor_tf_record_memft.py:77-147, split N ways)."""
     rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-    if device is None:
-        device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     config.image_info_path = os.path.join(config.tf_record_memft_dir, "image_info.json")
     config.save_path = os.path.join(config.tf_record_memft_dir, config.save_name)
     if rank == 0:
@@ -107,7 +105,11 @@ def run(config, dataset=None, blocks=vfeat.BLOCKS_R50_B3, device=None, rank=None
                                       prefetch=3, reuse_buffers=True,      # each batch is uploaded before the next is drawn
                                       pinned=True if nproc > 0 else torch.cuda.is_available(), image_dtype=np.uint8,
                                       processes=nproc)
-    batches = make_batches() if nproc > 0 else None      # decoding processes are forked BEFORE the GPU is initialised
+    # decoding processes are forked BEFORE this process makes its first torch.cuda call (device_count() included: on
+    # ROCm it may bring up the HIP runtime, and a forked child of an initialised runtime inherits its fds without its threads)
+    batches = make_batches() if nproc > 0 else None
+    if device is None:
+        device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     params = load_params(config.pretrained_param_path, config.model_type, blocks)
     model = get_model_class(config.model_type)(params, blocks, device=device)
     if batches is None:
