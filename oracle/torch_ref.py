@@ -79,9 +79,31 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
     valid = torch.arange(R)[None, :] < nb[:, None]
     s = torch.where(valid, s, torch.full_like(s, float("-inf")))
     att = torch.softmax(s, dim=-1)
-    p = torch.bmm(att.unsqueeze(1), V).squeeze(1)
+    extra_loss, extra_mid = 0.0, {}
+    if model_type == "vlmap_answer_adapt":          # vqa/model_vlmap_answer_adapt.py:132-142
+        va = _fc_ln_relu(V, P, sc["v_adapt"])
+        p = (att.unsqueeze(-1) * va).sum(1)
+        extra_mid["v_adapt"] = va
+    else:
+        p = torch.bmm(att.unsqueeze(1), V).squeeze(1)
     pl = _fc_ln_relu(p, P, sc["pooled_linear_l"])
-    ll = _fc_ln_relu(h, P, sc["q_linear_l"])
+    lin_in = h
+    if model_type == "vlmap_answer2":               # vqa/model_vlmap_answer2.py:127-131: FC + LN + tanh
+        pre = torch.addmm(P[sc["q_L_ft2"] + "/fc/biases"], h, P[sc["q_L_ft2"] + "/fc/weights"])
+        lin_in = torch.tanh(F.layer_norm(pre, pre.shape[1:], eps=O.LN_EPS) * P[sc["q_L_ft2"] + "/LayerNorm/gamma"]
+                            + P[sc["q_L_ft2"] + "/LayerNorm/beta"])
+    elif model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        qm = torch.addmm(P[sc["q_L_mean"] + "/fc/biases"], h, P[sc["q_L_mean"] + "/fc/weights"])
+        lin_in = qm
+        extra_mid["q_L_mean"] = qm
+        if model_type == "vlmap_answer_full":       # vqa/model_vlmap_answer_full.py:128-134, 272-276
+            qs = torch.addmm(P[sc["q_L_log_sigma_sq"] + "/fc/biases"], h, P[sc["q_L_log_sigma_sq"] + "/fc/weights"])
+            noise = masks["noise"] if torch.is_tensor(masks["noise"]) else _t(masks["noise"], dtype)
+            lin_in = qm + noise * torch.sqrt(torch.exp(qs))
+            kl = -0.5 * torch.sum(1 + qs - qm.pow(2) - qs.exp(), dim=-1).mean()
+            extra_loss = extra_loss + O.LATENT_LOSS_WEIGHT * kl
+            extra_mid.update(q_L_log_sigma_sq=qs, q_L_mean_noise=lin_in, latent_loss=kl)
+    ll = _fc_ln_relu(lin_in, P, sc["q_linear_l"])
     if model_type in O.NOC_FAMILY:        # vqa/model_vlmap_answer_noc.py:177-204, composed independently
         m_jl = masks["joint_l"] if torch.is_tensor(masks["joint_l"]) else _t(masks["joint_l"], dtype)
         vj = _fc_ln_relu(pl, P, sc["joint_v"]) * m_j / O.KEEP_JOINT
@@ -122,8 +144,22 @@ def forward(P, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_
         loss = (ell * _t(answer_masks["train"], dtype)).sum(-1).mean()
     else:
         loss = ell.sum(-1).mean()
-    mid = {"v_linear_v": v, "condition": h, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
-           "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z, "embed": e}
+    if model_type == "vlmap_answer_ent":            # vqa/model_vlmap_answer_ent.py:191-211, 281-292, with the TF ops' torch twins
+        m_t = masks["tile_joint"] if torch.is_tensor(masks["tile_joint"]) else _t(masks["tile_joint"], dtype)
+        B_, M = m_t.shape[0], m_t.shape[1]
+        tile = pl.detach().repeat(M, 1).reshape(B_, M, -1)                   # tf.tile([M, 1]) then reshape [-1, M, L]
+        tj = _fc_ln_relu(tile * ll.unsqueeze(1), P, sc["joint_fc"]) * m_t / O.KEEP_JOINT
+        tz = F.linear(tj, P[sc["head"] + "/fc/weights"].t(), P[sc["head"] + "/fc/biases"])
+        keep = torch.from_numpy((np.asarray(answer_masks["exist"]) * np.asarray(answer_masks["train"])) > 0.5)
+        prob = torch.softmax(tz[:, :, keep], dim=-1)
+        marg = prob.mean(dim=1)
+        neg_ent = (marg * torch.log(marg + 1e-8)).sum(-1).mean()
+        loss = loss + O.W_ENTROPY * neg_ent
+        extra_mid.update(marginal_prob=marg, entropy=neg_ent)
+    loss = loss + extra_loss
+    mid = {"v_linear_v": v, "condition": lin_in if model_type == "vlmap_answer2" else h, "q_linear_v": qv, "att_score": att,
+           "pooled_V_ft": p, "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z, "embed": e}
+    mid.update(extra_mid)
     return loss, mid
 
 

@@ -49,7 +49,27 @@ OUTPUT_GLOVE = "reasoning/output_glove:const"
 # plain 'classifier' head); standard_testmask (vqa/model_standard_testmask.py) is model_standard with the training
 # loss masked by the train-answer mask (:266-268) and an older, shorter report (:295-304)
 STANDARD_FAMILY = ("standard", "standard_word2vec", "standard_testmask")
-TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask", "vlmap_answer_noc", "vlmap_answer_nocarch")
+# The five older ablations of model_vlmap_answer (constructors without `image_features`, so only
+# vqa/trainer.py:84 builds them).  Each is model_vlmap_answer with ONE change:
+#   vlmap_answer2        vqa/model_vlmap_answer2.py:127-131,164  q_L_ft2 = fc_layer(q_L_ft, LN, tanh) feeds q_linear_l
+#                        (heavy_output['condition'] = q_L_ft2); q_linear_v still reads q_L_ft
+#   vlmap_answer_no_noise  vqa/model_vlmap_answer_no_noise.py:122-125,157  q_L_mean = linear fc_layer(q_L_ft) feeds q_linear_l
+#   vlmap_answer_full    vqa/model_vlmap_answer_full.py:124-134,166,217-223,272-276  VAE reparameterisation:
+#                        q_linear_l reads q_L_mean + noise * sqrt(exp(q_L_log_sigma_sq)), noise = random_normal(seed=123)
+#                        (an explicit input here, like the dropout masks); loss += 0.1 * KL latent loss
+#   vlmap_answer_adapt   vqa/model_vlmap_answer_adapt.py:132-142  v_adapt = fc_layer(V_ft, LN over the [R, H] block, ReLU)
+#                        is what the attention pools (pooled_V_ft is [B, H], pooled_linear_l maps H -> H)
+#   vlmap_answer_ent     vqa/model_vlmap_answer_ent.py:16,191-211,281-292  marginal-entropy regulariser: joint_fc + head
+#                        on NUM_MARGINAL pairings of every question with (stop-gradient) pooled features of the batch
+ABLATION_FAMILY = ("vlmap_answer2", "vlmap_answer_no_noise", "vlmap_answer_full", "vlmap_answer_adapt", "vlmap_answer_ent")
+LATENT_LOSS_WEIGHT = 0.1   # vqa/model_vlmap_answer_full.py:33
+W_ENTROPY = 0.1            # vqa/model_vlmap_answer_ent.py:14
+NUM_MARGINAL = 200         # vqa/model_vlmap_answer_ent.py:16
+TRAIN_MASKED_LOSS = ("vlmap_answer", "standard_word2vec", "standard_testmask", "vlmap_answer_noc",
+                     "vlmap_answer_nocarch") + ABLATION_FAMILY
+# the three oldest of them (_no_noise, _adapt, _full) carry the 9-key report of model_standard_testmask
+# (vqa/model_vlmap_answer_no_noise.py:210-219, _adapt.py:211-220, _full.py:220-232); _full adds its latent terms
+OLD_REPORT_TYPES = ("vlmap_answer_no_noise", "vlmap_answer_adapt", "vlmap_answer_full")
 # vqa/model_vlmap_answer_vqa_all2.py: model_vlmap_answer (fixed transferred fusion MLP + WordWeightAnswer head, :128-196)
 # plus a TRAINABLE second head `TunedWordWeightAnswer` on the same `joint` (:216-220); logits are summed (:226-227), the
 # loss is untuned * train_mask + tuned (:240-241) and the prediction takes the tuned logit on training answers and the
@@ -68,7 +88,7 @@ TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l"
 # directory does not know are replaced by the row minimum of the fixed logits (:192-194); the tuned loss is taken on the
 # SUM, ce(logit + tuned_logit) (:236-237); the training loss masks both terms, sum_a (untuned + tuned) * train_mask
 # (:241-242); pred = argmax(logit + tuned_logit) (:244)
-VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2") + NOC_FAMILY
+VLMAP_FAMILY = ("vlmap_answer", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2") + NOC_FAMILY + ABLATION_FAMILY
 TWO_HEAD_FAMILY = ("vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")
 # report keys of vqa/model_standard_testmask.py:295-304 in terms of the 13 keys of the current models
 TESTMASK_REPORT = {"answer_train_loss": "answer_train_loss", "answer_report_loss": "answer_report_loss",
@@ -129,6 +149,8 @@ def scope_names(model_type: str) -> dict:
         "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc",
         # vlmap_answer_noc / nocarch only
         "joint_v": "joint_v", "joint_l": "joint_l", "headV": "WordWeightAnswerV", "headL": "WordWeightAnswerL",
+        # the ablations (ABLATION_FAMILY): answer2 / no_noise + full / full / adapt
+        "q_L_ft2": "q_L_ft2", "q_L_mean": "q_L_mean", "q_L_log_sigma_sq": "q_L_log_sigma_sq", "v_adapt": "v_adapt",
     }
 
 
@@ -185,8 +207,16 @@ def init_params(rng, model_type="vlmap_answer", Vq=64, W=300, D=2048, H=1024, A=
     p[sc["gru_cand"] + "/bias"] = np.zeros(H, dtype)
     fc(sc["q_linear_v"], H, H, True)
     fc(sc["score"], H, 1, False)
-    fc(sc["pooled_linear_l"], D, H, True)
+    fc(sc["pooled_linear_l"], H if model_type == "vlmap_answer_adapt" else D, H, True)   # adapt pools the H-wide v_adapt
     fc(sc["q_linear_l"], H, H, True)
+    if model_type == "vlmap_answer2":
+        fc(sc["q_L_ft2"], H, H, True)
+    if model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        fc(sc["q_L_mean"], H, H, False)
+    if model_type == "vlmap_answer_full":
+        fc(sc["q_L_log_sigma_sq"], H, H, False)
+    if model_type == "vlmap_answer_adapt":
+        fc(sc["v_adapt"], D, H, True)
     if model_type in NOC_FAMILY:
         fc(sc["joint_v"], H, 2 * H, True)
         fc(sc["joint_l"], H, 2 * H, True)
@@ -259,6 +289,25 @@ def fc_ln_relu_forward(x, params, scope):
                                         params[scope + "/LayerNorm/beta"])
     y = np.maximum(ln, 0)
     return y, (x, pre, xhat, rstd, ln)
+
+
+def fc_ln_tanh_forward(x, params, scope):
+    """modules.fc_layer(use_bias, use_ln, activation_fn=tf.tanh): vqa/model_vlmap_answer2.py:127-130."""
+    pre = fc_forward(x, params[scope + "/fc/weights"], params[scope + "/fc/biases"])
+    ln, xhat, rstd = layer_norm_forward(pre, params[scope + "/LayerNorm/gamma"],
+                                        params[scope + "/LayerNorm/beta"])
+    return np.tanh(ln), (x, pre, xhat, rstd, ln)
+
+
+def old_report(report):
+    """the 9 report scalars of the three oldest ablations (same keys as model_standard_testmask) from the 13-key report"""
+    return {k: report[v] for k, v in TESTMASK_REPORT.items()}
+
+
+def marginal_index(B, M):
+    """vqa/model_vlmap_answer_ent.py:196-198: reshape(tile(pooled_linear_l, [M, 1]), [-1, M, L]) -- row (i, m) of the
+    tiled tensor is flat row i * M + m of the [M * B, L] tile, i.e. pooled_linear_l[(i * M + m) % B]."""
+    return (np.arange(B)[:, None] * M + np.arange(M)[None, :]) % B
 
 
 def gru_forward(x, lens, Wg, bg, Wc, bc):
@@ -405,8 +454,11 @@ def loss_and_report_all2(z1, z2, tgt, answer_masks):
 # ----------------------------------------------------------------------------
 # full forward
 # ----------------------------------------------------------------------------
-def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_answer"):
+def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="vlmap_answer", stop_grad_values=None):
     """Forward of model_vlmap_answer / model_standard.
+
+    stop_grad_values (tests only): {'pooled_linear_l': array} holds the value behind vlmap_answer_ent's tf.stop_gradient
+    fixed while parameters are perturbed, so that finite differences see the gradient TF propagates.
 
     batch: dict image_idx i64[B], q_intseq i32[B,T], q_intseq_len i32[B],
            answer_target f[B,A]  (vqa/datasets/input_ops_vqa_tf_record_memft.py:47-71)
@@ -427,9 +479,29 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
     att, feat = hadamard_attention_forward(                              # a6
         v, nb, qv, params[sc["score"] + "/fc/weights"], params[sc["score"] + "/fc/biases"],
         masks["att"])
-    p = np.einsum("br,brd->bd", att, V)                                  # a7
+    va = t_va = None
+    if model_type == "vlmap_answer_adapt":                               # :132-142: the attention pools v_adapt, not V_ft
+        va, t_va = fc_ln_relu_forward(V, params, sc["v_adapt"])
+        p = np.einsum("br,brd->bd", att, va)
+    else:
+        p = np.einsum("br,brd->bd", att, V)                              # a7
     pl, t_pl = fc_ln_relu_forward(p, params, sc["pooled_linear_l"])      # a8
-    ll, t_ll = fc_ln_relu_forward(h, params, sc["q_linear_l"])
+    # what q_linear_l reads: the GRU state, or one of the ablations' layers on top of it
+    lin_in, t_lin, extra_losses, extra_report = h, None, {}, {}
+    if model_type == "vlmap_answer2":
+        lin_in, t_lin = fc_ln_tanh_forward(h, params, sc["q_L_ft2"])
+    elif model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        qm = fc_forward(h, params[sc["q_L_mean"] + "/fc/weights"], params[sc["q_L_mean"] + "/fc/biases"])
+        lin_in, t_lin = qm, dict(qm=qm)
+        if model_type == "vlmap_answer_full":
+            qs = fc_forward(h, params[sc["q_L_log_sigma_sq"] + "/fc/weights"], params[sc["q_L_log_sigma_sq"] + "/fc/biases"])
+            sigma = np.sqrt(np.exp(qs))
+            lin_in = qm + masks["noise"] * sigma
+            latent = dt(-0.5) * (dt(1) + qs - qm * qm - np.exp(qs)).sum(axis=-1).mean()      # :272-276
+            t_lin = dict(qm=qm, qs=qs, sigma=sigma)
+            extra_losses["latent"] = dt(LATENT_LOSS_WEIGHT) * latent
+            extra_report.update(latent_loss=latent, train_latent_loss=extra_losses["latent"])
+    ll, t_ll = fc_ln_relu_forward(lin_in, params, sc["q_linear_l"])
     if model_type in NOC_FAMILY:
         vj0, t_vj = fc_ln_relu_forward(pl, params, sc["joint_v"])        # :177-181
         lj0, t_lj = fc_ln_relu_forward(ll, params, sc["joint_l"])        # :183-188
@@ -476,25 +548,61 @@ def forward(params, batch, table, nbox_table, answer_masks, masks, model_type="v
             extra_mid["tuned_joint"] = tj0 * masks["tuned_joint"] * dt(1.0 / KEEP_JOINT)
     else:
         loss, report, out, ell = loss_and_report(z, batch["answer_target"], answer_masks, model_type)  # a11
+    t_ent = None
+    if model_type == "vlmap_answer_ent":
+        # Maximum entropy regularisation (vqa/model_vlmap_answer_ent.py:191-211, 281-292): every question is paired with
+        # M pooled visual features of the batch (stop-gradient), pushed through joint_fc (+ its own dropout) and the
+        # head; the softmax over the known training answers is averaged over the M pairings and the NEGATIVE entropy of
+        # that marginal joins the loss with weight 0.1.  layer_norm of the [B, M, 2H] tensor normalises over (M, 2H).
+        Bn = pl.shape[0]
+        M = masks["tile_joint"].shape[1]
+        pl_const = pl if stop_grad_values is None else stop_grad_values["pooled_linear_l"]
+        tp = pl_const[marginal_index(Bn, M)]                                               # [B, M, H], no gradient
+        tin = tp * ll[:, None, :]
+        tj0, t_tj = fc_ln_relu_forward(tin, params, sc["joint_fc"])
+        tj = tj0 * masks["tile_joint"] * dt(1.0 / KEEP_JOINT)
+        tz = fc_forward(tj, params[sc["head"] + "/fc/weights"], params[sc["head"] + "/fc/biases"])
+        sel = (answer_masks["exist"] * answer_masks["train"]) > 0.5                      # train_exist_answer_mask_bool (:63-65)
+        mz = tz[:, :, sel]
+        ez = np.exp(mz - mz.max(axis=-1, keepdims=True))
+        prob = ez / ez.sum(axis=-1, keepdims=True)
+        mprob = prob.mean(axis=1)                                                          # [B, #train-exist answers]
+        neg_ent = (mprob * np.log(mprob + dt(1e-8))).sum(axis=-1).mean()
+        extra_losses["entropy"] = dt(W_ENTROPY) * neg_ent
+        extra_report.update(entropy=neg_ent, weighted_entropy=extra_losses["entropy"])
+        extra_mid["marginal_prob"] = mprob
+        t_ent = dict(tp=tp, tj=tj, t_tj=t_tj, prob=prob, mprob=mprob, sel=sel, M=M)
+    if model_type in OLD_REPORT_TYPES:
+        report = old_report(report)
+    report.update(extra_report)
+    for v_ in extra_losses.values():         # self.loss = sum of self.losses (:250-252)
+        loss = loss + v_
     out["att_score"] = att
     out["logit"] = z
     mid = {"num_V_ft": nb, "q_linear_v": qv, "att_score": att, "pooled_V_ft": p,
            "pooled_linear_l": pl, "l_linear_l": ll, "joint": j, "logit": z,
-           "pred": out["pred"], "v_linear_v": v, "condition": h, "V_ft": V}
+           "pred": out["pred"], "v_linear_v": v, "condition": lin_in if model_type == "vlmap_answer2" else h, "V_ft": V}
+    if va is not None:
+        mid["v_adapt"] = va
+    if model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        mid["q_L_mean"] = t_lin["qm"]
+    if model_type == "vlmap_answer_full":
+        mid["q_L_log_sigma_sq"], mid["q_L_mean_noise"] = t_lin["qs"], lin_in
     mid.update(extra_mid)
     tape = dict(V=V, nb=nb, v=v, t_v=t_v, e=e, h=h, t_gru=t_gru, qv=qv, t_qv=t_qv, att=att,
                 feat=feat, p=p, pl=pl, t_pl=t_pl, ll=ll, t_ll=t_ll, jin=jin, j0=j0, t_j=t_j,
-                j=j, z=z, j2=j2, z1=z1, z2=z2, z1_raw=z1_raw)
+                j=j, z=z, j2=j2, z1=z1, z2=z2, z1_raw=z1_raw, va=va, t_va=t_va, t_lin=t_lin, t_ent=t_ent,
+                model_type=model_type)
     return loss, report, out, mid, tape
 
 
 # ----------------------------------------------------------------------------
 # analytic backward
 # ----------------------------------------------------------------------------
-def _fc_ln_relu_backward(dy, tape, params, scope, grads, need_dx=True):
+def _fc_ln_relu_backward(dy, tape, params, scope, grads, need_dx=True, act="relu"):
     x, pre, xhat, rstd, ln = tape
     gamma = params[scope + "/LayerNorm/gamma"]
-    dln = dy * (ln > 0)
+    dln = dy * (ln > 0) if act == "relu" else dy * (1 - np.tanh(ln) ** 2)
     red = tuple(range(dln.ndim - 1))
     grads[scope + "/LayerNorm/beta"] = dln.sum(axis=red)
     grads[scope + "/LayerNorm/gamma"] = (dln * xhat).sum(axis=red)
@@ -568,17 +676,59 @@ def backward(params, batch, answer_masks, masks, tape, model_type="vlmap_answer"
     djin = _fc_ln_relu_backward(dj0, tape["t_j"], params, sc["joint_fc"], g)
     dpl = djin * tape["ll"]
     dll = djin * tape["pl"]
+    if model_type == "vlmap_answer_ent":
+        # the regulariser's path: marginal -> softmax of every pairing -> head -> dropout -> LN(M x 2H) + ReLU -> joint_fc
+        # -> l_linear_l only (pooled_linear_l is behind tf.stop_gradient, :197)
+        te = tape["t_ent"]
+        prob, mprob, M = te["prob"], te["mprob"], te["M"]
+        eps = dt(1e-8)
+        dmp = dt(W_ENTROPY) / dt(B) * (np.log(mprob + eps) + mprob / (mprob + eps))
+        dprob = np.broadcast_to(dmp[:, None, :] / dt(M), prob.shape)
+        dmz = prob * (dprob - (prob * dprob).sum(axis=-1, keepdims=True))
+        dtz = np.zeros(prob.shape[:2] + (z.shape[1],), z.dtype)
+        dtz[:, :, te["sel"]] = dmz
+        g[sc["head"] + "/fc/weights"] = g[sc["head"] + "/fc/weights"] + te["tj"].reshape(-1, te["tj"].shape[-1]).T @ dtz.reshape(-1, z.shape[1])
+        g[sc["head"] + "/fc/biases"] = g[sc["head"] + "/fc/biases"] + dtz.sum(axis=(0, 1))
+        dtj0 = (dtz @ Wh.T) * masks["tile_joint"] * dt(1.0 / KEEP_JOINT)
+        g2 = {}
+        dtin = _fc_ln_relu_backward(dtj0, te["t_tj"], params, sc["joint_fc"], g2)
+        for k_, v_ in g2.items():                    # joint_fc is one set of variables used at both call sites
+            g[k_] = g[k_] + v_
+        dll = dll + (dtin * te["tp"]).sum(axis=1)
     return _backward_below_joint(params, batch, masks, tape, sc, g, dpl, dll, dt)
 
 
 def _backward_below_joint(params, batch, masks, tape, sc, g, dpl, dll, dt):
     """everything upstream of pooled_linear_l / l_linear_l (shared by all model types)"""
     z = tape["z"]
+    model_type = tape.get("model_type")
+    B = z.shape[0]
     dp = _fc_ln_relu_backward(dpl, tape["t_pl"], params, sc["pooled_linear_l"], g)
-    dh = _fc_ln_relu_backward(dll, tape["t_ll"], params, sc["q_linear_l"], g)
-    # attention pooling: p = sum_r att * V   (V is an input: no dV)
+    dh = _fc_ln_relu_backward(dll, tape["t_ll"], params, sc["q_linear_l"], g)      # gradient wrt what q_linear_l read
+    if model_type == "vlmap_answer2":
+        dh = _fc_ln_relu_backward(dh, tape["t_lin"], params, sc["q_L_ft2"], g, act="tanh")
+    elif model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        tl, h_ = tape["t_lin"], tape["h"]
+        dqm = dh
+        if model_type == "vlmap_answer_full":
+            # x = mean + noise * exp(ls / 2); latent = -0.5 mean_B sum (1 + ls - mean^2 - exp(ls)), weight 0.1
+            lw = dt(LATENT_LOSS_WEIGHT) / dt(B)
+            dqs = dh * masks["noise"] * dt(0.5) * tl["sigma"] + lw * dt(0.5) * (np.exp(tl["qs"]) - dt(1))
+            dqm = dh + lw * tl["qm"]
+            g[sc["q_L_log_sigma_sq"] + "/fc/weights"] = h_.T @ dqs
+            g[sc["q_L_log_sigma_sq"] + "/fc/biases"] = dqs.sum(axis=0)
+        g[sc["q_L_mean"] + "/fc/weights"] = h_.T @ dqm
+        g[sc["q_L_mean"] + "/fc/biases"] = dqm.sum(axis=0)
+        dh = dqm @ params[sc["q_L_mean"] + "/fc/weights"].T
+        if model_type == "vlmap_answer_full":
+            dh = dh + dqs @ params[sc["q_L_log_sigma_sq"] + "/fc/weights"].T
+    # attention pooling: p = sum_r att * V   (V is an input: no dV; adapt pools the trainable v_adapt instead)
     V, att = tape["V"], tape["att"]
-    datt = np.einsum("bd,brd->br", dp, V)
+    if model_type == "vlmap_answer_adapt":
+        datt = np.einsum("bd,brd->br", dp, tape["va"])
+        _fc_ln_relu_backward(att[:, :, None] * dp[:, None, :], tape["t_va"], params, sc["v_adapt"], g, need_dx=False)
+    else:
+        datt = np.einsum("bd,brd->br", dp, V)
     ds = att * (datt - (att * datt).sum(axis=1, keepdims=True))      # softmax backward (masked rows: att=0)
     w = params[sc["score"] + "/fc/weights"]
     g[sc["score"] + "/fc/weights"] = np.einsum("br,brh->h", ds, tape["feat"])[:, None]
@@ -716,9 +866,13 @@ def make_table(rng, N, R, D, dtype=np.float32, full_boxes=True):
     return table, nbox
 
 
-def make_dropout_masks(rng, B, R, H, dtype=np.float32, model_type=None):
+def make_dropout_masks(rng, B, R, H, dtype=np.float32, model_type=None, num_marginal=NUM_MARGINAL):
     m = {"att": (rng.random((B, R, H)) < KEEP_ATT).astype(dtype),
          "joint": (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)}
     if model_type in NOC_FAMILY:          # second dropout site: l_joint (`joint` is v_joint's mask)
         m["joint_l"] = (rng.random((B, 2 * H)) < KEEP_JOINT).astype(dtype)
+    if model_type == "vlmap_answer_full":  # tf.random_normal(seed=123) of the reparameterisation, an explicit input here
+        m["noise"] = rng.standard_normal((B, H)).astype(dtype)
+    if model_type == "vlmap_answer_ent":   # tf.nn.dropout(tile_joint, 0.5): its own mask, [B, M, 2H]
+        m["tile_joint"] = (rng.random((B, num_marginal, 2 * H)) < KEEP_JOINT).astype(dtype)
     return m

@@ -16,12 +16,14 @@ def _case(seed, model_type, B=5, R=6, T=7, N=9, full_boxes=False, dtype=np.float
     table, nbox = O.make_table(rng, N, R, DIMS["D"], dtype, full_boxes=full_boxes)
     batch = O.make_batch(rng, B, T, DIMS["Vq"], DIMS["A"], N, dtype)
     am = O.make_answer_masks(rng, DIMS["A"], 15, dtype, exist_all=False)
-    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], dtype, model_type=model_type)
+    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], dtype, model_type=model_type, num_marginal=7)
     return p, table, nbox, batch, am, masks
 
 
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "standard_word2vec", "standard_testmask",
-                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc", "vlmap_answer_vqa_all"])
+                                        "vlmap_answer_vqa_all2", "vlmap_answer_noc", "vlmap_answer_vqa_all",
+                                        "vlmap_answer2", "vlmap_answer_no_noise", "vlmap_answer_full", "vlmap_answer_adapt",
+                                        "vlmap_answer_ent"])
 def test_forward_and_grads_match_torch_autograd(model_type):
     p, table, nbox, batch, am, masks = _case(11, model_type)
     loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, model_type)
@@ -29,7 +31,8 @@ def test_forward_and_grads_match_torch_autograd(model_type):
     tloss, tmid, tgrads, tdx = TR.loss_and_grads(p, batch, table, nbox, am, masks, model_type)
     assert abs(loss - tloss) <= 1e-10 * max(1, abs(tloss))
     for k in ("v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "pooled_linear_l",
-              "l_linear_l", "joint", "v_joint", "l_joint", "logit"):
+              "l_linear_l", "joint", "v_joint", "l_joint", "logit", "v_adapt", "q_L_mean", "q_L_log_sigma_sq",
+              "q_L_mean_noise", "marginal_prob"):
         if k in mid or k in tmid:
             np.testing.assert_allclose(mid[k], tmid[k], rtol=1e-9, atol=1e-11, err_msg=k)
     for k in p:
@@ -219,3 +222,137 @@ def test_standard_testmask_is_standard_with_the_masked_training_loss():
                                  "test_answer_accuracy", "normal_test_answer_accuracy", "max_exist_answer_accuracy",
                                  "test_max_answer_accuracy", "test_max_exist_answer_accuracy"])
     assert r9["answer_accuracy"] == report["answer_acc"] and r9["test_max_exist_answer_accuracy"] == report["test_max_exist_acc"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the five older ablations of model_vlmap_answer: known answers + finite differences
+# ------------------------------------------------------------------------------------------------------------------
+def _fd(p, name, idx, fwd, eps=1e-6):
+    pp = {k: v.copy() for k, v in p.items()}
+    pp[name][idx] += eps
+    lp = fwd(pp)
+    pp[name][idx] -= 2 * eps
+    return (lp - fwd(pp)) / (2 * eps)
+
+
+def test_answer2_tanh_layer_feeds_q_linear_l_only():
+    """vqa/model_vlmap_answer2.py:127-131,164: q_L_ft2 = tanh(LN(fc(q_L_ft))) is the `condition` and q_linear_l's input;
+    q_linear_v keeps reading the GRU state"""
+    mt = "vlmap_answer2"
+    p, table, nbox, batch, am, masks = _case(51, mt)
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    h = tape["h"]
+    pre = h @ p["q_L_ft2/fc/weights"] + p["q_L_ft2/fc/biases"]
+    ln = (pre - pre.mean(1, keepdims=True)) / np.sqrt(pre.var(1, keepdims=True) + O.LN_EPS)
+    want = np.tanh(ln * p["q_L_ft2/LayerNorm/gamma"] + p["q_L_ft2/LayerNorm/beta"])
+    np.testing.assert_allclose(mid["condition"], want, rtol=1e-12, atol=1e-14)
+    assert np.abs(mid["condition"]).max() <= 1.0
+    base = {k: v for k, v in p.items() if not k.startswith("q_L_ft2/")}
+    mid0 = O.forward(base, batch, table, nbox, am, masks, "vlmap_answer")[3]
+    np.testing.assert_array_equal(mid0["q_linear_v"], mid["q_linear_v"])          # the attention branch is untouched
+    assert np.abs(mid0["l_linear_l"] - mid["l_linear_l"]).max() > 1e-3
+    assert sorted(report) == sorted(O.REPORT_KEYS)
+    names = O.train_var_names(p, mt)
+    assert "q_L_ft2/fc/weights" in names and "q_L_ft2/LayerNorm/gamma" in names and "q_linear_l/fc/weights" not in names
+    grads, _ = O.backward(p, batch, am, masks, tape, mt)
+    fwd = lambda pp: O.forward(pp, batch, table, nbox, am, masks, mt)[0]
+    for name, idx in (("q_L_ft2/fc/weights", (3, 5)), ("q_L_ft2/LayerNorm/beta", (2,)), ("encode_L/rnn/gru_cell/candidate/bias", (4,))):
+        assert abs(_fd(p, name, idx, fwd) - grads[name][idx]) <= 1e-7 + 1e-5 * abs(grads[name][idx]), name
+
+
+def test_no_noise_and_full_known_answers():
+    """vqa/model_vlmap_answer_no_noise.py:122-125,157 and _full.py:124-134,166,217-223,272-276"""
+    p, table, nbox, batch, am, masks = _case(52, "vlmap_answer_full")
+    H = DIMS["H"]
+    # identity q_L_mean: no_noise is model_vlmap_answer with the older 9-key report
+    pn = {k: v for k, v in p.items() if not k.startswith("q_L_log_sigma_sq/")}
+    pn["q_L_mean/fc/weights"], pn["q_L_mean/fc/biases"] = np.eye(H), np.zeros(H)
+    ln_, rn, _, mn, _ = O.forward(pn, batch, table, nbox, am, masks, "vlmap_answer_no_noise")
+    base = {k: v for k, v in pn.items() if not k.startswith("q_L_mean/")}
+    l0, r0, _, m0, _ = O.forward(base, batch, table, nbox, am, masks, "vlmap_answer")
+    np.testing.assert_allclose(mn["logit"], m0["logit"], rtol=1e-12)
+    assert sorted(rn) == sorted(O.TESTMASK_REPORT) and rn["answer_accuracy"] == r0["answer_acc"] and ln_ == pytest.approx(l0, rel=1e-12)
+    # full: zero noise = no_noise's logits; the loss carries 0.1 x the KL term
+    z0 = dict(masks, noise=np.zeros_like(masks["noise"]))
+    lf, rf, _, mf, tf_ = O.forward(p, batch, table, nbox, am, z0, "vlmap_answer_full")
+    pnn = {k: v for k, v in p.items() if not k.startswith("q_L_log_sigma_sq/")}
+    lnn, _, _, mnn, _ = O.forward(pnn, batch, table, nbox, am, masks, "vlmap_answer_no_noise")
+    np.testing.assert_allclose(mf["logit"], mnn["logit"], rtol=1e-12)
+    qm, qs = mf["q_L_mean"], mf["q_L_log_sigma_sq"]
+    kl = -0.5 * np.mean(np.sum(1 + qs - qm ** 2 - np.exp(qs), axis=1))
+    assert rf["latent_loss"] == pytest.approx(kl, rel=1e-12) and rf["train_latent_loss"] == pytest.approx(0.1 * kl, rel=1e-12)
+    assert lf == pytest.approx(lnn + 0.1 * kl, rel=1e-12)
+    assert sorted(rf) == sorted(list(O.TESTMASK_REPORT) + ["latent_loss", "train_latent_loss"])
+    # a standard-normal posterior (mean 0, log sigma^2 0) has zero KL, and then x = noise exactly
+    pz = dict(p)
+    for s_ in ("q_L_mean", "q_L_log_sigma_sq"):
+        pz[s_ + "/fc/weights"], pz[s_ + "/fc/biases"] = np.zeros((H, H)), np.zeros(H)
+    lz, rz, _, mz, _ = O.forward(pz, batch, table, nbox, am, masks, "vlmap_answer_full")
+    assert rz["latent_loss"] == 0.0
+    np.testing.assert_array_equal(mz["q_L_mean_noise"], masks["noise"])
+    # finite differences (with noise): the sigma head and the mean head
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, "vlmap_answer_full")
+    grads, _ = O.backward(p, batch, am, masks, tape, "vlmap_answer_full")
+    fwd = lambda pp: O.forward(pp, batch, table, nbox, am, masks, "vlmap_answer_full")[0]
+    for name, idx in (("q_L_log_sigma_sq/fc/weights", (1, 2)), ("q_L_log_sigma_sq/fc/biases", (7,)), ("q_L_mean/fc/weights", (0, 3)),
+                      ("encode_L/rnn/gru_cell/gates/kernel", (14, 9))):
+        assert abs(_fd(p, name, idx, fwd) - grads[name][idx]) <= 1e-7 + 1e-5 * abs(grads[name][idx]), name
+
+
+def test_adapt_pools_the_adapted_features():
+    """vqa/model_vlmap_answer_adapt.py:132-142: pooled_V_ft = att . v_adapt with v_adapt = relu(LN_[R,H](fc(V_ft)))"""
+    mt = "vlmap_answer_adapt"
+    p, table, nbox, batch, am, masks = _case(53, mt)
+    assert p["pooled_linear_l/fc/weights"].shape == (DIMS["H"], DIMS["H"])
+    nbox[:] = np.maximum(nbox, 1)
+    nbox[batch["image_idx"][0]] = 1                                             # a one-box image: pooled = v_adapt[:, 0]
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    assert mid["pooled_V_ft"].shape == (5, DIMS["H"]) and mid["v_adapt"].shape == (5, 6, DIMS["H"])
+    np.testing.assert_allclose(mid["pooled_V_ft"][0], mid["v_adapt"][0, 0], rtol=1e-12)
+    np.testing.assert_allclose(mid["pooled_V_ft"], np.einsum("br,brh->bh", mid["att_score"], mid["v_adapt"]), rtol=1e-12)
+    pre = mid["V_ft"] @ p["v_adapt/fc/weights"] + p["v_adapt/fc/biases"]
+    mu, var = pre.mean((1, 2), keepdims=True), pre.var((1, 2), keepdims=True)        # LN over the whole [R, H] block
+    want = np.maximum((pre - mu) / np.sqrt(var + O.LN_EPS) * p["v_adapt/LayerNorm/gamma"] + p["v_adapt/LayerNorm/beta"], 0)
+    np.testing.assert_allclose(mid["v_adapt"], want, rtol=1e-11, atol=1e-13)
+    assert sorted(report) == sorted(O.TESTMASK_REPORT)
+    grads, _ = O.backward(p, batch, am, masks, tape, mt)
+    fwd = lambda pp: O.forward(pp, batch, table, nbox, am, masks, mt)[0]
+    for name, idx in (("v_adapt/fc/weights", (5, 2)), ("v_adapt/LayerNorm/gamma", (3,)), ("v_linear_v/fc/weights", (1, 1))):
+        assert abs(_fd(p, name, idx, fwd) - grads[name][idx]) <= 1e-7 + 1e-5 * abs(grads[name][idx]), name
+
+
+def test_ent_marginal_pairing_and_closed_forms():
+    """vqa/model_vlmap_answer_ent.py:191-211, 281-292"""
+    mt = "vlmap_answer_ent"
+    # tf.tile([M, 1]) + reshape [-1, M, L]: pairing (i, m) reads pooled_linear_l[(i * M + m) % B]
+    idx = O.marginal_index(5, 7)
+    tile = np.tile(np.arange(5)[:, None], (7, 1)).reshape(-1, 7)
+    np.testing.assert_array_equal(idx, tile)
+    assert idx[0, :6].tolist() == [0, 1, 2, 3, 4, 0] and idx[3, 0] == (3 * 7) % 5
+    p, table, nbox, batch, am, masks = _case(54, mt)
+    loss, report, out, mid, tape = O.forward(p, batch, table, nbox, am, masks, mt)
+    n_sel = int(((am["exist"] * am["train"]) > 0.5).sum())
+    assert mid["marginal_prob"].shape == (5, n_sel) and 0 < n_sel < 15
+    np.testing.assert_allclose(mid["marginal_prob"].sum(1), 1.0, rtol=1e-12)
+    ne = np.mean(np.sum(mid["marginal_prob"] * np.log(mid["marginal_prob"] + 1e-8), axis=1))
+    assert report["entropy"] == pytest.approx(ne, rel=1e-12) and report["weighted_entropy"] == pytest.approx(0.1 * ne, rel=1e-12)
+    base, rb, _, mb, _ = O.forward(p, batch, table, nbox, am, masks, "vlmap_answer")
+    np.testing.assert_array_equal(mb["logit"], mid["logit"])                     # the regulariser does not touch the answer path
+    assert loss == pytest.approx(base + 0.1 * ne, rel=1e-12)
+    assert sorted(report) == sorted(O.REPORT_KEYS + ["entropy", "weighted_entropy"])
+    # an untrained head (weights 0, bias -100): every pairing is uniform over the known training answers
+    pu = dict(p, **{"WordWeightAnswer/fc/weights": np.zeros_like(p["WordWeightAnswer/fc/weights"]),
+                    "WordWeightAnswer/fc/biases": np.full_like(p["WordWeightAnswer/fc/biases"], -100.0)})
+    ru = O.forward(pu, batch, table, nbox, am, masks, mt)[1]
+    assert ru["entropy"] == pytest.approx(np.log(1.0 / n_sel + 1e-8), rel=1e-12)
+    # gradient: only through l_linear_l (pooled_linear_l is behind stop_gradient); finite differences on train vars
+    grads, _ = O.backward(p, batch, am, masks, tape, mt)
+    g0, _ = O.backward(p, batch, am, masks, O.forward(p, batch, table, nbox, am, masks, "vlmap_answer")[4], "vlmap_answer")
+    np.testing.assert_array_equal(grads["v_linear_v/fc/weights"], g0["v_linear_v/fc/weights"])     # nothing reaches the visual side
+    assert np.abs(grads["encode_L/rnn/gru_cell/gates/kernel"] - g0["encode_L/rnn/gru_cell/gates/kernel"]).max() > 0
+    # tf.stop_gradient: the value of pooled_linear_l inside the regulariser is a constant of the differentiation
+    fwd = lambda pp: O.forward(pp, batch, table, nbox, am, masks, mt, stop_grad_values={"pooled_linear_l": mid["pooled_linear_l"]})[0]
+    for name, idx_ in (("encode_L/rnn/gru_cell/candidate/kernel", (13, 4)), ("encode_L/rnn/gru_cell/gates/bias", (6,)),
+                       ("q_linear_l/fc/biases", (2,)), ("joint_fc/LayerNorm/gamma", (9,)), ("WordWeightAnswer/fc/weights", (4, 3))):
+        # (many more ReLU gates than the base model: a smaller step keeps the stencil on one side of every kink)
+        assert abs(_fd(p, name, idx_, fwd, eps=1e-7) - grads[name][idx_]) <= 2e-7 + 1e-4 * abs(grads[name][idx_]), name
