@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VQA_HOT_ABI_VERSION 4
+#define VQA_HOT_ABI_VERSION 5
 
 enum {
     VQA_OK = 0,
@@ -331,7 +331,7 @@ int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, fl
 typedef struct {
     int32_t B, R, D, H, T, W, A, Vq;
     int64_t N_img;
-    int32_t model_type;      /* 0 = vlmap_answer, 1 = standard, 2 = standard_word2vec, 3 = standard_testmask (= 1 with
+    int32_t model_type;      /* 7..11: see VQA_MODEL_* below.  0 = vlmap_answer, 1 = standard, 2 = standard_word2vec, 3 = standard_testmask (= 1 with
                               * the training loss masked by the train-answer mask, vqa/model_standard_testmask.py:266-268),
                               * 4 = vlmap_answer_vqa_all2 (= 0 + the trainable TunedWordWeightAnswer head, summed logits,
                               * two-term loss, mixed-mask argmax: vqa/model_vlmap_answer_vqa_all2.py:196-244),
@@ -343,7 +343,34 @@ typedef struct {
     float keep_joint;        /* 0.5  vqa/model_vlmap_answer.py:180 */
     float inv_global_batch;  /* 1/B for one GPU, 1/(sum of shard sizes) under data parallel */
     int32_t flags;           /* VQA_FLAG_* bit mask, per call (no process-wide state) */
+    /* ABI 5: the five older ablations of model_vlmap_answer (model_type 7..11, see VQA_MODEL_* below) */
+    int32_t num_marginal;    /* 11 only: pairings per question, NUM_MARGINAL = 200 (vqa/model_vlmap_answer_ent.py:16) */
+    int32_t ent_cols;        /* 11 only: number of leading head columns the regulariser needs = 1 + the last answer index
+                              * with train_mask * exist_mask > 0.5 (the train mask is a prefix, :44-46), rounded up by the
+                              * caller as it likes (<= A); columns the masks exclude are ignored */
+    float extra_weight;      /* 10: latent_loss_weight 0.1 (vqa/model_vlmap_answer_full.py:33); 11: W_ENTROPY 0.1 (:14) */
 } vqa_dims_t;
+/* model_type 7..11 = model_vlmap_answer (0) with ONE change each:
+ *   7  vlmap_answer2          q_L_ft2 = fc_layer(q_L_ft, LN, tanh) feeds q_linear_l and is heavy_output['condition']
+ *                             (vqa/model_vlmap_answer2.py:127-131,164)
+ *   8  vlmap_answer_no_noise  q_L_mean = linear fc_layer(q_L_ft) feeds q_linear_l (vqa/model_vlmap_answer_no_noise.py:122-125,157)
+ *   9  vlmap_answer_adapt     v_adapt = fc_layer(V_ft, LN over [R,H], ReLU) is what the attention pools: pooled_V_ft is
+ *                             [B,H], pooled_linear_l maps H -> H (vqa/model_vlmap_answer_adapt.py:132-142)
+ *  10  vlmap_answer_full      q_linear_l reads q_L_mean + noise * sqrt(exp(q_L_log_sigma_sq)) with `noise` an explicit
+ *                             input (tf.random_normal(seed=123) in the reference); loss += extra_weight * KL
+ *                             (vqa/model_vlmap_answer_full.py:124-134,166,217-223,272-276)
+ *  11  vlmap_answer_ent       marginal-entropy regulariser: joint_fc (+ own dropout) + head on num_marginal pairings of every
+ *                             question with stop-gradient pooled_linear_l rows of the batch, softmax over the known training
+ *                             answers, mean over the pairings, loss += extra_weight * mean_b sum_a p log(p + 1e-8)
+ *                             (vqa/model_vlmap_answer_ent.py:191-211, 281-292)
+ * Types 10 and 11 report three more scalars behind the 13 of vqa_report_key: report[13] = latent_loss | entropy,
+ * report[14] = extra_weight * report[13], report[15] = the model's total loss (report[0] + report[14]); stats[b,15]
+ * carries the per-sample term for data-parallel reporting. */
+#define VQA_MODEL_ANSWER2 7
+#define VQA_MODEL_NO_NOISE 8
+#define VQA_MODEL_ADAPT 9
+#define VQA_MODEL_FULL 10
+#define VQA_MODEL_ENT 11
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
 #define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
                                      * (vqa_gemm_f32_gather) and leaves V_ft behind as a by-product; default: a gather
@@ -371,6 +398,11 @@ typedef struct {
                                          * WordWeightAnswerL [2H,A] (`head` is then WordWeightAnswerV); NULL otherwise */
     vqa_fc_t joint2;                    /* vlmap_answer_noc only: joint_l [H,2H] on l_linear_l (`joint_fc` is then joint_v on
                                          * pooled_linear_l; vqa/model_vlmap_answer_noc.py:177-188); NULL otherwise */
+    /* ABI 5 (model_type 7..11; NULL otherwise) */
+    vqa_fc_t q_L_ft2;                   /* 7: [H,H] + LayerNorm */
+    vqa_fc_t q_L_mean;                  /* 8, 10: [H,H], no LayerNorm */
+    vqa_fc_t q_L_log_sigma_sq;          /* 10: [H,H], no LayerNorm */
+    vqa_fc_t v_adapt;                   /* 9: [D,H] + LayerNorm over the [R,H] block (pooled_linear_l is then [H,H]) */
 } vqa_params_t;
 
 typedef struct {
@@ -387,6 +419,9 @@ typedef struct {
     const int32_t* live_rows;           /* HOST int[T] or NULL.  Non-NULL promises that the batch rows are sorted by
                                          * q_intseq_len, longest first, and live_rows[t] = #rows with len > t; the
                                          * recurrence then skips finished sequences (vqa_gru_seq_*_live). */
+    /* ABI 5 */
+    const float* noise;                 /* model_type 10: [B,H] standard-normal draws of the reparameterisation */
+    const uint8_t* keep_tile;           /* model_type 11: keep-mask of tf.nn.dropout(tile_joint, 0.5) [B,num_marginal,2H] or NULL */
 } vqa_batch_t;
 
 int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims);
@@ -595,6 +630,39 @@ int vqa_clock_sample(float us_per_sample, int n_samples, int n_workgroups, float
  * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
  * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */
 int vqa_stream_delay_us(float us, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Kernels of the five older model_vlmap_answer ablations (csrc/ablation_ops.hip); the whole-model entry points
+ * compose them for model_type 7..11.
+ * ------------------------------------------------------------------------ */
+/* vqa/model_vlmap_answer_full.py:128-134, 272-276: x = mean + noise * sqrt(exp(log_sigma_sq)) [B,H];
+ * kl_row[b] = -0.5 * sum_h (1 + log_sigma_sq - mean^2 - exp(log_sigma_sq)) (latent_loss = mean_b kl_row). */
+int vqa_reparam_fwd(const float* mean, const float* log_sigma_sq, const float* noise, float* x, float* kl_row, int B, int H,
+                    void* stream);
+/* its backward plus the KL term's own gradient, coef = latent weight / global batch:
+ * dmean = dx + coef * mean; dlog_sigma_sq = dx * noise * sqrt(exp(ls)) / 2 + coef * (exp(ls) - 1) / 2. */
+int vqa_reparam_bwd(const float* dx, const float* mean, const float* log_sigma_sq, const float* noise, float coef,
+                    float* dmean, float* dlog_sigma_sq, int64_t n, void* stream);
+/* out[b,r,:] = att[b,r] * dp[b,:]: gradient of attention_pooling (vlmap/modules.py:23-39) wrt the pooled memory, needed
+ * when the memory is the trainable v_adapt (vqa/model_vlmap_answer_adapt.py:142) instead of the input V_ft. */
+int vqa_outer_rows(const float* att, const float* dp, float* out, int B, int R, int H, void* stream);
+/* vqa/model_vlmap_answer_ent.py:196-199: x[(b,m),:] = pl[(b*M+m) % B,:] * ll[b,:] -- the tf.tile([M,1]) + reshape pairing
+ * times the broadcast l_linear_l, without materialising the tile; and the gradient wrt ll (pl is behind
+ * tf.stop_gradient): dll[b,:] (+)= sum_m dx[(b,m),:] * pl[(b*M+m) % B,:]. */
+int vqa_tile_mul_fwd(const float* pl, const float* ll, float* x, int B, int M, int H, void* stream);
+int vqa_tile_mul_bwd(const float* dx, const float* pl, float* dll, int B, int M, int H, int accumulate, void* stream);
+/* :205-211, 281-284 on the pairings' logits tz [B*M, ldz], IN PLACE: softmax over the answers a < cols with
+ * train_mask[a] * exist_mask[a] > 0.5, marginal[b,a] = mean over the M pairings [B,cols] (0 for excluded answers),
+ * ent_row[b] = sum_a marginal * log(marginal + 1e-8).  want_dz != 0: tz <- d loss / d logit with
+ * coef = W_ENTROPY / global batch; otherwise tz <- the pairings' probabilities.  cols <= 4096. */
+int vqa_marginal_entropy(float* tz, const float* train_mask, const float* exist_mask, float coef, float* marginal,
+                         float* ent_row, int B, int M, int cols, int ldz, int want_dz, void* stream);
+/* explicit, reproducible stand-in for tf.random_normal(seed=123) (vqa/model_vlmap_answer_full.py:133): out[i] is a
+ * standard-normal draw that depends only on (seed, offset + i) */
+int vqa_normal_noise(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* report[13] = mean_b extra_row[b], report[14] = weight * report[13], report[15] = report[0] + report[14] (run it after
+ * vqa_report_reduce); stats[b,15] = extra_row[b]. */
+int vqa_extra_report(const float* extra_row, float* stats, int B, float weight, float* report, void* stream);
 
 /* The same in dependency-ordered phases (bit mask): 1 = head..attention..v_linear_v / q_linear_v /
  * score gradients, 2 = GRU BPTT + embedding gradient + slice sum of squares, 4 = GRU gate weight / bias

@@ -10,7 +10,7 @@ def dev(a):
 
 
 def make_case(seed, model_type, B, R, T, N, dims, dtype=np.float32, full_boxes=False, num_train=None,
-              head="random", ragged=True):
+              head="random", ragged=True, num_marginal=O.NUM_MARGINAL):
     rng = np.random.default_rng(seed)
     p = O.init_params(rng, model_type, dtype=dtype, head=head, **dims)
     if head == "random":
@@ -18,8 +18,19 @@ def make_case(seed, model_type, B, R, T, N, dims, dtype=np.float32, full_boxes=F
     table, nbox = O.make_table(rng, N, R, dims["D"], dtype, full_boxes=full_boxes)
     batch = O.make_batch(rng, B, T, dims["Vq"], dims["A"], N, dtype, ragged=ragged)
     am = O.make_answer_masks(rng, dims["A"], num_train or int(dims["A"] * 0.75), dtype, exist_all=False)
-    masks = O.make_dropout_masks(rng, B, R, dims["H"], dtype, model_type=model_type)
+    masks = O.make_dropout_masks(rng, B, R, dims["H"], dtype, model_type=model_type, num_marginal=num_marginal)
     return p, table, nbox, batch, am, masks
+
+
+def variant_inputs(masks):
+    """the explicit extra inputs of two ablations as FusionEngine.forward keywords: vlmap_answer_full's noise [B, H],
+    vlmap_answer_ent's pairing dropout keep-mask [B, M, 2H]"""
+    kw = {}
+    if "noise" in masks:
+        kw["noise"] = dev(masks["noise"].astype(np.float32))
+    if "tile_joint" in masks:
+        kw["keep_tile"] = dev(masks["tile_joint"].astype(np.uint8))
+    return kw
 
 
 def make_engine(model_type, p, table, nbox, am, B, R, T, dims, global_batch=None, **kw):

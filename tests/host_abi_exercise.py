@@ -34,20 +34,27 @@ ok([lib.vqa_pretrain_report_key(i) is not None for i in range(-1, 15)] == [False
 off, n = C.c_int64(), C.c_int64()
 names = [b"V_ft", b"num_V_ft", b"v_linear_v", b"condition", b"q_linear_v", b"att_score", b"pooled_V_ft", b"pooled_linear_l",
          b"l_linear_l", b"joint", b"logit", b"pred", b"stats", b"report", b"dlogit", b"dx_embed", b"hs", b"xp", b"x_tm"]
-for mt in range(7):
+VARIANT_TENSORS = {4: [b"logit_fixed", b"logit_tuned", b"dlogit_tuned"], 6: [b"logit_fixed", b"logit_tuned", b"dlogit_tuned", b"logit_raw", b"rowmin"],
+                   5: [b"l_joint", b"pre_jl"], 7: [b"q_L_ft2", b"pre_ft2", b"d_ft2"], 8: [b"q_L_mean", b"d_qm"], 9: [b"v_adapt", b"pre_va", b"d_va"],
+                   10: [b"q_L_mean", b"q_L_log_sigma_sq", b"q_L_mean_noise", b"extra_row"],
+                   11: [b"tile_in", b"pre_tj", b"tile_joint", b"tile_z", b"marginal_prob", b"extra_row", b"d_tile_in"]}
+for mt in range(12):
     for (B, R, D, H, T, W, A, Vq, N) in ((1, 1, 4, 4, 1, 1, 1, 1, 1), (5, 6, 24, 16, 7, 12, 21, 30, 9),
                                          (7, 36, 64, 32, 3, 300, 50, 60, 16), (512, 36, 2048, 1024, 14, 300, 3000, 16384, 8192)):
         d = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N, model_type=mt, keep_att=0.8, keep_joint=0.5,
-                      inv_global_batch=1.0 / B)
+                      inv_global_batch=1.0 / B, num_marginal=200 if mt == 11 else 0, ent_cols=min(A, 2272) if mt == 11 else 0,
+                      extra_weight=0.1)
         total = lib.vqa_fusion_workspace_bytes(C.byref(d))
         ok(total > 0, "workspace bytes %r" % ((mt, B),))
-        for nm in names + ([b"logit_fixed", b"logit_tuned", b"dlogit_tuned"] if mt in (4, 6) else []) + ([b"logit_raw", b"rowmin"] if mt == 6 else []) + ([b"l_joint", b"pre_jl"] if mt == 5 else []):
+        for nm in names + VARIANT_TENSORS.get(mt, []):
             ok(lib.vqa_fusion_tensor(C.byref(d), nm, C.byref(off), C.byref(n)) == 0, "tensor %s" % nm)
             ok(off.value % 16 == 0 and 0 <= off.value and off.value + 4 * n.value <= total, "tensor %s inside the workspace" % nm)
         ok(lib.vqa_fusion_tensor(C.byref(d), b"logit_tuned", C.byref(off), C.byref(n)) == (0 if mt in (4, 6) else -1), "variant tensor")
         ok(lib.vqa_fusion_tensor(C.byref(d), b"", C.byref(off), C.byref(n)) == -1, "empty name")
         ok(lib.vqa_fusion_tensor(C.byref(d), b"x" * 300, None, None) == -1, "long unknown name")
-for bad in (dict(B=0), dict(R=0), dict(model_type=7), dict(model_type=-1), dict(H=-4), dict(N_img=0)):
+for bad in (dict(B=0), dict(R=0), dict(model_type=12), dict(model_type=-1), dict(H=-4), dict(N_img=0),
+            dict(model_type=11), dict(model_type=11, num_marginal=3), dict(model_type=11, num_marginal=3, ent_cols=5),
+            dict(model_type=11, num_marginal=1 << 28, ent_cols=4), dict(model_type=11, num_marginal=2, ent_cols=4097, A=5000)):
     kw = dict(B=4, R=4, D=8, H=8, T=2, W=4, A=4, Vq=4, N_img=4, model_type=0)
     kw.update(bad)
     ok(lib.vqa_fusion_workspace_bytes(C.byref(_lib.Dims(**kw))) < 0, "bad dims %r" % (bad,))

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(built, repo_root):
 
 def test_version_error_strings_and_report_keys(built):
     lib = built.load()
-    assert lib.vqa_hot_version() == built.ABI_VERSION == 4
+    assert lib.vqa_hot_version() == built.ABI_VERSION == 5
     assert lib.vqa_hot_error_string(0) == b"ok"
     assert b"workspace" in lib.vqa_hot_error_string(-5)
     from oracle import vqa_oracle as O

@@ -58,13 +58,22 @@ def test_log_message_format():
 
 
 def test_importer_registry():
-    assert importer.get_model_types() == ["standard", "standard_testmask", "standard_word2vec", "vlmap_answer",
-                                          "vlmap_answer_noc", "vlmap_answer_nocarch", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2"]
+    native = importer.get_model_types()
+    assert native == ["standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc",
+                      "vlmap_answer_nocarch", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2",
+                      "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise"]
     assert importer.get_model_class("vlmap_answer_") is importer.get_model_class("vlmap_answer_vqa_all")      # vqa/importer.py:33
     assert importer.get_model_class("vlmap_answer_nocarch").__mro__[1] is importer.get_model_class("vlmap_answer_noc")
-    assert importer.get_model_class("vlmap_answer_vqa_all2").MODEL_TYPE == "vlmap_answer_vqa_all2"
-    with pytest.raises(ValueError, match="out of scope"):
-        importer.get_model_class("vlmap_answer_full")
+    for t in native:
+        assert importer.get_model_class(t).MODEL_TYPE == t
+    # every entry of the reference registry (vqa/importer.py:1-14) is either native or refused by name
+    reference = ["vqa", "standard", "standard_testmask", "standard_word2vec", "vlmap_only", "vlmap_finetune", "vlmap_answer",
+                 "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_noc", "vlmap_answer_nocarch",
+                 "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise"]
+    assert set(native) <= set(reference)
+    for t in sorted(set(reference) - set(native)):
+        with pytest.raises(ValueError, match="out of scope"):
+            importer.get_model_class(t)
     with pytest.raises(ValueError, match="Unknown model_type"):
         importer.get_model_class("nope")
 

@@ -21,7 +21,8 @@ class Dims(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("T", C.c_int32),
                 ("W", C.c_int32), ("A", C.c_int32), ("Vq", C.c_int32), ("N_img", C.c_int64),
                 ("model_type", C.c_int32), ("keep_att", C.c_float), ("keep_joint", C.c_float),
-                ("inv_global_batch", C.c_float), ("flags", C.c_int32)]
+                ("inv_global_batch", C.c_float), ("flags", C.c_int32),
+                ("num_marginal", C.c_int32), ("ent_cols", C.c_int32), ("extra_weight", C.c_float)]
 
 
 FLAG_DETERMINISTIC = 1
@@ -37,7 +38,8 @@ class Params(C.Structure):
     _fields_ = [("embed", C.c_void_p), ("v_linear_v", Fc),
                 ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
                 ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
-                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc), ("joint2", Fc)]
+                ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc), ("joint2", Fc),
+                ("q_L_ft2", Fc), ("q_L_mean", Fc), ("q_L_log_sigma_sq", Fc), ("v_adapt", Fc)]
 
 
 class Batch(C.Structure):
@@ -45,7 +47,7 @@ class Batch(C.Structure):
                 ("q_intseq", C.c_void_p), ("q_intseq_len", C.c_void_p), ("answer_target", C.c_void_p),
                 ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
                 ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p),
-                ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p)]
+                ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p), ("noise", C.c_void_p), ("keep_tile", C.c_void_p)]
 
 
 class PtDims(C.Structure):
@@ -161,6 +163,14 @@ SIGNATURES = {
     "vqa_probe_labels": (_I, [C.c_char_p, _I]),
     "vqa_roctx_enable": (_I, [_I]),
     "vqa_stream_delay_us": (_I, [_F, _P]),
+    "vqa_reparam_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "vqa_reparam_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _L, _P]),
+    "vqa_outer_rows": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vqa_tile_mul_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vqa_tile_mul_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_marginal_entropy": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vqa_extra_report": (_I, [_P, _P, _I, _F, _P, _P]),
+    "vqa_normal_noise": (_I, [_P, _L, C.c_uint64, C.c_uint64, _P]),
     "vqa_conv2d_bwd_workspace_floats": (_L, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "vqa_conv2d_nhwc_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
     "vqa_clock_sample": (_I, [_F, _I, _I, _P, _P]),
@@ -192,7 +202,7 @@ SIGNATURES = {
                                  _P, _P]),
 }
 
-ABI_VERSION = 4      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
+ABI_VERSION = 5      # VQA_HOT_ABI_VERSION of include/vqa_hot.h
 
 _lib = None
 

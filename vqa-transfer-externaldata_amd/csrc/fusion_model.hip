@@ -72,6 +72,27 @@ Layout make_layout(const vqa_dims_t& d) {
         L.add("logit_fixed", B * A); L.add("logit_tuned", B * A); L.add("dlogit_tuned", B * A);
     }
     if (d.model_type == 6) { L.add("logit_raw", B * A); L.add("rowmin", B); }      // before the row-minimum substitution
+    // the five older ablations (vqa_hot.h: VQA_MODEL_*)
+    if (d.model_type == VQA_MODEL_ANSWER2) {
+        L.add("pre_ft2", B * H); L.add("q_L_ft2", B * H); L.add("mean_ft2", B); L.add("rstd_ft2", B);
+        L.add("d_ft2", B * H); L.add("d_pre_ft2", B * H);
+    }
+    if (d.model_type == VQA_MODEL_NO_NOISE || d.model_type == VQA_MODEL_FULL) { L.add("q_L_mean", B * H); L.add("d_qm", B * H); }
+    if (d.model_type == VQA_MODEL_FULL) {
+        L.add("q_L_log_sigma_sq", B * H); L.add("q_L_mean_noise", B * H); L.add("d_qs", B * H); L.add("d_lin", B * H);
+    }
+    if (d.model_type == VQA_MODEL_FULL || d.model_type == VQA_MODEL_ENT) L.add("extra_row", B);
+    if (d.model_type == VQA_MODEL_ADAPT) {
+        L.add("pre_va", B * R * H); L.add("v_adapt", B * R * H); L.add("mean_va", B); L.add("rstd_va", B);
+        L.add("d_va", B * R * H); L.add("d_pre_va", B * R * H);
+    }
+    if (d.model_type == VQA_MODEL_ENT) {
+        const int64_t M = d.num_marginal, C = d.ent_cols;
+        L.add("tile_in", B * M * H); L.add("pre_tj", B * M * 2 * H); L.add("tile_joint", B * M * 2 * H);
+        L.add("mean_tj", B); L.add("rstd_tj", B);
+        L.add("tile_z", B * M * C); L.add("marginal_prob", B * C);
+        L.add("d_tile_joint", B * M * 2 * H); L.add("d_pre_tj", B * M * 2 * H); L.add("d_tile_in", B * M * H);
+    }
     L.add("stats", B * VQA_STAT_COUNT);
     L.add("pred", B);
     L.add("report", 16);
@@ -104,6 +125,10 @@ Layout make_layout(const vqa_dims_t& d) {
     g(0, 0, T * B, 3 * H, W); g(0, 1, T * B, W, 3 * H); g(1, 0, W, 3 * H, T * B);  // packed x-projection
     g(1, 0, Wp, 3 * H, T * B);
     g(0, 0, B, W, 2 * H); g(0, 0, B, A, W); g(0, 1, B, W, A); g(1, 0, 2 * H, W, B); g(0, 1, B, 2 * H, W);  // word2vec head
+    if (d.model_type == VQA_MODEL_ENT) {
+        const int64_t M = d.num_marginal, C = d.ent_cols;
+        g(0, 0, B * M, 2 * H, H); g(0, 0, B * M, C, 2 * H); g(0, 1, B * M, 2 * H, C); g(0, 1, B * M, H, 2 * H);
+    }
     L.add("gemm_ws", max64(gw, 4));
     L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
     int64_t cw = 0;
@@ -290,9 +315,16 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 }
 
 bool dims_ok(const vqa_dims_t* d) {
-    return d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-           d->N_img > 0 && d->model_type >= 0 && d->model_type <= 6;
+    if (!(d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
+          d->N_img > 0 && d->model_type >= 0 && d->model_type <= VQA_MODEL_ENT))
+        return false;
+    if (d->model_type == VQA_MODEL_ENT)       // the pairings' tensors are addressed with 32-bit element counts
+        return d->num_marginal > 0 && d->ent_cols > 0 && d->ent_cols <= d->A && d->ent_cols <= 4096 &&
+               (int64_t)d->B * d->num_marginal * (2 * (int64_t)d->H > d->ent_cols ? 2 * (int64_t)d->H : d->ent_cols) < (1ll << 30);
+    return true;
 }
+// K of pooled_linear_l = width of what the attention pools: v_adapt [R,H] for vlmap_answer_adapt, V_ft [R,D] otherwise
+inline int64_t pooled_dim(const vqa_dims_t& d) { return d.model_type == VQA_MODEL_ADAPT ? d.H : d.D; }
 
 // FC + LN + ReLU forward (modules.fc_layer, vlmap/modules.py:630-650)
 int fc_ln_relu_fwd(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N, const vqa_fc_t& p, int rows,
@@ -346,7 +378,8 @@ extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64
     if (!dims_ok(dims) || name == nullptr) return VQA_ERR_ARG;
     const Layout L = make_layout(*dims);
     const char* key = name;
-    if (strcmp(name, "condition") == 0) {  // heavy_output['condition'] = final GRU state = hs[T]
+    if (strcmp(name, "condition") == 0 && dims->model_type == VQA_MODEL_ANSWER2) key = "q_L_ft2";   // model_vlmap_answer2.py:131
+    else if (strcmp(name, "condition") == 0) {  // heavy_output['condition'] = final GRU state = hs[T]
         const Entry* h = L.find("hs");
         if (offset_bytes) *offset_bytes = h->off + (int64_t)dims->T * dims->B * dims->H * 4;
         if (n_elems) *n_elems = (int64_t)dims->B * dims->H;
@@ -388,6 +421,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     const bool forked = fork_side(c, sd);
     Ctx cv{*dims, L, c.ws, forked ? sd.s : c.st, forked ? 1 : 0};
     const bool fuse_gather = gather_mode(dims) == 1 && (D % 32 == 0) && (H % 4 == 0) && vqa_aligned16(bt->table);
+    const int mt = dims->model_type;
     // The visual branch (a1 + a2).  With the side stream it is launched first and overlaps the recurrence; on one
     // stream it runs AFTER the question branch, right before the attention that consumes it: V_ft (151 MB) and
     // v_linear_v (75 MB) are then still in the 256 MB Infinity Cache when the attention kernel reads them, instead
@@ -412,6 +446,11 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                                 cv.f("mean_v"), cv.f("rstd_v"), (int)B, (int)R, (int)H, cv.st));
         } else {
             TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_linear_v, (int)R, "pre_v", "v_linear_v", "mean_v", "rstd_v",
+                               nullptr, 1.f));
+        }
+        if (mt == VQA_MODEL_ADAPT) {     // v_adapt: a second FC + LN[R,H] + ReLU on the same V_ft (:132-135)
+            VQA_REQUIRE(P->v_adapt.w != nullptr && P->v_adapt.gamma != nullptr, VQA_ERR_ARG);
+            TRY(fc_ln_relu_fwd(cv, cv.f("V_ft"), B * R, D, H, P->v_adapt, (int)R, "pre_va", "v_adapt", "mean_va", "rstd_va",
                                nullptr, 1.f));
         }
         return VQA_OK;
@@ -457,21 +496,45 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         }
     }
     const float* h = hs + T * B * H;
+    // what q_linear_l reads: the GRU state, or one of the ablations' layers on top of it
+    const float* lin_in = h;
+    if (mt == VQA_MODEL_ANSWER2) {           // q_L_ft2 = tanh(LN(fc(q_L_ft)))   (vqa/model_vlmap_answer2.py:127-130)
+        VQA_REQUIRE(P->q_L_ft2.w != nullptr && P->q_L_ft2.gamma != nullptr, VQA_ERR_ARG);
+        ProbeScope ps("fc.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, H, H, h, (int)H, P->q_L_ft2.w, (int)H, c.f("pre_ft2"), (int)H, P->q_L_ft2.b));
+        TRY(vqa_ln_act_fwd(c.f("pre_ft2"), P->q_L_ft2.gamma, P->q_L_ft2.beta, nullptr, 1.f, c.f("q_L_ft2"), c.f("mean_ft2"),
+                           c.f("rstd_ft2"), (int)B, 1, (int)H, 1, c.st));
+        lin_in = c.f("q_L_ft2");
+    } else if (mt == VQA_MODEL_NO_NOISE || mt == VQA_MODEL_FULL) {     // q_L_mean: a plain linear layer (:122-125)
+        VQA_REQUIRE(P->q_L_mean.w != nullptr, VQA_ERR_ARG);
+        ProbeScope ps("fc.fwd_gemm", c.st);
+        TRY(gemm(c, 0, 0, B, H, H, h, (int)H, P->q_L_mean.w, (int)H, c.f("q_L_mean"), (int)H, P->q_L_mean.b));
+        lin_in = c.f("q_L_mean");
+        if (mt == VQA_MODEL_FULL) {          // reparameterisation (vqa/model_vlmap_answer_full.py:128-134)
+            VQA_REQUIRE(P->q_L_log_sigma_sq.w != nullptr && bt->noise != nullptr, VQA_ERR_ARG);
+            TRY(gemm(c, 0, 0, B, H, H, h, (int)H, P->q_L_log_sigma_sq.w, (int)H, c.f("q_L_log_sigma_sq"), (int)H,
+                     P->q_L_log_sigma_sq.b));
+            TRY(vqa_reparam_fwd(c.f("q_L_mean"), c.f("q_L_log_sigma_sq"), bt->noise, c.f("q_L_mean_noise"), c.f("extra_row"),
+                                (int)B, (int)H, c.st));
+            lin_in = c.f("q_L_mean_noise");
+        }
+    }
     // a5
     TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
     if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
     if (visual_late) TRY(visual_branch());
-    // a6 + a7
+    // a6 + a7 (vlmap_answer_adapt pools v_adapt [R,H] instead of V_ft [R,D])
+    const int64_t Dp = pooled_dim(*dims);
     {
     ProbeScope ps("attn_pool.fwd", c.st);
-    TRY(vqa_attn_pool_fwd(c.f("v_linear_v"), c.f("q_linear_v"), c.f("V_ft"), c.i32("num_V_ft"), P->score.w, P->score.b,
-                          bt->keep_att, dims->keep_att, c.f("att_score"), c.f("pooled_V_ft"), (int)B, (int)R, (int)H,
-                          (int)D, c.st));
+    TRY(vqa_attn_pool_fwd(c.f("v_linear_v"), c.f("q_linear_v"), c.f(mt == VQA_MODEL_ADAPT ? "v_adapt" : "V_ft"),
+                          c.i32("num_V_ft"), P->score.w, P->score.b, bt->keep_att, dims->keep_att, c.f("att_score"),
+                          c.f("pooled_V_ft"), (int)B, (int)R, (int)H, (int)Dp, c.st));
     }
     // a8
-    TRY(fc_ln_relu_fwd(c, c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, 1, "pre_pl", "pooled_linear_l", "mean_pl",
+    TRY(fc_ln_relu_fwd(c, c.f("pooled_V_ft"), B, Dp, H, P->pooled_linear_l, 1, "pre_pl", "pooled_linear_l", "mean_pl",
                        "rstd_pl", nullptr, 1.f));
-    TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(c, lin_in, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
     // a9
     if (dims->model_type == 5) {
         // vlmap_answer_noc (vqa/model_vlmap_answer_noc.py:177-188): no composition -- joint_v on pooled_linear_l and joint_l
@@ -530,6 +593,23 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                          dims->model_type != 1 ? 1 : 0, dims->inv_global_batch, c.f("stats"), c.i32("pred"),
                          want_dz ? c.f("dlogit") : nullptr, (int)B, (int)A, c.st));
     TRY(vqa_report_reduce(c.f("stats"), (int)B, c.f("report"), c.st));
+    if (mt == VQA_MODEL_ENT) {
+        // Maximum entropy regularisation (vqa/model_vlmap_answer_ent.py:191-211, 281-292): joint_fc (+ its own dropout)
+        // and the head's first ent_cols columns on num_marginal pairings of every question; tile_z ends up holding
+        // d loss / d logit of the pairings (want_dz) or their probabilities
+        ProbeScope ps("ent.fwd", c.st);
+        const int64_t M = dims->num_marginal, C = dims->ent_cols;
+        TRY(vqa_tile_mul_fwd(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("tile_in"), (int)B, (int)M, (int)H, c.st));
+        TRY(gemm(c, 0, 0, B * M, 2 * H, H, c.f("tile_in"), (int)H, P->joint_fc.w, (int)(2 * H), c.f("pre_tj"), (int)(2 * H),
+                 P->joint_fc.b));
+        TRY(vqa_ln_relu_fwd(c.f("pre_tj"), P->joint_fc.gamma, P->joint_fc.beta, bt->keep_tile, dims->keep_joint,
+                            c.f("tile_joint"), c.f("mean_tj"), c.f("rstd_tj"), (int)B, (int)M, (int)(2 * H), c.st));
+        TRY(gemm(c, 0, 0, B * M, C, 2 * H, c.f("tile_joint"), (int)(2 * H), P->head.w, (int)A, c.f("tile_z"), (int)C, P->head.b));
+        TRY(vqa_marginal_entropy(c.f("tile_z"), bt->train_mask, bt->exist_mask, dims->extra_weight * dims->inv_global_batch,
+                                 c.f("marginal_prob"), c.f("extra_row"), (int)B, (int)M, (int)C, (int)C, want_dz, c.st));
+    }
+    if (mt == VQA_MODEL_FULL || mt == VQA_MODEL_ENT)      // latent_loss | entropy, its weighted form and the total loss
+        TRY(vqa_extra_report(c.f("extra_row"), c.f("stats"), (int)B, dims->extra_weight, c.f("report"), c.st));
     return VQA_OK;
 }
 
@@ -559,6 +639,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     const float* h = hs + T * B * H;
     float* dh = c.f("d_h0");
     float* dxp = c.f("dxp");
+    const int mt = dims->model_type;
+    const int64_t Dp = pooled_dim(*dims);
 
     if (phases & 1) {
     {
@@ -613,16 +695,72 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
                         c.st));
     }
     }
-    TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, D, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
+    if (mt == VQA_MODEL_ENT) {
+        // the regulariser's path back to l_linear_l (pooled_linear_l is behind tf.stop_gradient, :197): tile_z holds
+        // d loss / d logit; head and joint_fc are frozen (filter_train_vars :86-94), so only dX products run
+        ProbeScope ps("ent.bwd", c.st);
+        const int64_t M = dims->num_marginal, C = dims->ent_cols;
+        TRY(gemm(c, 0, 1, B * M, 2 * H, C, c.f("tile_z"), (int)C, P->head.w, (int)A, c.f("d_tile_joint"), (int)(2 * H)));
+        TRY(vqa_ln_relu_bwd(c.f("d_tile_joint"), c.f("pre_tj"), c.f("mean_tj"), c.f("rstd_tj"), P->joint_fc.gamma,
+                            P->joint_fc.beta, bt->keep_tile, dims->keep_joint, c.f("d_pre_tj"), nullptr, nullptr, nullptr,
+                            (int)B, (int)M, (int)(2 * H), c.st));
+        TRY(gemm(c, 0, 1, B * M, H, 2 * H, c.f("d_pre_tj"), (int)(2 * H), P->joint_fc.w, (int)(2 * H), c.f("d_tile_in"), (int)H));
+        TRY(vqa_tile_mul_bwd(c.f("d_tile_in"), c.f("pooled_linear_l"), c.f("d_ll"), (int)B, (int)M, (int)H, 1, c.st));
+    }
+    TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, Dp, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
                        "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));
+    if (mt == VQA_MODEL_ANSWER2) {
+        // q_linear_l read q_L_ft2: back through it, then through tanh + LN + FC (trainable) into dh
+        TRY(fc_ln_relu_bwd(c, c.f("d_ll"), c.f("q_L_ft2"), B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll",
+                           "rstd_ll", nullptr, 1.f, "d_pre_ll", c.f("d_ft2"), false));
+        const bool train = G->q_L_ft2.w != nullptr;
+        TRY(vqa_ln_act_bwd(c.f("d_ft2"), c.f("pre_ft2"), c.f("mean_ft2"), c.f("rstd_ft2"), P->q_L_ft2.gamma, P->q_L_ft2.beta,
+                           nullptr, 1.f, c.f("d_pre_ft2"), train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
+                           train ? c.part(2) : nullptr, (int)B, 1, (int)H, 1, c.st));
+        if (train) {
+            TRY(vqa_colsum3(c.part(0), c.part(1), c.part(2), (int)B, (int)H, (int)H, G->q_L_ft2.gamma, G->q_L_ft2.beta,
+                            G->q_L_ft2.b, c.colsum_ws(), c.colsum_ws_floats(), c.st));
+            TRY(gemm(c, 1, 0, H, H, B, h, (int)H, c.f("d_pre_ft2"), (int)H, G->q_L_ft2.w, (int)H));
+        }
+        TRY(gemm(c, 0, 1, B, H, H, c.f("d_pre_ft2"), (int)H, P->q_L_ft2.w, (int)H, dh, (int)H));
+    } else if (mt == VQA_MODEL_NO_NOISE || mt == VQA_MODEL_FULL) {
+        // q_linear_l read q_L_mean (+ noise * sigma): linear layers on the GRU state
+        const bool full = mt == VQA_MODEL_FULL;
+        float* d_in = c.f(full ? "d_lin" : "d_qm");
+        TRY(fc_ln_relu_bwd(c, c.f("d_ll"), c.f(full ? "q_L_mean_noise" : "q_L_mean"), B, H, H, P->q_linear_l, &G->q_linear_l,
+                           1, "pre_ll", "mean_ll", "rstd_ll", nullptr, 1.f, "d_pre_ll", d_in, false));
+        if (full)      // through x = mean + noise * sigma, plus the KL term's own gradient (weight / global batch)
+            TRY(vqa_reparam_bwd(d_in, c.f("q_L_mean"), c.f("q_L_log_sigma_sq"), bt->noise,
+                                dims->extra_weight * dims->inv_global_batch, c.f("d_qm"), c.f("d_qs"), B * H, c.st));
+        if (G->q_L_mean.w != nullptr) {
+            TRY(gemm(c, 1, 0, H, H, B, h, (int)H, c.f("d_qm"), (int)H, G->q_L_mean.w, (int)H));
+            TRY(colsum(c, c.f("d_qm"), B, H, (int)H, G->q_L_mean.b));
+        }
+        TRY(gemm(c, 0, 1, B, H, H, c.f("d_qm"), (int)H, P->q_L_mean.w, (int)H, dh, (int)H));
+        if (full) {
+            if (G->q_L_log_sigma_sq.w != nullptr) {
+                TRY(gemm(c, 1, 0, H, H, B, h, (int)H, c.f("d_qs"), (int)H, G->q_L_log_sigma_sq.w, (int)H));
+                TRY(colsum(c, c.f("d_qs"), B, H, (int)H, G->q_L_log_sigma_sq.b));
+            }
+            TRY(gemm(c, 0, 1, B, H, H, c.f("d_qs"), (int)H, P->q_L_log_sigma_sq.w, (int)H, dh, (int)H, nullptr, dh, (int)H));
+        }
+    } else {
     TRY(fc_ln_relu_bwd(c, c.f("d_ll"), h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll",
                        nullptr, 1.f, "d_pre_ll", dh, false));
+    }
     // attention + pooling
     {
     ProbeScope ps("attn_pool.bwd", c.st);
-    TRY(vqa_attn_pool_bwd(c.f("d_pooled"), c.f("v_linear_v"), c.f("q_linear_v"), c.f("V_ft"), c.f("att_score"),
-                          P->score.w, bt->keep_att, dims->keep_att, c.f("d_v"), c.f("d_qv"), c.f("part_dw"),
-                          c.f("part_db"), (int)B, (int)R, (int)H, (int)D, c.st));
+    TRY(vqa_attn_pool_bwd(c.f("d_pooled"), c.f("v_linear_v"), c.f("q_linear_v"), c.f(mt == VQA_MODEL_ADAPT ? "v_adapt" : "V_ft"),
+                          c.f("att_score"), P->score.w, bt->keep_att, dims->keep_att, c.f("d_v"), c.f("d_qv"), c.f("part_dw"),
+                          c.f("part_db"), (int)B, (int)R, (int)H, (int)Dp, c.st));
+    }
+    if (mt == VQA_MODEL_ADAPT) {
+        // the pooled memory is trainable here: d v_adapt = att (x) d pooled, then LN[R,H] + ReLU + FC backward (V_ft is an
+        // input: parameters only), like v_linear_v's
+        TRY(vqa_outer_rows(c.f("att_score"), c.f("d_pooled"), c.f("d_va"), (int)B, (int)R, (int)H, c.st));
+        TRY(fc_ln_relu_bwd(c, c.f("d_va"), c.f("V_ft"), B * R, D, H, P->v_adapt, &G->v_adapt, (int)R, "pre_va", "mean_va",
+                           "rstd_va", nullptr, 1.f, "d_pre_va", nullptr, false));
     }
     if (G->score.w != nullptr) {
         ProbeScope ps("attn_pool.bwd", c.st);

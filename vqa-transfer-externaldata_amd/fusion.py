@@ -45,7 +45,13 @@ NOC_FAMILY = ("vlmap_answer_noc", "vlmap_answer_nocarch")
 FROZEN_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l", "WordWeightAnswerV", "WordWeightAnswerL")
 TRANSFER_TOP_SCOPES_NOC = ("q_linear_l", "pooled_linear_l", "joint_v", "joint_l")
 TWO_HEAD_FAMILY = ("vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")       # fixed head + trainable TunedWordWeightAnswer
-VLMAP_FAMILY = ("vlmap_answer",) + TWO_HEAD_FAMILY + NOC_FAMILY
+# the five older ablations of model_vlmap_answer, each the base model with ONE change (include/vqa_hot.h: VQA_MODEL_*):
+# vqa/model_vlmap_answer2.py, _no_noise.py, _adapt.py, _full.py, _ent.py
+ABLATION_FAMILY = ("vlmap_answer2", "vlmap_answer_no_noise", "vlmap_answer_adapt", "vlmap_answer_full", "vlmap_answer_ent")
+VLMAP_FAMILY = ("vlmap_answer",) + TWO_HEAD_FAMILY + NOC_FAMILY + ABLATION_FAMILY
+NUM_MARGINAL = 200            # vqa/model_vlmap_answer_ent.py:16
+W_ENTROPY = 0.1               # vqa/model_vlmap_answer_ent.py:14
+LATENT_LOSS_WEIGHT = 0.1      # vqa/model_vlmap_answer_full.py:33
 
 
 def scope_names(model_type):
@@ -69,7 +75,9 @@ def scope_names(model_type):
             "pooled_linear_l": pre + "pooled_linear_l", "q_linear_l": pre + "q_linear_l",
             "joint_fc": pre + "joint_fc", "head": head,
             # vlmap_answer_vqa_all2 only (:202-220): the tuned head and the two tuned layers that feed nothing
-            "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc"}
+            "head2": "TunedWordWeightAnswer", "tuned_q_linear_l": "tuned_q_linear_l", "tuned_joint_fc": "tuned_joint_fc",
+            # the ablations: answer2 (:127-130) | no_noise + full (:122-125) | full (:124-131) | adapt (:132-135)
+            "q_L_ft2": "q_L_ft2", "q_L_mean": "q_L_mean", "q_L_log_sigma_sq": "q_L_log_sigma_sq", "v_adapt": "v_adapt"}
 
 
 def variable_shapes(model_type, Vq, W, D, H, A):
@@ -91,8 +99,16 @@ def variable_shapes(model_type, Vq, W, D, H, A):
     s[sc["gru_cand"] + "/bias"] = (H,)
     fc(sc["q_linear_v"], H, H, True)
     fc(sc["score"], H, 1, False)
-    fc(sc["pooled_linear_l"], D, H, True)
+    fc(sc["pooled_linear_l"], H if model_type == "vlmap_answer_adapt" else D, H, True)   # adapt pools the H-wide v_adapt
     fc(sc["q_linear_l"], H, H, True)
+    if model_type == "vlmap_answer2":
+        fc(sc["q_L_ft2"], H, H, True)
+    if model_type in ("vlmap_answer_no_noise", "vlmap_answer_full"):
+        fc(sc["q_L_mean"], H, H, False)
+    if model_type == "vlmap_answer_full":
+        fc(sc["q_L_log_sigma_sq"], H, H, False)
+    if model_type == "vlmap_answer_adapt":
+        fc(sc["v_adapt"], D, H, True)
     fc(sc["joint_fc"], H, 2 * H, True)
     # standard_word2vec: the classifier maps into the 300-d word space (vqa/model_standard_word2vec.py:180-183)
     fc(sc["head"], 2 * H, W if model_type == "standard_word2vec" else A, False)
@@ -167,16 +183,20 @@ def flat_layout(model_type, shapes):
 
 class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
-                     "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6}
+                     "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6,
+                     "vlmap_answer2": 7, "vlmap_answer_no_noise": 8, "vlmap_answer_adapt": 9, "vlmap_answer_full": 10,
+                     "vlmap_answer_ent": 11}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
-                 fused_gather=False):
+                 fused_gather=False, num_marginal=NUM_MARGINAL, ent_cols=None):
         """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
         from float atomics to an atomic-free kernel, ~30 us slower at bs 512).  Per engine: the choice travels in
         vqa_dims_t.flags with every call, no process-wide library state is touched.
         fused_gather=True: no feature-gather pass; v_linear_v's GEMM reads the table rows through image_idx
-        (vqa_gemm_f32_gather).  Same step time as the default at bs 512, 151 MB less HBM traffic."""
+        (vqa_gemm_f32_gather).  Same step time as the default at bs 512, 151 MB less HBM traffic.
+        num_marginal / ent_cols (vlmap_answer_ent): pairings per question, and how many leading head columns the
+        regulariser computes (None: from the answer masks at bind_inputs -- 1 + the last known training answer)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
@@ -188,7 +208,11 @@ class FusionEngine:
                               keep_att=keep_att, keep_joint=keep_joint,
                               inv_global_batch=1.0 / float(global_batch or B),
                               flags=(_lib.FLAG_DETERMINISTIC if deterministic else 0) |
-                                    (_lib.FLAG_FUSED_GATHER if fused_gather else 0))
+                                    (_lib.FLAG_FUSED_GATHER if fused_gather else 0),
+                              num_marginal=int(num_marginal) if model_type == "vlmap_answer_ent" else 0,
+                              ent_cols=int(ent_cols or A) if model_type == "vlmap_answer_ent" else 0,
+                              extra_weight={"vlmap_answer_ent": W_ENTROPY, "vlmap_answer_full": LATENT_LOSS_WEIGHT}.get(model_type, 0.0))
+        self._ent_cols_given = ent_cols is not None
         self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
         lay = flat_layout(model_type, self.shapes)
         self.train_names, self.frozen_names = lay["train_names"], lay["frozen_names"]
@@ -292,7 +316,11 @@ class FusionEngine:
             joint_fc=fc(sc["joint_fc"], True), head=fc(sc["head"], False),
             answer_glove=self.answer_glove.data_ptr() if self.answer_glove is not None else None,
             head2=fc(sc["head2"], False) if self.model_type in TWO_HEAD_FAMILY + NOC_FAMILY else _lib.Fc(),
-            joint2=fc(sc["joint2"], True) if self.model_type in NOC_FAMILY else _lib.Fc())
+            joint2=fc(sc["joint2"], True) if self.model_type in NOC_FAMILY else _lib.Fc(),
+            q_L_ft2=fc(sc["q_L_ft2"], True) if self.model_type == "vlmap_answer2" else _lib.Fc(),
+            q_L_mean=fc(sc["q_L_mean"], False) if self.model_type in ("vlmap_answer_no_noise", "vlmap_answer_full") else _lib.Fc(),
+            q_L_log_sigma_sq=fc(sc["q_L_log_sigma_sq"], False) if self.model_type == "vlmap_answer_full" else _lib.Fc(),
+            v_adapt=fc(sc["v_adapt"], True) if self.model_type == "vlmap_answer_adapt" else _lib.Fc())
 
     def resize(self, B, T, global_batch=None):
         """Re-target the engine to another batch size / padded question length (the reference pads
@@ -310,9 +338,17 @@ class FusionEngine:
         if need > self.workspace.numel():
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
-        for a in ("_keep_att", "_keep_joint", "_keep_joint2"):
+        for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise"):
             if hasattr(self, a):
                 delattr(self, a)
+
+    def _grow_workspace(self):
+        need = int(self.lib.vqa_fusion_workspace_bytes(C.byref(self.dims)))
+        if need <= 0:
+            raise _lib.VqaHotError("vqa_fusion_workspace_bytes rejected the dims")
+        if need > self.workspace.numel():
+            self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        self._tensor_cache = {}
 
     # ------------------------------------------------------------------ workspace views
     def tensor(self, name):
@@ -335,9 +371,25 @@ class FusionEngine:
         """Device-resident feature table [N,R,D] f32, num_boxes i32 [N], float [A] masks."""
         self._table, self._nbox = table, nbox_table
         self._amask = answer_masks
+        if self.model_type == "vlmap_answer_ent" and not self._ent_cols_given:
+            # the regulariser only looks at answers with train * exist > 0.5 (vqa/model_vlmap_answer_ent.py:63-65) and the
+            # train mask is a prefix (:44-46): the head GEMM of the pairings stops after the last such column, rounded up
+            # to the GEMM's 32-column granularity
+            sel = torch.nonzero((answer_masks["train"] * answer_masks["exist"]) > 0.5)
+            last = int(sel.max()) + 1 if sel.numel() else 1
+            cols = min(self.dims.A, (last + 31) // 32 * 32)
+            if cols != self.dims.ent_cols:
+                self.dims.ent_cols = cols
+                self._grow_workspace()
 
-    def _batch_struct(self, batch, keep_att, keep_joint, keep_joint2=None):
+    def _batch_struct(self, batch, keep_att, keep_joint, keep_joint2=None, noise=None, keep_tile=None):
         d = self.dims
+        if self.model_type == "vlmap_answer_full":
+            if noise is None:
+                raise ValueError("vlmap_answer_full needs the reparameterisation noise [B, H] (make_noise)")
+            assert noise.dtype == torch.float32 and noise.numel() == d.B * d.H and noise.is_contiguous()
+        if keep_tile is not None:
+            assert keep_tile.dtype == torch.uint8 and keep_tile.numel() == d.B * d.num_marginal * 2 * d.H
         assert batch["image_idx"].dtype == torch.int64 and batch["image_idx"].numel() == d.B
         assert batch["q_intseq"].dtype == torch.int32 and tuple(batch["q_intseq"].shape) == (d.B, d.T)
         assert batch["q_intseq_len"].dtype == torch.int32
@@ -352,7 +404,7 @@ class FusionEngine:
             assert live.shape == (d.T,) and (np.diff(live) <= 0).all() and 0 <= live[-1] and live[0] <= d.B
         if keep_joint2 is not None:
             assert keep_joint2.dtype == torch.uint8 and keep_joint2.numel() == d.B * 2 * d.H
-        self._batch_keepalive = (batch, keep_att, keep_joint, keep_joint2, live)
+        self._batch_keepalive = (batch, keep_att, keep_joint, keep_joint2, live, noise, keep_tile)
         am = self._amask
         return _lib.Batch(
             table=self._table.data_ptr(), nbox_table=self._nbox.data_ptr(),
@@ -363,11 +415,15 @@ class FusionEngine:
             keep_att=keep_att.data_ptr() if keep_att is not None else None,
             keep_joint=keep_joint.data_ptr() if keep_joint is not None else None,
             keep_joint2=keep_joint2.data_ptr() if keep_joint2 is not None else None,
-            live_rows=live.ctypes.data if live is not None else None)
+            live_rows=live.ctypes.data if live is not None else None,
+            noise=noise.data_ptr() if noise is not None else None,
+            keep_tile=keep_tile.data_ptr() if keep_tile is not None else None)
 
-    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None):
-        """keep_joint2: vlmap_answer_noc only -- the keep-mask of l_joint (keep_joint is v_joint's)"""
-        self._bs = self._batch_struct(batch, keep_att, keep_joint, keep_joint2)
+    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None, noise=None, keep_tile=None):
+        """keep_joint2: vlmap_answer_noc only -- the keep-mask of l_joint (keep_joint is v_joint's);
+        noise: vlmap_answer_full only -- standard-normal draws [B, H] of the reparameterisation (make_noise);
+        keep_tile: vlmap_answer_ent only -- keep-mask [B, num_marginal, 2H] of the pairings' dropout (make_keep_mask_tile)"""
+        self._bs = self._batch_struct(batch, keep_att, keep_joint, keep_joint2, noise, keep_tile)
         _lib.check(self.lib.vqa_fusion_forward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._bs),
                                                C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
                                                1 if want_dz else 0, self._stream()), "vqa_fusion_forward")
@@ -421,8 +477,8 @@ class FusionEngine:
                                           self.n_train, C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, lr_t,
                                           ADAM_B1, ADAM_B2, ADAM_EPS, self._stream()), "vqa_clip_adam")
 
-    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None):
-        self.forward(batch, keep_att, keep_joint, want_dz=True, keep_joint2=keep_joint2)
+    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None, noise=None, keep_tile=None):
+        self.forward(batch, keep_att, keep_joint, want_dz=True, keep_joint2=keep_joint2, noise=noise, keep_tile=keep_tile)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(reducer=allreduce)          # bucketed, overlapped with the backward phases
         else:
@@ -456,8 +512,34 @@ class FusionEngine:
             r = out[:13].cpu().numpy()
         return {self.lib.vqa_report_key(i).decode(): float(r[i]) for i in range(13)}
 
+    EXTRA_REPORT_KEYS = {"vlmap_answer_full": ("latent_loss", "train_latent_loss"),       # vqa/model_vlmap_answer_full.py:222-223
+                         "vlmap_answer_ent": ("entropy", "weighted_entropy")}               # vqa/model_vlmap_answer_ent.py:293-294
+
+    def extra_report(self, global_rows=None, group=None):
+        """vlmap_answer_full / _ent: the two report scalars behind the 13 (report[13], report[14]) and the model's total
+        loss (report[15] = answer_train_loss + the weighted term); {} for every other model.  Data parallel: the
+        per-sample terms travel in stats[:, 15] and are reduced like the other statistics."""
+        keys = self.EXTRA_REPORT_KEYS.get(self.model_type)
+        if keys is None:
+            return {}
+        import torch.distributed as dist
+        if global_rows is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            r = self.tensor("report")[13:16].cpu().numpy()
+            return {keys[0]: float(r[0]), keys[1]: float(r[1]), "total_loss": float(r[2])}
+        d = self.dims
+        s = self.tensor("stats").view(d.B, 16)[:, [0, 15]].sum(0)
+        if dist.get_backend(group) == "gloo":
+            h = s.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            s = h
+        else:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+        a, e = (float(x) / float(global_rows) for x in s.cpu())
+        return {keys[0]: e, keys[1]: d.extra_weight * e, "total_loss": a + d.extra_weight * e}
+
     def loss(self):
-        return self.tensor("report")[0]
+        """the scalar optimize_loss minimises: sum of the model's `losses` (vqa/model_vlmap_answer.py:304-306)"""
+        return self.tensor("report")[15 if self.model_type in self.EXTRA_REPORT_KEYS else 0]
 
     def make_keep_masks(self, seed, step, row_offset=0, global_rows=None):
         """Reproducible dropout keep-masks for (seed, step) -- the explicit stand-in for
@@ -479,6 +561,34 @@ class FusionEngine:
                                              off + Bg * d.R * d.H + row_offset * 2 * d.H, d.keep_joint,
                                              self._stream()), "vqa_dropout_mask")
         return self._keep_att, self._keep_joint
+
+    def make_keep_mask_tile(self, seed, step, row_offset=0, global_rows=None):
+        """vlmap_answer_ent: keep-mask [B, num_marginal, 2H] of tf.nn.dropout(tile_joint, 0.5)
+        (vqa/model_vlmap_answer_ent.py:205), its own region of the (seed, step) stream, indexed by the global batch row"""
+        d = self.dims
+        Bg = int(global_rows) if global_rows is not None else d.B
+        per_row = d.num_marginal * 2 * d.H
+        n = d.B * per_row
+        if not hasattr(self, "_keep_tile"):
+            self._keep_tile = torch.empty(n, dtype=torch.uint8, device=self.device)
+        off = (2 << 40) + step * (Bg * per_row) + row_offset * per_row
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_tile.data_ptr()), n, seed, off, d.keep_joint,
+                                             self._stream()), "vqa_dropout_mask")
+        return self._keep_tile
+
+    def make_noise(self, seed, step, row_offset=0, global_rows=None):
+        """vlmap_answer_full: the standard-normal draws [B, H] that tf.random_normal(seed=123) produces inside the
+        reference graph (vqa/model_vlmap_answer_full.py:133), as an explicit reproducible input keyed by (seed, step) and
+        the global batch row"""
+        d = self.dims
+        Bg = int(global_rows) if global_rows is not None else d.B
+        n = d.B * d.H
+        if not hasattr(self, "_noise"):
+            self._noise = torch.empty(n, dtype=torch.float32, device=self.device)
+        off = step * (Bg * d.H) + row_offset * d.H
+        _lib.check(self.lib.vqa_normal_noise(C.c_void_p(self._noise.data_ptr()), n, seed, off, self._stream()),
+                   "vqa_normal_noise")
+        return self._noise
 
     def make_keep_mask_joint2(self, seed, step, row_offset=0, global_rows=None):
         """vlmap_answer_noc: the second dropout site's keep-mask (l_joint), from its own region of the same stream"""

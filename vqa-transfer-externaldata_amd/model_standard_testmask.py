@@ -17,6 +17,4 @@ REPORT_KEYS = (("answer_train_loss", "answer_train_loss"), ("answer_report_loss"
 
 class Model(_Base):
     MODEL_TYPE = "standard_testmask"
-
-    def map_report(self, report):
-        return {new: report[old] for new, old in REPORT_KEYS}
+    REPORT_RENAME = REPORT_KEYS

@@ -141,6 +141,8 @@ class Model(object):
     MODEL_TYPE = "vlmap_answer"
 
     def __init__(self, batch, config, is_train=True, image_features=None):
+        """The five older ablations (model_vlmap_answer2 / _no_noise / _adapt / _full / _ent) predate `image_features` in
+        the reference (their constructors are (batch, config, is_train)); the argument stays optional here for all."""
         self.batch = batch
         self.config = config
         self.image_dir = getattr(config, "image_dir", None)
@@ -214,7 +216,7 @@ class Model(object):
                 p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
             else:
                 p[n] = np.zeros(s, np.float32)
-        if self.MODEL_TYPE in ("vlmap_answer",) + F.TWO_HEAD_FAMILY:      # the other heads keep their Xavier / zero initialisation
+        if self.MODEL_TYPE in ("vlmap_answer",) + F.TWO_HEAD_FAMILY + F.ABLATION_FAMILY:      # the other heads keep their Xavier / zero initialisation
             w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
             p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
         elif self.MODEL_TYPE in F.NOC_FAMILY:      # WordWeightAnswerV / L from v_class_* / l_class_* (:190-202)
@@ -293,9 +295,24 @@ class Model(object):
         return db
 
     # ---------------------------------------------------------------- build = forward
-    def map_report(self, report):
-        """the step's 13 report scalars under this model's `report` keys (variants with an older report rename them)"""
-        return report
+    REPORT_RENAME = None      # ((new key, key of the 13-scalar report), ...) for the variants with an older, shorter report
+
+    def map_report(self, report, extra=None):
+        """the step's 13 report scalars under this model's `report` keys (variants with an older report rename them),
+        plus a variant's additional scalars (`extra`: FusionEngine.extra_report, e.g. latent_loss / entropy)"""
+        out = dict(report) if self.REPORT_RENAME is None else {new: report[old] for new, old in self.REPORT_RENAME}
+        if extra:
+            out.update({k: v for k, v in extra.items() if k != "total_loss"})
+        out.update(self._constant_report())
+        return out
+
+    def _constant_report(self):
+        """report entries that are not computed from the batch (e.g. model_step of the oldest variants)"""
+        return {}
+
+    def _variant_inputs(self, eng, seed, row_offset, global_rows, dropout_off):
+        """extra per-step inputs of a variant as keyword arguments of FusionEngine.forward (noise, keep_tile)"""
+        return {}
 
     def build(self):
         """build network architecture and loss (here: run it on self.batch)"""
@@ -318,21 +335,29 @@ class Model(object):
             if self.MODEL_TYPE in F.NOC_FAMILY:
                 kj2 = eng.make_keep_mask_joint2(int(getattr(self.config, "seed", 123)), self._step,
                                                 row_offset=int(getattr(self.config, "shard_row_offset", 0) or 0), global_rows=gb)
+        extra_in = self._variant_inputs(eng, int(getattr(self.config, "seed", 123)),
+                                        int(getattr(self.config, "shard_row_offset", 0) or 0), gb,
+                                        bool(getattr(self.config, "dropout_off", False)))
         self._step += 1
         self._db, self._keep = db, (ka, kj)
-        eng.forward(db, ka, kj, want_dz=self.is_train, keep_joint2=kj2)
+        eng.forward(db, ka, kj, want_dz=self.is_train, keep_joint2=kj2, **extra_in)
 
         d = eng.dims
         A, R = d.A, d.R
         stats = eng.tensor("stats").view(B, 16)
         rep = eng.tensor("report")
         keys = [eng.lib.vqa_report_key(i).decode() for i in range(13)]
-        self.report = self.map_report({k: rep[i] for i, k in enumerate(keys)})
+        xk = eng.EXTRA_REPORT_KEYS.get(self.MODEL_TYPE)
+        self.report = self.map_report({k: rep[i] for i, k in enumerate(keys)},
+                                      {xk[0]: rep[13], xk[1]: rep[14]} if xk else None)
         self.losses = {"answer": rep[0]}
-        self.loss = rep[0]
+        if xk:        # self.losses['latent'] / ['entropy'] = the weighted term; self.loss = their sum
+            self.losses[{"vlmap_answer_full": "latent", "vlmap_answer_ent": "entropy"}[self.MODEL_TYPE]] = rep[14]
+        self.loss = eng.loss()
+        Dp = d.H if self.MODEL_TYPE == "vlmap_answer_adapt" else d.D     # adapt pools the H-wide v_adapt
         self.mid_result = {
             "num_V_ft": eng.tensor("num_V_ft"), "q_linear_v": eng.tensor("q_linear_v").view(B, -1),
-            "att_score": eng.tensor("att_score").view(B, R), "pooled_V_ft": eng.tensor("pooled_V_ft").view(B, -1),
+            "att_score": eng.tensor("att_score").view(B, R), "pooled_V_ft": eng.tensor("pooled_V_ft")[:B * Dp].view(B, Dp),
             "pooled_linear_l": eng.tensor("pooled_linear_l").view(B, -1),
             "l_linear_l": eng.tensor("l_linear_l").view(B, -1), "joint": eng.tensor("joint").view(B, -1),
             "logit": eng.tensor("logit").view(B, A), "pred": eng.tensor("pred"),

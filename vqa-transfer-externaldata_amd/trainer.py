@@ -168,8 +168,10 @@ class Trainer(object):
     def _report_values(self):
         torch.cuda.synchronize(self.model.device)
         # data parallel: statistics are reduced over the ranks, so every rank logs the global-batch report
-        rep = self.model.engine.report(global_rows=self.config.global_batch if self.world > 1 else None)
-        return float(rep["answer_train_loss"]), self.model.map_report(rep)
+        gr = self.config.global_batch if self.world > 1 else None
+        rep = self.model.engine.report(global_rows=gr)
+        extra = self.model.engine.extra_report(global_rows=gr)      # latent_loss / entropy of the two variants that have one
+        return float(extra.get("total_loss", rep["answer_train_loss"])), self.model.map_report(rep, extra)
 
     # ------------------------------------------------------------------ steps
     def run_train_step(self, use_heavy_summary):
