@@ -19,7 +19,11 @@ MID = ["num_V_ft", "v_linear_v", "condition", "q_linear_v", "att_score", "pooled
        "l_linear_l", "joint", "logit", "pred"]
 
 
-def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
+ABLATION_MID = {"vlmap_answer2": [], "vlmap_answer_no_noise": ["q_L_mean"], "vlmap_answer_adapt": ["v_adapt"],
+                "vlmap_answer_full": ["q_L_mean", "q_L_log_sigma_sq", "q_L_mean_noise"], "vlmap_answer_ent": ["marginal_prob"]}
+
+
+def fusion_case(model_type, seed, B=8, R=36, T=14, N=16, num_marginal=5):
     rng = np.random.default_rng(seed)
     p = O.perturb_ln_params(O.init_params(rng, model_type, **DIMS), rng)
     table, nbox = O.make_table(rng, N, R, DIMS["D"], full_boxes=False)
@@ -28,7 +32,7 @@ def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
     batch["q_intseq"][0] = 0
     nbox[batch["image_idx"][1]] = 1
     am = O.make_answer_masks(rng, DIMS["A"], 37, exist_all=False)
-    masks = O.make_dropout_masks(rng, B, R, DIMS["H"])
+    masks = O.make_dropout_masks(rng, B, R, DIMS["H"], model_type=model_type, num_marginal=num_marginal)
     to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
     loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
                                              to64(masks), model_type)
@@ -38,12 +42,16 @@ def fusion_case(model_type, seed, B=8, R=36, T=14, N=16):
     z.update({"param/" + k: v for k, v in p.items()})
     z.update({"batch/" + k: v for k, v in batch.items()})
     z.update({"amask/" + k: v for k, v in am.items()})
-    z.update({"keep/" + k: v.astype(np.uint8) for k, v in masks.items()})
+    z.update({"keep/" + k: v.astype(np.uint8) for k, v in masks.items() if k != "noise"})
+    if "noise" in masks:                              # vlmap_answer_full: the reparameterisation's normal draws, float32
+        z["noise"] = masks["noise"]
     z["table"], z["nbox"] = table, nbox
-    z.update({"mid/" + k: np.asarray(mid[k]) for k in MID})
+    z.update({"mid/" + k: np.asarray(mid[k]) for k in MID + ABLATION_MID.get(model_type, [])})
+    z["loss"] = np.float64(loss)                      # sum of the model's losses
     z.update({"report/" + k: np.float64(v) for k, v in report.items()})
     z.update({"out/" + k: np.asarray(out[k]) for k in ("all_score", "max_train_score", "test_obj_score",
-                                                       "test_attr_score", "test_obj_max_score", "test_attr_max_score")})
+                                                       "test_attr_score", "test_obj_max_score", "test_attr_max_score")
+              if k in out})
     z.update({"grad/" + k: v.astype(np.float32) for k, v in grads.items()})
     z["dx_embed"] = dx.astype(np.float32)
     if model_type == "vlmap_answer_vqa_all2":
@@ -97,6 +105,8 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "fusion_standard_b8.npz"), **fusion_case("standard", 102))
     np.savez_compressed(os.path.join(HERE, "fusion_standard_word2vec_b4.npz"), **fusion_case("standard_word2vec", 103, B=4))
     np.savez_compressed(os.path.join(HERE, "fusion_vlmap_answer_vqa_all2_b8.npz"), **fusion_case("vlmap_answer_vqa_all2", 104))
+    for i, mt in enumerate(O.ABLATION_FAMILY):       # the five older ablations of model_vlmap_answer
+        np.savez_compressed(os.path.join(HERE, "fusion_%s_b8.npz" % mt), **fusion_case(mt, 110 + i))
     np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy.npz"), **pretrain_case())
     np.savez_compressed(os.path.join(HERE, "pretrain_cfg5_toy_persite.npz"), **pretrain_case(ln_shared=False))
     np.savez_compressed(os.path.join(HERE, "vfeat_resnet_narrow.npz"), **conv_case())

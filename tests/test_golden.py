@@ -10,7 +10,7 @@ from oracle import vqa_oracle as O
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FUSION = ["fusion_vlmap_answer_b8.npz", "fusion_standard_b8.npz", "fusion_standard_word2vec_b4.npz",
-          "fusion_vlmap_answer_vqa_all2_b8.npz"]
+          "fusion_vlmap_answer_vqa_all2_b8.npz"] + ["fusion_%s_b8.npz" % mt for mt in O.ABLATION_FAMILY]
 # one LayerNorm per shared fc_layer scope (TF 1.x; default) / one per call site: the parameter names say which
 PRETRAIN = ["pretrain_cfg5_toy.npz", "pretrain_cfg5_toy_persite.npz"]
 
@@ -27,18 +27,25 @@ def test_oracle_reproduces_fusion_golden(name):
     mt = str(z["model_type"])
     to64 = lambda d: {k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in d.items()}
     masks = {k: v.astype(np.float64) for k, v in sub("keep/").items()}
+    if "noise" in z.files:
+        masks["noise"] = z["noise"].astype(np.float64)
     loss, report, out, mid, tape = O.forward(to64(sub("param/")), to64(sub("batch/")), z["table"].astype(np.float64),
                                              z["nbox"], to64(sub("amask/")), masks, mt)
     for k, v in sub("mid/").items():
         np.testing.assert_allclose(np.asarray(mid[k], np.float64), v, rtol=1e-12, atol=1e-12, err_msg=k)
     for k, v in sub("report/").items():
         assert abs(report[k] - float(v)) <= 1e-12 * max(1, abs(float(v))), k
-    assert np.all(sub("mid/")["condition"][0] == 0)                    # the fixture keeps the len-0 question
+    assert abs(loss - float(z["loss"])) <= 1e-12 * max(1, abs(float(z["loss"])))
+    if mt != "vlmap_answer2":                                           # (its `condition` is tanh(LN(.)) of the GRU state)
+        assert np.all(sub("mid/")["condition"][0] == 0)                 # the fixture keeps the len-0 question
     np.testing.assert_array_equal(sub("mid/")["att_score"][1], np.eye(int(z["R"]))[0])   # and the 1-box image
     # float32 oracle stays within the published tolerance of its float64 self
     f32 = lambda d: {k: (v.astype(np.float32) if v.dtype.kind == "f" else v) for k, v in d.items()}
     _, _, _, mid32, _ = O.forward(f32(sub("param/")), f32(sub("batch/")), z["table"], z["nbox"], f32(sub("amask/")),
                                   {k: v.astype(np.float32) for k, v in masks.items()}, mt)
+    grads, dx = O.backward(to64(sub("param/")), to64(sub("batch/")), to64(sub("amask/")), masks, tape, mt)
+    for k, v in sub("grad/").items():
+        np.testing.assert_allclose(grads[k], v, rtol=2e-6, atol=1e-9, err_msg=k)       # stored as float32
     assert np.abs(mid32["logit"] - sub("mid/")["logit"]).max() < 1e-3
     np.testing.assert_array_equal(mid32["pred"], sub("mid/")["pred"])
 
@@ -91,25 +98,39 @@ def test_hip_matches_fusion_golden(name):
     kw = {}
     if mt == "standard_word2vec":      # the constant answer-GloVe matrix travels beside the variables
         kw["answer_glove"] = params[O.OUTPUT_GLOVE]
+    if mt == "vlmap_answer_ent":
+        kw["num_marginal"] = int(sub("keep/")["tile_joint"].shape[1])
     eng = F.FusionEngine(model_type=mt, B=B, R=R, T=T, N_img=N,
                          params={k: v for k, v in params.items() if not O.is_const(k)}, **dims, **kw)
     eng.bind_inputs(table=dev(z["table"]), nbox_table=dev(z["nbox"]),
                     answer_masks={k: dev(v) for k, v in sub("amask/").items()})
     batch = {k: dev(v) for k, v in sub("batch/").items()}
     keep = sub("keep/")
-    eng.forward(batch, dev(keep["att"]), dev(keep["joint"]), want_dz=True)
+    kw = {}
+    if "noise" in z.files:
+        kw["noise"] = dev(z["noise"].astype(np.float32))
+    if "tile_joint" in keep:
+        kw["keep_tile"] = dev(keep["tile_joint"])
+    eng.forward(batch, dev(keep["att"]), dev(keep["joint"]), want_dz=True, **kw)
     eng.backward()
     torch.cuda.synchronize()
     mid = sub("mid/")
     np.testing.assert_array_equal(eng.tensor("pred").cpu().numpy(), mid["pred"])            # bit exact
     np.testing.assert_array_equal(eng.tensor("num_V_ft").cpu().numpy(), mid["num_V_ft"])
     assert np.abs(eng.tensor("logit").cpu().numpy().reshape(mid["logit"].shape) - mid["logit"]).max() < 1e-3
-    for k in ("v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "joint"):
-        got = eng.tensor(k).cpu().numpy().reshape(mid[k].shape)
+    for k in ("v_linear_v", "condition", "q_linear_v", "att_score", "pooled_V_ft", "joint", "v_adapt", "q_L_mean",
+              "q_L_log_sigma_sq", "q_L_mean_noise"):
+        if k not in mid:
+            continue
+        got = eng.tensor(k).cpu().numpy()[:mid[k].size].reshape(mid[k].shape)
         assert np.abs(got - mid[k]).max() <= 2e-4 * max(1.0, np.abs(mid[k]).max()), k
     rep = eng.report()
+    rep.update(eng.extra_report())
+    old = {new: rep[o] for new, o in O.TESTMASK_REPORT.items()}            # the oldest variants' key names
     for k, v in sub("report/").items():
-        assert abs(rep[k] - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+        got = rep[k] if k in rep else old[k]
+        assert abs(got - float(v)) <= 1e-4 * max(1.0, abs(float(v))), k
+    assert abs(float(eng.loss()) - float(z["loss"])) <= 1e-4 * max(1.0, abs(float(z["loss"])))
     grads = sub("grad/")
     for n in eng.train_names:
         if n.endswith("score/fc/biases"):

@@ -135,7 +135,7 @@ def test_ent_edge_cases_and_eval_mode():
     run_engine(eng, batch, masks)
     _check_against_oracle(eng, mt, p, table, nbox, batch, am, masks, B, R, T, dims)
     # eval mode + no pairing dropout: probabilities of every pairing
-    nodrop = dict(masks, tile_joint=np.ones_like(masks["tile_joint"]))
+    nodrop = dict(masks, tile_joint=np.full_like(masks["tile_joint"], O.KEEP_JOINT))      # mask / keep = 1: dropout off
     ka, kj = dev(masks["att"].astype(np.uint8)), dev(masks["joint"].astype(np.uint8))
     eng.forward(dev_batch(batch), ka, kj, want_dz=False)              # keep_tile = None
     torch.cuda.synchronize()
