@@ -498,4 +498,4 @@ def test_tuning_switches_of_the_step_keep_parity():
                         "test_hip_matches_fusion_golden", "-p", "no:cacheprovider"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "4 passed" in r.stdout, r.stdout[-500:]       # the four fusion fixtures
+    assert "9 passed" in r.stdout, r.stdout[-500:]       # the nine fusion fixtures

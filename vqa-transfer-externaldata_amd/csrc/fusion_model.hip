@@ -57,7 +57,8 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("gru_r", T * B * H); L.add("gru_u", T * B * H); L.add("gru_c", T * B * H); L.add("gru_rh", T * B * H);
     L.add("pre_qv", B * H); L.add("q_linear_v", B * H); L.add("mean_qv", B); L.add("rstd_qv", B);
     L.add("att_score", B * R);
-    L.add("pooled_V_ft", B * D);
+    const int64_t Dp = d.model_type == VQA_MODEL_ADAPT ? H : D;      // width of what the attention pools (pooled_dim)
+    L.add("pooled_V_ft", B * Dp);
     L.add("pre_pl", B * H); L.add("pooled_linear_l", B * H); L.add("mean_pl", B); L.add("rstd_pl", B);
     L.add("pre_ll", B * H); L.add("l_linear_l", B * H); L.add("mean_ll", B); L.add("rstd_ll", B);
     L.add("joint_in", B * H);
@@ -102,7 +103,7 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("d_joint", B * 2 * H); L.add("d_pre_j", B * 2 * H);
     L.add("d_joint_in", B * H);
     L.add("d_pl", B * H); L.add("d_ll", B * H); L.add("d_pre_pl", B * H); L.add("d_pre_ll", B * H);
-    L.add("d_pooled", B * D);
+    L.add("d_pooled", B * Dp);
     L.add("d_h0", B * H); L.add("d_h1", B * H);
     L.add("d_v", B * R * H); L.add("d_pre_v", B * R * H);
     L.add("d_qv", B * H); L.add("d_pre_qv", B * H);

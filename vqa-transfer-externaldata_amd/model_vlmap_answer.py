@@ -354,10 +354,9 @@ class Model(object):
         if xk:        # self.losses['latent'] / ['entropy'] = the weighted term; self.loss = their sum
             self.losses[{"vlmap_answer_full": "latent", "vlmap_answer_ent": "entropy"}[self.MODEL_TYPE]] = rep[14]
         self.loss = eng.loss()
-        Dp = d.H if self.MODEL_TYPE == "vlmap_answer_adapt" else d.D     # adapt pools the H-wide v_adapt
         self.mid_result = {
             "num_V_ft": eng.tensor("num_V_ft"), "q_linear_v": eng.tensor("q_linear_v").view(B, -1),
-            "att_score": eng.tensor("att_score").view(B, R), "pooled_V_ft": eng.tensor("pooled_V_ft")[:B * Dp].view(B, Dp),
+            "att_score": eng.tensor("att_score").view(B, R), "pooled_V_ft": eng.tensor("pooled_V_ft").view(B, -1),
             "pooled_linear_l": eng.tensor("pooled_linear_l").view(B, -1),
             "l_linear_l": eng.tensor("l_linear_l").view(B, -1), "joint": eng.tensor("joint").view(B, -1),
             "logit": eng.tensor("logit").view(B, A), "pred": eng.tensor("pred"),
