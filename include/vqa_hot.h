@@ -321,6 +321,13 @@ int64_t vqa_sumsq_workspace_floats(int64_t n);
 int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float clip,
                   float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* the same with lr_t read from DEVICE memory at run time: the form a captured train-step graph replays (vqa_graph_*) */
+/* step_dev[0] += 1; lr_t_dev[0] = lr_dev[0] * sqrt(1 - beta2^step) / (1 - beta1^step) (TF1 Adam's bias-corrected rate),
+ * computed on the device so that a replayed graph advances its own step count */
+int vqa_adam_lr_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* lr_t_dev, void* stream);
+int vqa_clip_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float clip,
+                      const float* lr_t_dev, float beta1, float beta2, float eps, void* stream);
+
 /* explicit dropout keep-mask (counter-based, reproducible): out[i] = u(seed,i) < keep_prob */
 int vqa_dropout_mask(uint8_t* out, int64_t n, uint64_t seed, uint64_t offset, float keep_prob, void* stream);
 
@@ -630,6 +637,21 @@ int vqa_clock_sample(float us_per_sample, int n_samples, int n_workgroups, float
  * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
  * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */
 int vqa_stream_delay_us(float us, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Whole-step hipGraph capture / replay (csrc/graph.hip).  Every whole-model entry point, vqa_sumsq and
+ * vqa_clip_adam_dev only enqueue work on the caller's stream (side streams are forked / joined with events), so:
+ *     vqa_graph_capture_begin(stream); <one whole train step on `stream`>; vqa_graph_capture_end(stream, &exec, &n);
+ *     every later step: refresh the inputs IN PLACE (same device addresses), then vqa_graph_launch(exec, stream).
+ * Kernel arguments are frozen at capture: buffers must stay where they are, per-step scalars live in device memory.
+ * `stream` must not be the NULL stream.  n_nodes_out (may be NULL) receives the node count of the captured graph.
+ * ------------------------------------------------------------------------ */
+int vqa_graph_capture_begin(void* stream);
+int vqa_graph_capture_end(void* stream, void** exec_out, int* n_nodes_out);
+int vqa_graph_capture_abort(void* stream);
+int vqa_graph_launch(void* exec, void* stream);
+int vqa_graph_destroy(void* exec);
+int vqa_stream_is_capturing(void* stream);      /* 1 while `stream` is in capture */
 
 /* ------------------------------------------------------------------------
  * Kernels of the five older model_vlmap_answer ablations (csrc/ablation_ops.hip); the whole-model entry points

@@ -151,6 +151,14 @@ SIGNATURES = {
     "vqa_sumsq_workspace_floats": (_L, [_L]),
     "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
+    "vqa_clip_adam_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _F, _F, _F, _P]),
+    "vqa_adam_lr_step": (_I, [_P, _P, _F, _F, _P, _P]),
+    "vqa_graph_capture_begin": (_I, [_P]),
+    "vqa_graph_capture_end": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "vqa_graph_capture_abort": (_I, [_P]),
+    "vqa_graph_launch": (_I, [_P, _P]),
+    "vqa_graph_destroy": (_I, [_P]),
+    "vqa_stream_is_capturing": (_I, [_P]),
     "vqa_conv2d_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "vqa_im2col_nhwc": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), _P, _I, _P]),
     "vqa_pad_c3c4_nhwc": (_I, [_P, _I, _I, _I, C.POINTER(C.c_float), _P, _P]),

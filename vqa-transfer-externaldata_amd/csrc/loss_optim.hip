@@ -343,8 +343,11 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        const float* __restrict__ norm_sq, float clip, float lr_t,
-                                                        float b1, float b2, float eps) {
+                                                        const float* __restrict__ norm_sq, float clip, float lr_host,
+                                                        const float* __restrict__ lr_dev, float b1, float b2, float eps) {
+    // lr_t from device memory when the launch is replayed from a captured graph (the bias-corrected rate changes every
+    // step and a replay cannot change a by-value argument)
+    const float lr_t = lr_dev != nullptr ? lr_dev[0] : lr_host;
     // clip_by_global_norm: g * clip / max(norm, clip)
     const float scale = (norm_sq != nullptr) ? clip / fmaxf(sqrtf(norm_sq[0]), clip) : 1.f;
     const int64_t n4 = n / 4;
@@ -372,6 +375,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
             v[i] = b2 * v[i] + (1.f - b2) * gs * gs;
             p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
         }
+}
+
+// step <- step + 1; lr_t = lr * sqrt(1 - b2^step) / (1 - b1^step): the host arithmetic of an eager step, on the device so
+// that a captured train-step graph carries its own step count
+__global__ void adam_lr_step_kernel(int64_t* __restrict__ step, const float* __restrict__ lr, float b1, float b2,
+                                    float* __restrict__ lr_t) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t t = step[0] + 1;
+    step[0] = t;
+    const double c = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+    lr_t[0] = (float)((double)lr[0] * c);
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -527,7 +541,27 @@ extern "C" int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64
     if (n == 0) return VQA_OK;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4 + 1, 256), 4096));
     hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm_sq, clip,
-                       lr_t, beta1, beta2, eps);
+                       lr_t, (const float*)nullptr, beta1, beta2, eps);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_adam_lr_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* lr_t_dev,
+                                void* stream) {
+    VQA_REQUIRE(step_dev && lr_dev && lr_t_dev, VQA_ERR_ARG);
+    hipLaunchKernelGGL(adam_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, lr_t_dev);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_clip_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
+                                 float clip, const float* lr_t_dev, float beta1, float beta2, float eps, void* stream) {
+    VQA_REQUIRE(p && g && m && v && lr_t_dev && n >= 0, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_aligned16(p) && vqa_aligned16(g) && vqa_aligned16(m) && vqa_aligned16(v), VQA_ERR_ALIGN);
+    if (n == 0) return VQA_OK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4 + 1, 256), 4096));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm_sq, clip,
+                       0.f, lr_t_dev, beta1, beta2, eps);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }

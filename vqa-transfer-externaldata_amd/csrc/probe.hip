@@ -74,6 +74,11 @@ int vqa_probe_begin(const char* label, hipStream_t st, void** handle) {
         flags |= 1;
     }
     if (!g.on) return flags;
+    {   // a stream in graph capture: timing events recorded there would become graph nodes; the probe stays out
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        else if (cs == hipStreamCaptureStatusActive) return flags;
+    }
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.on) return flags;
     auto it = g.by_label.find(label);

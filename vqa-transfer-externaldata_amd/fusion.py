@@ -330,12 +330,14 @@ class FusionEngine:
         d = self.dims
         if B == d.B and T == d.T and global_batch is None:
             return
+        self.drop_graphs()            # captured step graphs hold this shape's buffers
         d.B, d.T = B, T
         d.inv_global_batch = 1.0 / float(global_batch or B)
         need = int(self.lib.vqa_fusion_workspace_bytes(C.byref(d)))
         if need <= 0:
             raise _lib.VqaHotError("vqa_fusion_workspace_bytes rejected the dims")
         if need > self.workspace.numel():
+            self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
         for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise"):
@@ -347,6 +349,7 @@ class FusionEngine:
         if need <= 0:
             raise _lib.VqaHotError("vqa_fusion_workspace_bytes rejected the dims")
         if need > self.workspace.numel():
+            self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
 
@@ -486,6 +489,90 @@ class FusionEngine:
             if allreduce is not None:
                 allreduce(self.grad_flat)
         self.optimizer_step(lr)
+
+    # ------------------------------------------------------------------ whole step as one hipGraph replay
+    def train_step_graph(self, batch, lr, seed, step):
+        """One train step = refresh the step's inputs in place + ONE vqa_graph_launch.
+        The first call for a shape (B, T, live_rows) captures forward -> backward -> device-side Adam rate -> norm ->
+        clip + Adam on a private stream into an executable graph (csrc/graph.hip); later calls copy the batch into the
+        graph's static input buffers, regenerate the dropout masks (and a variant's noise / pairing mask) for
+        (seed, step) in place, and replay.  Same kernels, same arithmetic as train_step (bitwise, with
+        deterministic=True); single process only (a data-parallel step keeps the eager path and its bucketed reducer).
+        The Adam step count lives on the device (vqa_adam_lr_step) and is kept equal to self.step_count."""
+        d = self.dims
+        live = batch.get("live_rows")
+        live_key = None if live is None else tuple(int(x) for x in np.asarray(live))
+        key = (d.B, d.T, live_key)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+            self._g_stream = torch.cuda.Stream(device=self.device)
+            self._g_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._g_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._g_lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._g_step_value, self._g_lr_value = None, None
+        g = self._graphs.get(key)
+        cur = torch.cuda.current_stream(self.device)
+        if g is None:
+            static = {k: torch.empty_like(batch[k]) for k in ("image_idx", "q_intseq", "q_intseq_len", "answer_target")}
+            if live is not None:
+                static["live_rows"] = np.ascontiguousarray(live, dtype=np.int32)
+            g = {"static": static, "exec": None}
+        st = g["static"]
+        self._g_stream.wait_stream(cur)
+        with torch.cuda.stream(self._g_stream):
+            for k in ("image_idx", "q_intseq", "q_intseq_len", "answer_target"):
+                st[k].copy_(batch[k], non_blocking=True)
+            if self._g_step_value != self.step_count:
+                self._g_step.fill_(self.step_count)
+            if self._g_lr_value != lr:
+                self._g_lr.fill_(lr)
+                self._g_lr_value = lr
+            ka, kj = self.make_keep_masks(seed, step)
+            extra = {}
+            if self.model_type in NOC_FAMILY:
+                extra["keep_joint2"] = self.make_keep_mask_joint2(seed, step)
+            if self.model_type == "vlmap_answer_full":
+                extra["noise"] = self.make_noise(seed, step)
+            if self.model_type == "vlmap_answer_ent":
+                extra["keep_tile"] = self.make_keep_mask_tile(seed, step)
+            if g["exec"] is None:
+                sp = C.c_void_p(self._g_stream.cuda_stream)
+                _lib.check(self.lib.vqa_graph_capture_begin(sp), "vqa_graph_capture_begin")
+                try:
+                    self.forward(st, ka, kj, want_dz=True, **extra)
+                    self.backward()
+                    e = self.embed_floats
+                    dense, tail = self.grad_flat[e:self.n_train], self.grad_flat[self.n_train:]
+                    _lib.check(self.lib.vqa_sumsq(C.c_void_p(dense.data_ptr()), dense.numel(), C.c_void_p(tail.data_ptr()),
+                                                  C.c_void_p(self.norm_sq.data_ptr()), C.c_void_p(self.sumsq_ws.data_ptr()),
+                                                  self.sumsq_ws.numel(), sp), "vqa_sumsq")
+                    _lib.check(self.lib.vqa_adam_lr_step(C.c_void_p(self._g_step.data_ptr()), C.c_void_p(self._g_lr.data_ptr()),
+                                                         ADAM_B1, ADAM_B2, C.c_void_p(self._g_lr_t.data_ptr()), sp),
+                               "vqa_adam_lr_step")
+                    _lib.check(self.lib.vqa_clip_adam_dev(
+                        C.c_void_p(self.train_flat.data_ptr()), C.c_void_p(self.grad_flat.data_ptr()),
+                        C.c_void_p(self.m_flat.data_ptr()), C.c_void_p(self.v_flat.data_ptr()), self.n_train,
+                        C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, C.c_void_p(self._g_lr_t.data_ptr()), ADAM_B1, ADAM_B2,
+                        ADAM_EPS, sp), "vqa_clip_adam_dev")
+                except Exception:
+                    self.lib.vqa_graph_capture_abort(sp)
+                    raise
+                ex, n_nodes = C.c_void_p(), C.c_int()
+                _lib.check(self.lib.vqa_graph_capture_end(sp, C.byref(ex), C.byref(n_nodes)), "vqa_graph_capture_end")
+                g["exec"], g["nodes"], g["keep"] = ex, int(n_nodes.value), (ka, kj, extra, self._bs, self._batch_keepalive)
+                self._graphs[key] = g
+            _lib.check(self.lib.vqa_graph_launch(g["exec"], C.c_void_p(self._g_stream.cuda_stream)), "vqa_graph_launch")
+        cur.wait_stream(self._g_stream)
+        self.step_count += 1
+        self._g_step_value = self.step_count
+        return g["nodes"]
+
+    def drop_graphs(self):
+        """destroys the captured step graphs (they hold the workspace's addresses: call before the workspace moves)"""
+        for g in getattr(self, "_graphs", {}).values():
+            if g.get("exec") is not None:
+                self.lib.vqa_graph_destroy(g["exec"])
+        self._graphs = {}
 
     # ------------------------------------------------------------------ results
     def report(self, global_rows=None, group=None):
