@@ -322,9 +322,10 @@ int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const
                   float lr_t, float beta1, float beta2, float eps, void* stream);
 
 /* the same with lr_t read from DEVICE memory at run time: the form a captured train-step graph replays (vqa_graph_*) */
-/* step_dev[0] += 1; lr_t_dev[0] = lr_dev[0] * sqrt(1 - beta2^step) / (1 - beta1^step) (TF1 Adam's bias-corrected rate),
- * computed on the device so that a replayed graph advances its own step count */
-int vqa_adam_lr_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* lr_t_dev, void* stream);
+/* step_dev[0] += 1; lr_t_dev[0] = (float)(lr_dev[0] * sqrt(1 - beta2^step) / (1 - beta1^step)) (TF1 Adam's bias-corrected
+ * rate, in double like the host's arithmetic of an eager step), computed on the device so that a replayed graph advances
+ * its own step count */
+int vqa_adam_lr_step(int64_t* step_dev, const double* lr_dev, double beta1, double beta2, float* lr_t_dev, void* stream);
 int vqa_clip_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float clip,
                       const float* lr_t_dev, float beta1, float beta2, float eps, void* stream);
 

@@ -152,7 +152,7 @@ SIGNATURES = {
     "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
     "vqa_clip_adam_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _F, _F, _F, _P]),
-    "vqa_adam_lr_step": (_I, [_P, _P, _F, _F, _P, _P]),
+    "vqa_adam_lr_step": (_I, [_P, _P, C.c_double, C.c_double, _P, _P]),
     "vqa_graph_capture_begin": (_I, [_P]),
     "vqa_graph_capture_end": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "vqa_graph_capture_abort": (_I, [_P]),

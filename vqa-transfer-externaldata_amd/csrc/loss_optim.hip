@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
 
 // step <- step + 1; lr_t = lr * sqrt(1 - b2^step) / (1 - b1^step): the host arithmetic of an eager step, on the device so
 // that a captured train-step graph carries its own step count
-__global__ void adam_lr_step_kernel(int64_t* __restrict__ step, const float* __restrict__ lr, float b1, float b2,
+__global__ void adam_lr_step_kernel(int64_t* __restrict__ step, const double* __restrict__ lr, double b1, double b2,
                                     float* __restrict__ lr_t) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int64_t t = step[0] + 1;
     step[0] = t;
-    const double c = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-    lr_t[0] = (float)((double)lr[0] * c);
+    // the host's expression, term by term in double: lr * sqrt(1 - b2^t) / (1 - b1^t)
+    lr_t[0] = (float)(lr[0] * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -546,7 +546,7 @@ extern "C" int vqa_clip_adam(float* p, const float* g, float* m, float* v, int64
     return VQA_OK;
 }
 
-extern "C" int vqa_adam_lr_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* lr_t_dev,
+extern "C" int vqa_adam_lr_step(int64_t* step_dev, const double* lr_dev, double beta1, double beta2, float* lr_t_dev,
                                 void* stream) {
     VQA_REQUIRE(step_dev && lr_dev && lr_t_dev, VQA_ERR_ARG);
     hipLaunchKernelGGL(adam_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, lr_t_dev);

@@ -507,7 +507,7 @@ class FusionEngine:
             self._graphs = {}
             self._g_stream = torch.cuda.Stream(device=self.device)
             self._g_step = torch.zeros(1, dtype=torch.int64, device=self.device)
-            self._g_lr = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._g_lr = torch.zeros(1, dtype=torch.float64, device=self.device)
             self._g_lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._g_step_value, self._g_lr_value = None, None
         g = self._graphs.get(key)
