@@ -379,6 +379,16 @@ typedef struct {
 #define VQA_MODEL_ADAPT 9
 #define VQA_MODEL_FULL 10
 #define VQA_MODEL_ENT 11
+/* 12 = vlmap_finetune / vlmap_only (vqa/model_vlmap_finetune.py:89-211; model_vlmap_only.py differs in its train set
+ * only, i.e. in which members of `grads` are NULL): the question is encoded by a bi-directional GRU of H/2 + H/2 units
+ * (encode_L_bidirection; gru_* = forward cell, gru_bw_* = backward cell), q_L_ft = concat(final states) feeds
+ * q_linear_l; the image attention's query is q_linear_v(pooled_q_v), pooled_q_v = a question SELF-attention
+ * (word_attention: keys q_att_key(bi-GRU outputs) [B,T,H] with LayerNorm over [T,H], query q_att_query(q_L_ft), its own
+ * dropout mask keep_word) pooling v_word_fc(V_WordMap[q]) [B,T,H].  report[0..2] = answer_train_loss,
+ * answer_report_loss, answer_accuracy (:207-211; = entries 0, 1, 2 of vqa_report_key).  The gradient of V_WordMap is
+ * scatter-added like the first table's (grads.embed2 pre-zeroed); embed_slice_sq receives the sum of squares of BOTH
+ * tables' un-aggregated slices (the second one only when grads.embed2 != NULL). */
+#define VQA_MODEL_BI 12
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
 #define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
                                      * (vqa_gemm_f32_gather) and leaves V_ft behind as a by-product; default: a gather
@@ -411,6 +421,13 @@ typedef struct {
     vqa_fc_t q_L_mean;                  /* 8, 10: [H,H], no LayerNorm */
     vqa_fc_t q_L_log_sigma_sq;          /* 10: [H,H], no LayerNorm */
     vqa_fc_t v_adapt;                   /* 9: [D,H] + LayerNorm over the [R,H] block (pooled_linear_l is then [H,H]) */
+    /* model_type 12 (NULL otherwise); gru_wg .. gru_bc are then the FORWARD cell [W+H/2, H], [H], [W+H/2, H/2], [H/2] */
+    float* embed2;                      /* V_WordMap/embed_map [Vq,W] */
+    float *gru_bw_wg, *gru_bw_bg;       /* encode_L_bi/bidirectional_rnn/bw/gru_cell/gates/{kernel,bias} */
+    float *gru_bw_wc, *gru_bw_bc;       /* .../bw/gru_cell/candidate/{kernel,bias} */
+    vqa_fc_t q_att_key, q_att_query;    /* [H,H] + LayerNorm (over [T,H] / over [H]) */
+    vqa_fc_t word_score;                /* word_attention/compute/score [H,1] */
+    vqa_fc_t v_word_fc;                 /* [W,H] + LayerNorm over [T,H] */
 } vqa_params_t;
 
 typedef struct {
@@ -430,6 +447,7 @@ typedef struct {
     /* ABI 5 */
     const float* noise;                 /* model_type 10: [B,H] standard-normal draws of the reparameterisation */
     const uint8_t* keep_tile;           /* model_type 11: keep-mask of tf.nn.dropout(tile_joint, 0.5) [B,num_marginal,2H] or NULL */
+    const uint8_t* keep_word;           /* model_type 12: keep-mask of the word attention's dropout [B,T,H] or NULL */
 } vqa_batch_t;
 
 int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims);
@@ -638,6 +656,31 @@ int vqa_clock_sample(float us_per_sample, int n_samples, int n_workgroups, float
  * The whole-model entry points use it to start the recurrence's independent row chains in anti-phase
  * (VQA_HOT_GRU_CHAINS / VQA_HOT_GRU_CHAIN_DELAY_US, csrc/fusion_model.hip). */
 int vqa_stream_delay_us(float us, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Bi-directional question encoder (modules.encode_L_bidirection, vlmap/modules.py:100-122) of
+ * vqa/model_vlmap_finetune.py / model_vlmap_only.py: helpers around the fused GRU recurrence (csrc/bi_ops.hip).
+ * tf.nn.bidirectional_dynamic_rnn runs the backward cell on reverse_sequence(inputs, len) and reverses its outputs
+ * back; outputs past a row's length are zero, final states are carried through.
+ * ------------------------------------------------------------------------ */
+/* q_rev[b,t] = q[b, len_b-1-t] for t < len_b, q[b,t] otherwise (tf.reverse_sequence on token ids [B,T]) */
+int vqa_reverse_tokens(const int32_t* q, const int32_t* len, int32_t* q_rev, int B, int T, void* stream);
+/* hs_fw / hs_bw [T+1,B,h] (time-major states of the two recurrences, the backward one over reversed tokens) ->
+ * q_map [B,T,2h] = concat(outputs) in ORIGINAL token order, zero past the length; q_ft [B,2h] = concat(final states) */
+int vqa_bi_outputs_fwd(const float* hs_fw, const float* hs_bw, const int32_t* len, float* q_map, float* q_ft, int B, int T,
+                       int h, void* stream);
+/* its transpose: d_map [B,T,2h], d_ft [B,2h] -> per-step output gradients dout_fw / dout_bw [T,B,h] in each recurrence's
+ * own step order (zero past the length) and the final-state gradients dhT_fw / dhT_bw [B,h] */
+int vqa_bi_outputs_bwd(const float* d_map, const float* d_ft, const int32_t* len, float* dout_fw, float* dout_bw,
+                       float* dhT_fw, float* dhT_bw, int B, int T, int h, void* stream);
+/* dx[t,b,:] = dx_fw[t,b,:] + dx_bw[len_b-1-t, b,:] (t < len_b; plain sum otherwise): gradient wrt the looked-up
+ * embeddings [T,B,W] time-major = the un-aggregated IndexedSlices of the embedding gradient */
+int vqa_bi_dx_combine(const float* dx_fw, const float* dx_bw, const int32_t* len, float* dx, int B, int T, int W,
+                      void* stream);
+/* vqa_gru_seq_bwd with a gradient on every step's output: d_outs [T,B,H], zero where t >= len */
+int vqa_gru_seq_bwd_outs(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len, const float* hs,
+                         const float* r, const float* u, const float* c, const float* d_outs, float* dxp,
+                         float* dh_scratch, int T, int B, int H, void* stream);
 
 /* ------------------------------------------------------------------------
  * Whole-step hipGraph capture / replay (csrc/graph.hip).  Every whole-model entry point, vqa_sumsq and

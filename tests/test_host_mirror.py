@@ -61,7 +61,8 @@ def test_importer_registry():
     native = importer.get_model_types()
     assert native == ["standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc",
                       "vlmap_answer_nocarch", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2",
-                      "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise"]
+                      "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise", "vlmap_finetune",
+                      "vlmap_only"]
     assert importer.get_model_class("vlmap_answer_") is importer.get_model_class("vlmap_answer_vqa_all")      # vqa/importer.py:33
     assert importer.get_model_class("vlmap_answer_nocarch").__mro__[1] is importer.get_model_class("vlmap_answer_noc")
     for t in native:

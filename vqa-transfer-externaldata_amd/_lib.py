@@ -39,7 +39,9 @@ class Params(C.Structure):
                 ("gru_wg", C.c_void_p), ("gru_bg", C.c_void_p), ("gru_wc", C.c_void_p), ("gru_bc", C.c_void_p),
                 ("q_linear_v", Fc), ("score", Fc), ("pooled_linear_l", Fc), ("q_linear_l", Fc),
                 ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc), ("joint2", Fc),
-                ("q_L_ft2", Fc), ("q_L_mean", Fc), ("q_L_log_sigma_sq", Fc), ("v_adapt", Fc)]
+                ("q_L_ft2", Fc), ("q_L_mean", Fc), ("q_L_log_sigma_sq", Fc), ("v_adapt", Fc),
+                ("embed2", C.c_void_p), ("gru_bw_wg", C.c_void_p), ("gru_bw_bg", C.c_void_p), ("gru_bw_wc", C.c_void_p),
+                ("gru_bw_bc", C.c_void_p), ("q_att_key", Fc), ("q_att_query", Fc), ("word_score", Fc), ("v_word_fc", Fc)]
 
 
 class Batch(C.Structure):
@@ -47,7 +49,8 @@ class Batch(C.Structure):
                 ("q_intseq", C.c_void_p), ("q_intseq_len", C.c_void_p), ("answer_target", C.c_void_p),
                 ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
                 ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p),
-                ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p), ("noise", C.c_void_p), ("keep_tile", C.c_void_p)]
+                ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p), ("noise", C.c_void_p), ("keep_tile", C.c_void_p),
+                ("keep_word", C.c_void_p)]
 
 
 class PtDims(C.Structure):
@@ -152,6 +155,11 @@ SIGNATURES = {
     "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
     "vqa_clip_adam_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _F, _F, _F, _P]),
+    "vqa_reverse_tokens": (_I, [_P, _P, _P, _I, _I, _P]),
+    "vqa_bi_outputs_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_bi_outputs_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_bi_dx_combine": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_gru_seq_bwd_outs": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_adam_lr_step": (_I, [_P, _P, C.c_double, C.c_double, _P, _P]),
     "vqa_graph_capture_begin": (_I, [_P]),
     "vqa_graph_capture_end": (_I, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),

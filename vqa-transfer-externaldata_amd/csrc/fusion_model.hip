@@ -87,6 +87,30 @@ Layout make_layout(const vqa_dims_t& d) {
         L.add("pre_va", B * R * H); L.add("v_adapt", B * R * H); L.add("mean_va", B); L.add("rstd_va", B);
         L.add("d_va", B * R * H); L.add("d_pre_va", B * R * H);
     }
+    if (d.model_type == VQA_MODEL_BI) {
+        // bi-directional question encoder + question self-attention (the forward cell reuses x_tm / xp / hs / gru_* / dxp /
+        // wx_cat / bx_cat / dwx_cat above with h = H / 2 columns; the backward cell gets its own)
+        const int64_t h = H / 2, Wq = ((W + 1 + 3) / 4) * 4;
+        L.add("q_rev", B * T);
+        L.add("x_tm_bw", T * B * Wq); L.add("xp_bw", T * B * 3 * h);
+        L.add("wx_cat_bw", W * 3 * h); L.add("bx_cat_bw", 3 * h); L.add("dwx_cat_bw", Wq * 3 * h);
+        L.add("hs_bw", (T + 1) * B * h);
+        L.add("gru_r_bw", T * B * h); L.add("gru_u_bw", T * B * h); L.add("gru_c_bw", T * B * h); L.add("gru_rh_bw", T * B * h);
+        L.add("q_L_map", B * T * H); L.add("q_L_ft", B * H);
+        L.add("pre_key", B * T * H); L.add("q_att_key", B * T * H); L.add("mean_key", B); L.add("rstd_key", B);
+        L.add("pre_query", B * H); L.add("q_att_query", B * H); L.add("mean_query", B); L.add("rstd_query", B);
+        L.add("w_att_score", B * T);
+        L.add("e2", B * T * W); L.add("pre_vw", B * T * H); L.add("q_v_ft", B * T * H); L.add("mean_vw", B); L.add("rstd_vw", B);
+        L.add("pooled_q_v", B * H);
+        L.add("d_pooled_qv", B * H); L.add("d_key", B * T * H); L.add("d_pre_key", B * T * H);
+        L.add("d_query", B * H); L.add("d_pre_query", B * H);
+        L.add("d_qvft", B * T * H); L.add("d_pre_vw", B * T * H); L.add("d_e2", B * T * W); L.add("sq_e2", 4);
+        L.add("d_qmap", B * T * H);
+        L.add("dout_fw", T * B * h); L.add("dout_bw", T * B * h);
+        L.add("dhT_fw", B * h); L.add("dhT_bw", B * h); L.add("dhS_fw", B * h); L.add("dhS_bw", B * h);
+        L.add("dxp_bw", T * B * 3 * h); L.add("dx_fw", T * B * W); L.add("dx_bw", T * B * W);
+        L.add("part_wdw", B * H); L.add("part_wdb", B);
+    }
     if (d.model_type == VQA_MODEL_ENT) {
         const int64_t M = d.num_marginal, C = d.ent_cols;
         L.add("tile_in", B * M * H); L.add("pre_tj", B * M * 2 * H); L.add("tile_joint", B * M * 2 * H);
@@ -126,6 +150,12 @@ Layout make_layout(const vqa_dims_t& d) {
     g(0, 0, T * B, 3 * H, W); g(0, 1, T * B, W, 3 * H); g(1, 0, W, 3 * H, T * B);  // packed x-projection
     g(1, 0, Wp, 3 * H, T * B);
     g(0, 0, B, W, 2 * H); g(0, 0, B, A, W); g(0, 1, B, W, A); g(1, 0, 2 * H, W, B); g(0, 1, B, 2 * H, W);  // word2vec head
+    if (d.model_type == VQA_MODEL_BI) {
+        const int64_t h = H / 2;
+        g(0, 0, T * B, 3 * h, W); g(0, 1, T * B, W, 3 * h); g(1, 0, Wp, 3 * h, T * B); g(1, 0, h, 2 * h, T * B); g(1, 0, h, h, T * B);
+        g(0, 0, B * T, H, H); g(0, 1, B * T, H, H); g(1, 0, H, H, B * T);
+        g(0, 0, B * T, H, W); g(0, 1, B * T, W, H); g(1, 0, W, H, B * T);
+    }
     if (d.model_type == VQA_MODEL_ENT) {
         const int64_t M = d.num_marginal, C = d.ent_cols;
         g(0, 0, B * M, 2 * H, H); g(0, 0, B * M, C, 2 * H); g(0, 1, B * M, 2 * H, C); g(0, 1, B * M, H, 2 * H);
@@ -137,10 +167,12 @@ Layout make_layout(const vqa_dims_t& d) {
     cw = max64(cw, vqa_colsum_workspace_floats((int)(T * B), (int)(3 * H)));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)W));
+    cw = max64(cw, vqa_colsum_workspace_floats((int)(B * T), (int)H));
     L.add("colsum_ws", max64(3 * cw, 4));    // x3: vqa_colsum3 reduces three partial matrices per launch
     L.add("colsum_ws1", max64(3 * cw, 4));
     L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
     L.add("sumsq_ws", max64(vqa_sumsq_workspace_floats(T * B * W), 4));
+    L.add("sumsq_ws2", max64(vqa_sumsq_workspace_floats(T * B * W), 4));
     return L;
 }
 
@@ -317,8 +349,9 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     if (!(d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-          d->N_img > 0 && d->model_type >= 0 && d->model_type <= VQA_MODEL_ENT))
+          d->N_img > 0 && d->model_type >= 0 && d->model_type <= VQA_MODEL_BI))
         return false;
+    if (d->model_type == VQA_MODEL_BI) return d->H % 8 == 0;      // two cells of H / 2 units, 16-byte rows each
     if (d->model_type == VQA_MODEL_ENT)       // the pairings' tensors are addressed with 32-bit element counts
         return d->num_marginal > 0 && d->ent_cols > 0 && d->ent_cols <= d->A && d->ent_cols <= 4096 &&
                (int64_t)d->B * d->num_marginal * (2 * (int64_t)d->H > d->ent_cols ? 2 * (int64_t)d->H : d->ent_cols) < (1ll << 30);
@@ -368,6 +401,150 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
     return VQA_OK;
 }
 
+// ---- model_type 12: bi-directional question encoder + question self-attention (vqa/model_vlmap_finetune.py:119-150) ----
+struct BiGru { const float *wg, *bg, *wc, *bc; };
+
+int bi_question_fwd(const Ctx& c, const vqa_params_t* P, const vqa_batch_t* bt) {
+    const vqa_dims_t& d = c.d;
+    const int64_t B = d.B, H = d.H, T = d.T, W = d.W, h = H / 2;
+    const int64_t Wp = ((W + 1 + 3) / 4) * 4;
+    VQA_REQUIRE(P->embed2 && P->gru_bw_wg && P->gru_bw_bg && P->gru_bw_wc && P->gru_bw_bc && P->q_att_key.w &&
+                    P->q_att_key.gamma && P->q_att_query.w && P->q_att_query.gamma && P->word_score.w && P->word_score.b &&
+                    P->v_word_fc.w && P->v_word_fc.gamma,
+                VQA_ERR_ARG);
+    int32_t* q_rev = c.i32("q_rev");
+    {
+        ProbeScope ps("embed.fwd", c.st);
+        TRY(vqa_reverse_tokens(bt->q_intseq, bt->q_intseq_len, q_rev, (int)B, (int)T, c.st));
+        TRY(vqa_embed_fwd_ld(P->embed, bt->q_intseq, c.f("x_tm"), (int)B, (int)T, (int)W, d.Vq, (int)Wp, c.st));
+        TRY(vqa_embed_fwd_ld(P->embed, q_rev, c.f("x_tm_bw"), (int)B, (int)T, (int)W, d.Vq, (int)Wp, c.st));
+        // the second embedding, batch-major rows (b, t): one "sequence" per token
+        TRY(vqa_embed_fwd_ld(P->embed2, bt->q_intseq, c.f("e2"), (int)(B * T), 1, (int)W, d.Vq, (int)W, c.st));
+    }
+    const BiGru cell[2] = {{P->gru_wg, P->gru_bg, P->gru_wc, P->gru_bc}, {P->gru_bw_wg, P->gru_bw_bg, P->gru_bw_wc, P->gru_bw_bc}};
+    static const char* const nm[2][9] = {{"x_tm", "xp", "wx_cat", "bx_cat", "hs", "gru_r", "gru_u", "gru_c", "gru_rh"},
+                                         {"x_tm_bw", "xp_bw", "wx_cat_bw", "bx_cat_bw", "hs_bw", "gru_r_bw", "gru_u_bw",
+                                          "gru_c_bw", "gru_rh_bw"}};
+    for (int k = 0; k < 2; ++k) {
+        {
+            ProbeScope ps("gru.xp_gemm", c.st);
+            TRY(vqa_gru_pack_wx(cell[k].wg, cell[k].wc, cell[k].bg, cell[k].bc, c.f(nm[k][2]), c.f(nm[k][3]), (int)W, (int)h, c.st));
+            TRY(gemm(c, 0, 0, T * B, 3 * h, W, c.f(nm[k][0]), (int)Wp, c.f(nm[k][2]), (int)(3 * h), c.f(nm[k][1]), (int)(3 * h),
+                     c.f(nm[k][3])));
+        }
+        float* hs = c.f(nm[k][4]);
+        if (hipMemsetAsync(hs, 0, (size_t)B * h * sizeof(float), c.st) != hipSuccess) return VQA_ERR_LAUNCH;
+        ProbeScope ps("gru.fwd", c.st);
+        TRY(vqa_gru_seq_fwd_rows(c.f(nm[k][1]), cell[k].wg + W * 2 * h, cell[k].wc + W * h, bt->q_intseq_len, hs, c.f(nm[k][5]),
+                                 c.f(nm[k][6]), c.f(nm[k][7]), c.f(nm[k][8]), (int)T, (int)B, (int)h, 0, (int)B, c.st));
+    }
+    TRY(vqa_bi_outputs_fwd(c.f("hs"), c.f("hs_bw"), bt->q_intseq_len, c.f("q_L_map"), c.f("q_L_ft"), (int)B, (int)T, (int)h, c.st));
+    // keys: fc_layer on [B,T,H] -- LayerNorm over the whole [T,H] block of a question, padded positions included
+    TRY(fc_ln_relu_fwd(c, c.f("q_L_map"), B * T, H, H, P->q_att_key, (int)T, "pre_key", "q_att_key", "mean_key", "rstd_key",
+                       nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(c, c.f("q_L_ft"), B, H, H, P->q_att_query, 1, "pre_query", "q_att_query", "mean_query", "rstd_query",
+                       nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(c, c.f("e2"), B * T, W, H, P->v_word_fc, (int)T, "pre_vw", "q_v_ft", "mean_vw", "rstd_vw", nullptr, 1.f));
+    ProbeScope ps("attn_pool.fwd", c.st);
+    return vqa_attn_pool_fwd(c.f("q_att_key"), c.f("q_att_query"), c.f("q_v_ft"), bt->q_intseq_len, P->word_score.w,
+                             P->word_score.b, bt->keep_word, d.keep_att, c.f("w_att_score"), c.f("pooled_q_v"), (int)B, (int)T,
+                             (int)H, (int)H, c.st);
+}
+
+// everything between d(pooled_q_v) / d(q_L_ft) and the two recurrences' inputs: word attention, v_word_fc (+ the second
+// embedding's slices), q_att_query, q_att_key.  dh = gradient wrt q_L_ft so far (q_linear_l's share), accumulated into.
+int bi_question_bwd_head(const Ctx& c, const vqa_params_t* P, const vqa_params_t* G, const vqa_batch_t* bt, float* dh) {
+    const vqa_dims_t& d = c.d;
+    const int64_t B = d.B, H = d.H, T = d.T, W = d.W;
+    {
+        ProbeScope ps("attn_pool.bwd", c.st);
+        TRY(vqa_attn_pool_bwd(c.f("d_pooled_qv"), c.f("q_att_key"), c.f("q_att_query"), c.f("q_v_ft"), c.f("w_att_score"),
+                              P->word_score.w, bt->keep_word, d.keep_att, c.f("d_key"), c.f("d_query"), c.f("part_wdw"),
+                              c.f("part_wdb"), (int)B, (int)T, (int)H, (int)H, c.st));
+        if (G->word_score.w != nullptr) {
+            TRY(colsum(c, c.f("part_wdw"), B, H, (int)H, G->word_score.w));
+            TRY(colsum(c, c.f("part_wdb"), B, 1, 1, G->word_score.b));
+        }
+        // the pooled memory is a trainable layer's output here: d q_v_ft = w_att (x) d pooled_q_v
+        TRY(vqa_outer_rows(c.f("w_att_score"), c.f("d_pooled_qv"), c.f("d_qvft"), (int)B, (int)T, (int)H, c.st));
+    }
+    const bool e2_train = G->embed2 != nullptr;
+    if (G->v_word_fc.w != nullptr || e2_train)
+        TRY(fc_ln_relu_bwd(c, c.f("d_qvft"), c.f("e2"), B * T, W, H, P->v_word_fc, &G->v_word_fc, (int)T, "pre_vw", "mean_vw",
+                           "rstd_vw", nullptr, 1.f, "d_pre_vw", e2_train ? c.f("d_e2") : nullptr, false));
+    if (e2_train) {      // V_WordMap: scatter-add of the batch-major slices (every position, padding included) + their norm
+        ProbeScope ps("embed.bwd", c.st);
+        TRY(vqa_embed_bwd_len_det(c.f("d_e2"), bt->q_intseq, nullptr, G->embed2, (int)(B * T), 1, (int)W, d.Vq,
+                                  (d.flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
+        TRY(vqa_sumsq(c.f("d_e2"), B * T * W, nullptr, c.f("sq_e2"), c.f("sumsq_ws2"), c.L.find("sumsq_ws2")->n, c.st));
+    }
+    TRY(fc_ln_relu_bwd(c, c.f("d_query"), c.f("q_L_ft"), B, H, H, P->q_att_query, &G->q_att_query, 1, "pre_query", "mean_query",
+                       "rstd_query", nullptr, 1.f, "d_pre_query", dh, true));
+    return fc_ln_relu_bwd(c, c.f("d_key"), c.f("q_L_map"), B * T, H, H, P->q_att_key, &G->q_att_key, (int)T, "pre_key", "mean_key",
+                          "rstd_key", nullptr, 1.f, "d_pre_key", c.f("d_qmap"), false);
+}
+
+// phase 2: both BPTTs, the gradient wrt the looked-up embeddings, LearnGloVe's scatter-add and the slice norm
+int bi_question_bwd_bptt(const Ctx& c, const vqa_params_t* P, const vqa_params_t* G, const vqa_batch_t* bt, const float* dh,
+                         float* embed_slice_sq) {
+    const vqa_dims_t& d = c.d;
+    const int64_t B = d.B, H = d.H, T = d.T, W = d.W, h = H / 2;
+    TRY(vqa_bi_outputs_bwd(c.f("d_qmap"), dh, bt->q_intseq_len, c.f("dout_fw"), c.f("dout_bw"), c.f("dhT_fw"), c.f("dhT_bw"),
+                           (int)B, (int)T, (int)h, c.st));
+    {
+        ProbeScope ps("gru.bwd", c.st);
+        TRY(vqa_gru_seq_bwd_outs(c.f("dhT_fw"), P->gru_wg + W * 2 * h, P->gru_wc + W * h, bt->q_intseq_len, c.f("hs"), c.f("gru_r"),
+                                 c.f("gru_u"), c.f("gru_c"), c.f("dout_fw"), c.f("dxp"), c.f("dhS_fw"), (int)T, (int)B, (int)h, c.st));
+        TRY(vqa_gru_seq_bwd_outs(c.f("dhT_bw"), P->gru_bw_wg + W * 2 * h, P->gru_bw_wc + W * h, bt->q_intseq_len, c.f("hs_bw"),
+                                 c.f("gru_r_bw"), c.f("gru_u_bw"), c.f("gru_c_bw"), c.f("dout_bw"), c.f("dxp_bw"), c.f("dhS_bw"),
+                                 (int)T, (int)B, (int)h, c.st));
+    }
+    {
+        ProbeScope ps("gru.dx_gemm", c.st);
+        TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)h, c.st));
+        TRY(gemm(c, 0, 1, T * B, W, 3 * h, c.f("dxp"), (int)(3 * h), c.f("wx_cat"), (int)(3 * h), c.f("dx_fw"), (int)W));
+        TRY(vqa_gru_pack_wx(P->gru_bw_wg, P->gru_bw_wc, P->gru_bw_bg, P->gru_bw_bc, c.f("wx_cat_bw"), c.f("bx_cat_bw"), (int)W,
+                            (int)h, c.st));
+        TRY(gemm(c, 0, 1, T * B, W, 3 * h, c.f("dxp_bw"), (int)(3 * h), c.f("wx_cat_bw"), (int)(3 * h), c.f("dx_bw"), (int)W));
+        TRY(vqa_bi_dx_combine(c.f("dx_fw"), c.f("dx_bw"), bt->q_intseq_len, c.f("dx_embed"), (int)B, (int)T, (int)W, c.st));
+    }
+    ProbeScope ps("embed.bwd", c.st);
+    if (G->embed != nullptr)
+        TRY(vqa_embed_bwd_len_det(c.f("dx_embed"), bt->q_intseq, bt->q_intseq_len, G->embed, (int)B, (int)T, (int)W, d.Vq,
+                                  (d.flags & VQA_FLAG_DETERMINISTIC) ? 1 : 0, c.st));
+    if (embed_slice_sq != nullptr)
+        TRY(vqa_sumsq(c.f("dx_embed"), T * B * W, G->embed2 != nullptr ? c.f("sq_e2") : nullptr, embed_slice_sq, c.f("sumsq_ws"),
+                      c.L.find("sumsq_ws")->n, c.st));
+    return VQA_OK;
+}
+
+// phases 4 / 8: the two cells' gate (incl. every x row and bias) / candidate recurrent weight gradients
+int bi_question_bwd_weights(const Ctx& c, const vqa_params_t* G, int phases) {
+    const vqa_dims_t& d = c.d;
+    const int64_t B = d.B, H = d.H, T = d.T, W = d.W, h = H / 2;
+    const int64_t Wp = ((W + 1 + 3) / 4) * 4;
+    float* const gw[2][4] = {{G->gru_wg, G->gru_wc, G->gru_bg, G->gru_bc}, {G->gru_bw_wg, G->gru_bw_wc, G->gru_bw_bg, G->gru_bw_bc}};
+    static const char* const nm[2][5] = {{"x_tm", "dxp", "dwx_cat", "hs", "gru_rh"}, {"x_tm_bw", "dxp_bw", "dwx_cat_bw", "hs_bw", "gru_rh_bw"}};
+    for (int k = 0; k < 2; ++k) {
+        if (gw[k][0] == nullptr) continue;
+        float* dxp = c.f(nm[k][1]);
+        if (phases & 4) {
+            {
+                ProbeScope ps("gru.dwx_gemm", c.st);
+                TRY(gemm(c, 1, 0, Wp, 3 * h, T * B, c.f(nm[k][0]), (int)Wp, dxp, (int)(3 * h), c.f(nm[k][2]), (int)(3 * h)));
+                TRY(vqa_gru_unpack_dwx_bias(c.f(nm[k][2]), gw[k][0], gw[k][1], gw[k][2], gw[k][3], (int)W, (int)h, c.st));
+            }
+            ProbeScope ps("gru.dwh_gemm", c.st);
+            TRY(gemm(c, 1, 0, h, 2 * h, T * B, c.f(nm[k][3]), (int)h, dxp, (int)(3 * h), gw[k][0] + W * 2 * h, (int)(2 * h)));
+        }
+        if (phases & 8) {
+            ProbeScope ps("gru.dwh_gemm", c.st);
+            TRY(gemm(c, 1, 0, h, h, T * B, c.f(nm[k][4]), (int)h, dxp + 2 * h, (int)(3 * h), gw[k][1] + W * h, (int)h));
+        }
+    }
+    return VQA_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims) {
@@ -380,6 +557,7 @@ extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64
     const Layout L = make_layout(*dims);
     const char* key = name;
     if (strcmp(name, "condition") == 0 && dims->model_type == VQA_MODEL_ANSWER2) key = "q_L_ft2";   // model_vlmap_answer2.py:131
+    else if (strcmp(name, "condition") == 0 && dims->model_type == VQA_MODEL_BI) key = "q_L_ft";  // concat of the two final states
     else if (strcmp(name, "condition") == 0) {  // heavy_output['condition'] = final GRU state = hs[T]
         const Entry* h = L.find("hs");
         if (offset_bytes) *offset_bytes = h->off + (int64_t)dims->T * dims->B * dims->H * 4;
@@ -459,6 +637,13 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     const bool visual_late = !forked && visual_late_enabled();
     if (!visual_late) TRY(visual_branch());
     if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
+    const float* h = nullptr;            // the question code q_L_ft [B,H]
+    const float* qv_in = nullptr;        // what q_linear_v reads
+    if (mt == VQA_MODEL_BI) {
+        TRY(bi_question_fwd(c, P, bt));
+        h = c.f("q_L_ft");
+        qv_in = c.f("pooled_q_v");
+    } else {
     // a3: embedding lookup, time-major
     // x_tm rows carry the constant 1 after the W inputs (vqa_embed_fwd_ld): the x-part weight-gradient GEMM then also
     // delivers the bias gradients, and the two passes over dxp that summed its columns are gone
@@ -496,7 +681,9 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
             }));
         }
     }
-    const float* h = hs + T * B * H;
+    h = hs + T * B * H;
+    qv_in = h;
+    }
     // what q_linear_l reads: the GRU state, or one of the ablations' layers on top of it
     const float* lin_in = h;
     if (mt == VQA_MODEL_ANSWER2) {           // q_L_ft2 = tanh(LN(fc(q_L_ft)))   (vqa/model_vlmap_answer2.py:127-130)
@@ -521,7 +708,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         }
     }
     // a5
-    TRY(fc_ln_relu_fwd(c, h, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
+    TRY(fc_ln_relu_fwd(c, qv_in, B, H, H, P->q_linear_v, 1, "pre_qv", "q_linear_v", "mean_qv", "rstd_qv", nullptr, 1.f));
     if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
     if (visual_late) TRY(visual_branch());
     // a6 + a7 (vlmap_answer_adapt pools v_adapt [R,H] instead of V_ft [R,D])
@@ -746,8 +933,8 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
             TRY(gemm(c, 0, 1, B, H, H, c.f("d_qs"), (int)H, P->q_L_log_sigma_sq.w, (int)H, dh, (int)H, nullptr, dh, (int)H));
         }
     } else {
-    TRY(fc_ln_relu_bwd(c, c.f("d_ll"), h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll",
-                       nullptr, 1.f, "d_pre_ll", dh, false));
+    TRY(fc_ln_relu_bwd(c, c.f("d_ll"), mt == VQA_MODEL_BI ? c.f("q_L_ft") : h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll",
+                       "mean_ll", "rstd_ll", nullptr, 1.f, "d_pre_ll", dh, false));
     }
     // attention + pooling
     {
@@ -778,12 +965,24 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
                            "mean_v", "rstd_v", nullptr, 1.f, "d_pre_v", nullptr, false));
         if (forked && !join_side_record(sd)) return VQA_ERR_LAUNCH;
     }
+    if (mt == VQA_MODEL_BI) {
+        // q_linear_v read pooled_q_v; from there back through the question self-attention into d q_L_ft (dh) / d q_L_map
+        TRY(fc_ln_relu_bwd(c, c.f("d_qv"), c.f("pooled_q_v"), B, H, H, P->q_linear_v, &G->q_linear_v, 1, "pre_qv", "mean_qv",
+                           "rstd_qv", nullptr, 1.f, "d_pre_qv", c.f("d_pooled_qv"), false));
+        TRY(bi_question_bwd_head(c, P, G, bt, dh));
+    } else {
     // q_linear_v: dh += ...
     TRY(fc_ln_relu_bwd(c, c.f("d_qv"), h, B, H, H, P->q_linear_v, &G->q_linear_v, 1, "pre_qv", "mean_qv", "rstd_qv",
                        nullptr, 1.f, "d_pre_qv", dh, true));
+    }
     if (forked && hipStreamWaitEvent(c.st, sd.join, 0) != hipSuccess) return VQA_ERR_LAUNCH;
     }   // phase 1
 
+    if (mt == VQA_MODEL_BI) {
+        if (phases & 2) TRY(bi_question_bwd_bptt(c, P, G, bt, dh, embed_slice_sq));
+        if (phases & 12) TRY(bi_question_bwd_weights(c, G, phases));
+        return VQA_OK;
+    }
     if (phases & 2) {
     // GRU back-propagation through time (gate math fused into the GEMM epilogues)
     const float* Wg_h = P->gru_wg + W * 2 * H;

@@ -1576,6 +1576,55 @@ extern "C" int vqa_gru_seq_bwd_rows(float* dh_T, const float* Wg_h, const float*
     return VQA_OK;
 }
 
+// BPTT of a recurrence whose per-step OUTPUTS are consumed too (the bi-directional encoder of vqa/model_vlmap_finetune.py:
+// q_L_map = every step's state): d_outs [T,B,H], the gradient wrt the output of step t (zero where t >= len, as
+// dynamic_rnn zeroes those outputs), joins the running state gradient before step t is differentiated -- one small add
+// per step in front of the same two fused launches as vqa_gru_seq_bwd.
+extern "C" int vqa_gru_seq_bwd_outs(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len, const float* hs,
+                                    const float* r, const float* u, const float* c, const float* d_outs, float* dxp,
+                                    float* dh_scratch, int T, int B, int H, void* stream) {
+    VQA_REQUIRE(dh_T && Wg_h && Wc_h && len && hs && r && u && c && d_outs && dxp && dh_scratch && T >= 0 && B > 0 && H > 0,
+                VQA_ERR_ARG);
+    VQA_REQUIRE(H % 4 == 0, VQA_ERR_ALIGN);
+    if (T == 0) return VQA_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t BH = (int64_t)B * H;
+    const int ld = 3 * H;
+    float* dh_acc = dh_scratch;
+    {
+        const int t = T - 1;
+        float* dxpt = dxp + (int64_t)t * B * ld;
+        int rc = vqa_add_inplace(dh_T, d_outs + t * BH, BH, stream);
+        if (rc != VQA_OK) return rc;
+        rc = vqa_gru_bwd_a(dh_T, hs + t * BH, u + t * BH, c + t * BH, len, t, dxpt + 2 * H, ld, dxpt + H, ld, dh_acc, B, H,
+                           stream);
+        if (rc != VQA_OK) return rc;
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        float* dxpt = dxp + (int64_t)t * B * ld;
+        EpiArgs e1{};
+        e1.H = H; e1.ldo = ld; e1.h_prev = hs + t * BH; e1.i0 = r + t * BH; e1.o0 = dxpt; e1.o1 = dh_acc;
+        GemmArgs a1 = make_args(B, H, H, dxpt + 2 * H, ld, Wc_h, H, nullptr, 0, nullptr, nullptr, 0);
+        int rc = launch_gru<EPI_BWD_RH>(gru_cfg_bwd(B), a1, e1, st);
+        if (rc != VQA_OK) return rc;
+        if (t > 0) {
+            rc = vqa_add_inplace(dh_acc, d_outs + (t - 1) * BH, BH, stream);     // + dL/d(output of step t-1)
+            if (rc != VQA_OK) return rc;
+            float* dxpp = dxp + (int64_t)(t - 1) * B * ld;
+            float* dh_next = (dh_acc == dh_scratch) ? dh_T : dh_scratch;
+            EpiArgs e2{};
+            e2.H = H; e2.t = t - 1; e2.ldo = ld; e2.len = len; e2.h_prev = hs + (t - 1) * BH;
+            e2.i0 = u + (t - 1) * BH; e2.i1 = c + (t - 1) * BH; e2.o0 = dxpp + 2 * H; e2.o1 = dxpp + H;
+            e2.o2 = dh_next;
+            GemmArgs a2 = make_args(B, H, 2 * H, dxpt, ld, Wg_h, 2 * H, nullptr, 0, nullptr, dh_acc, H);
+            rc = launch_gru<EPI_BWD_DH>(gru_cfg_bwd(B), a2, e2, st);
+            if (rc != VQA_OK) return rc;
+            dh_acc = dh_next;
+        }
+    }
+    return VQA_OK;
+}
+
 // ---------------------------------------------------------------------------- convolution (NHWC)
 // slim resnet_v1 inference conv + folded BatchNorm (+ residual) (+ ReLU): vlmap/modules.py:143-191,
 // 219-239, 552-572.  1x1/stride-1 convs are plain GEMMs over [B*H*W, Ci]; every other filter is an

@@ -49,6 +49,12 @@ TWO_HEAD_FAMILY = ("vlmap_answer_vqa_all", "vlmap_answer_vqa_all2")       # fixe
 # vqa/model_vlmap_answer2.py, _no_noise.py, _adapt.py, _full.py, _ent.py
 ABLATION_FAMILY = ("vlmap_answer2", "vlmap_answer_no_noise", "vlmap_answer_adapt", "vlmap_answer_full", "vlmap_answer_ent")
 VLMAP_FAMILY = ("vlmap_answer",) + TWO_HEAD_FAMILY + NOC_FAMILY + ABLATION_FAMILY
+# the bi-directional-GRU generation: vqa/model_vlmap_finetune.py and model_vlmap_only.py (same graph, different train set)
+BI_FAMILY = ("vlmap_finetune", "vlmap_only")
+FROZEN_TOP_SCOPES_ONLY = ("V_WordMap", "v_word_fc", "q_linear_v", "v_linear_v", "hadamard_attention", "q_linear_l",
+                          "pooled_linear_l", "joint_fc", "WordWeightAnswer")                     # model_vlmap_only.py:64-76
+TRANSFER_TOP_SCOPES_BI = ("v_word_fc", "q_linear_v", "v_linear_v", "hadamard_attention", "q_linear_l", "pooled_linear_l",
+                          "joint_fc")                                                            # model_vlmap_finetune.py:70-87
 NUM_MARGINAL = 200            # vqa/model_vlmap_answer_ent.py:16
 W_ENTROPY = 0.1               # vqa/model_vlmap_answer_ent.py:14
 LATENT_LOSS_WEIGHT = 0.1      # vqa/model_vlmap_answer_full.py:33
@@ -63,6 +69,15 @@ def scope_names(model_type):
                 "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
                 "pooled_linear_l": "pooled_linear_l", "q_linear_l": "q_linear_l",
                 "joint_fc": "joint_v", "joint2": "joint_l", "head": "WordWeightAnswerV", "head2": "WordWeightAnswerL"}
+    if model_type in BI_FAMILY:
+        g = "encode_L_bi/bidirectional_rnn/%s/gru_cell/%s"
+        return {"embed": "LearnGloVe/embed_map", "embed2": "V_WordMap/embed_map", "v_linear_v": "v_linear_v",
+                "gru_gates": g % ("fw", "gates"), "gru_cand": g % ("fw", "candidate"),
+                "gru_bw_gates": g % ("bw", "gates"), "gru_bw_cand": g % ("bw", "candidate"),
+                "q_att_key": "q_att_key", "q_att_query": "q_att_query", "word_score": "word_attention/compute/score",
+                "v_word_fc": "v_word_fc", "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
+                "pooled_linear_l": "pooled_linear_l", "q_linear_l": "q_linear_l", "joint_fc": "joint_fc",
+                "head": "WordWeightAnswer"}
     if model_type in VLMAP_FAMILY:
         pre, head = "", "WordWeightAnswer"
     elif model_type in STANDARD_FAMILY:
@@ -92,6 +107,26 @@ def variable_shapes(model_type, Vq, W, D, H, A):
             s[scope + "/LayerNorm/beta"] = (fout,)
             s[scope + "/LayerNorm/gamma"] = (fout,)
 
+    if model_type in BI_FAMILY:          # encode_L_bidirection: two cells of H / 2 units each (vlmap/modules.py:103-104)
+        if H % 2:
+            raise ValueError("the bi-directional encoder is built for an even language dimension")
+        h = H // 2
+        s[sc["embed2"]] = (Vq, W)
+        fc(sc["v_linear_v"], D, H, True)
+        for gates, cand in ((sc["gru_gates"], sc["gru_cand"]), (sc["gru_bw_gates"], sc["gru_bw_cand"])):
+            s[gates + "/kernel"], s[gates + "/bias"] = (W + h, 2 * h), (2 * h,)
+            s[cand + "/kernel"], s[cand + "/bias"] = (W + h, h), (h,)
+        fc(sc["q_att_key"], H, H, True)
+        fc(sc["q_att_query"], H, H, True)
+        fc(sc["word_score"], H, 1, False)
+        fc(sc["v_word_fc"], W, H, True)
+        fc(sc["q_linear_v"], H, H, True)
+        fc(sc["score"], H, 1, False)
+        fc(sc["pooled_linear_l"], D, H, True)
+        fc(sc["q_linear_l"], H, H, True)
+        fc(sc["joint_fc"], H, 2 * H, True)
+        fc(sc["head"], 2 * H, A, False)
+        return s
     fc(sc["v_linear_v"], D, H, True)
     s[sc["gru_gates"] + "/kernel"] = (W + H, 2 * H)
     s[sc["gru_gates"] + "/bias"] = (2 * H,)
@@ -124,8 +159,10 @@ def variable_shapes(model_type, Vq, W, D, H, A):
 
 def filter_train_vars(names, model_type):
     """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
-    if model_type in STANDARD_FAMILY:
+    if model_type in STANDARD_FAMILY or model_type == "vlmap_finetune":      # model_vlmap_finetune.py:64-68: everything
         return list(names)
+    if model_type == "vlmap_only":
+        return [n for n in names if n.split("/")[0] not in FROZEN_TOP_SCOPES_ONLY]
     frozen = FROZEN_TOP_SCOPES_NOC if model_type in NOC_FAMILY else FROZEN_TOP_SCOPES_VLMAP
     return [n for n in names if n.split("/")[0] not in frozen]
 
@@ -134,6 +171,8 @@ def filter_transfer_vars(names, model_type):
     """vqa/model_vlmap_answer.py:91-100 / vqa/model_standard.py:86-93."""
     if model_type in STANDARD_FAMILY:
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
+    if model_type in BI_FAMILY:
+        return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_BI]
     keep = TRANSFER_TOP_SCOPES_NOC if model_type in NOC_FAMILY else TRANSFER_TOP_SCOPES_VLMAP
     return [n for n in names if n.split("/")[0] in keep]
 
@@ -150,10 +189,13 @@ def flat_layout(model_type, shapes):
     bucketed reducer, in the order it starts them."""
     sc = scope_names(model_type)
     names = sorted(shapes)
-    embed = sc["embed"]
     train = filter_train_vars(names, model_type)
-    gru_first = sorted((n for n in train if n.startswith("encode_L/")), key=lambda n: ("/candidate/" not in n, n))
-    train_names = [embed] + gru_first + [n for n in train if n != embed and not n.startswith("encode_L/")]
+    # scatter-added tables first (the bi-directional models have a second one, V_WordMap, trainable in vlmap_finetune):
+    # they are zeroed before every backward and their norm is taken over the un-aggregated slices (tail slot)
+    embeds = [sc["embed"]] + ([sc["embed2"]] if sc.get("embed2") in train else [])
+    is_gru = lambda n: n.startswith("encode_L/") or n.startswith("encode_L_bi/")
+    gru_first = sorted((n for n in train if is_gru(n)), key=lambda n: ("/candidate/" not in n, n))
+    train_names = embeds + gru_first + [n for n in train if n not in embeds and not is_gru(n)]
     frozen_names = [n for n in names if n not in train]
 
     def carve(name_list):
@@ -166,11 +208,11 @@ def flat_layout(model_type, shapes):
 
     train_tab, n_train = carve(train_names)
     frozen_tab, n_frozen = carve(frozen_names)
-    embed_floats = _pad4(int(np.prod(shapes[embed])))
-    # the GRU tensors must sit right after the table, and inside them [candidate/* | gates/*]: the gate half is reduced
+    embed_floats = sum(_pad4(int(np.prod(shapes[n]))) for n in embeds)
+    # the GRU tensors must sit right after the tables, and inside them [candidate/* | gates/*]: the gate half is reduced
     # while the candidate half is computed
-    gru = [n for n in train_names if n.startswith("encode_L/")]
-    assert train_names[1:1 + len(gru)] == gru, "flat layout: encode_L/* must follow the embedding"
+    gru = [n for n in train_names if is_gru(n)]
+    assert train_names[len(embeds):len(embeds) + len(gru)] == gru, "flat layout: the GRU kernels must follow the embeddings"
     gru_end = embed_floats + sum(_pad4(int(np.prod(shapes[n]))) for n in gru)
     cand = [n for n in gru if "/candidate/" in n]
     assert gru[:len(cand)] == cand, "flat layout: candidate/* precede gates/*"
@@ -185,7 +227,7 @@ class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
                      "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6,
                      "vlmap_answer2": 7, "vlmap_answer_no_noise": 8, "vlmap_answer_adapt": 9, "vlmap_answer_full": 10,
-                     "vlmap_answer_ent": 11}
+                     "vlmap_answer_ent": 11, "vlmap_finetune": 12, "vlmap_only": 12}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
@@ -320,7 +362,13 @@ class FusionEngine:
             q_L_ft2=fc(sc["q_L_ft2"], True) if self.model_type == "vlmap_answer2" else _lib.Fc(),
             q_L_mean=fc(sc["q_L_mean"], False) if self.model_type in ("vlmap_answer_no_noise", "vlmap_answer_full") else _lib.Fc(),
             q_L_log_sigma_sq=fc(sc["q_L_log_sigma_sq"], False) if self.model_type == "vlmap_answer_full" else _lib.Fc(),
-            v_adapt=fc(sc["v_adapt"], True) if self.model_type == "vlmap_answer_adapt" else _lib.Fc())
+            v_adapt=fc(sc["v_adapt"], True) if self.model_type == "vlmap_answer_adapt" else _lib.Fc(),
+            **({} if self.model_type not in BI_FAMILY else dict(
+                embed2=ptr(sc["embed2"]),
+                gru_bw_wg=ptr(sc["gru_bw_gates"] + "/kernel"), gru_bw_bg=ptr(sc["gru_bw_gates"] + "/bias"),
+                gru_bw_wc=ptr(sc["gru_bw_cand"] + "/kernel"), gru_bw_bc=ptr(sc["gru_bw_cand"] + "/bias"),
+                q_att_key=fc(sc["q_att_key"], True), q_att_query=fc(sc["q_att_query"], True),
+                word_score=fc(sc["word_score"], False), v_word_fc=fc(sc["v_word_fc"], True))))
 
     def resize(self, B, T, global_batch=None):
         """Re-target the engine to another batch size / padded question length (the reference pads
@@ -340,7 +388,7 @@ class FusionEngine:
             self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
-        for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise"):
+        for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise", "_keep_word"):
             if hasattr(self, a):
                 delattr(self, a)
 
@@ -385,8 +433,10 @@ class FusionEngine:
                 self.dims.ent_cols = cols
                 self._grow_workspace()
 
-    def _batch_struct(self, batch, keep_att, keep_joint, keep_joint2=None, noise=None, keep_tile=None):
+    def _batch_struct(self, batch, keep_att, keep_joint, keep_joint2=None, noise=None, keep_tile=None, keep_word=None):
         d = self.dims
+        if keep_word is not None:
+            assert keep_word.dtype == torch.uint8 and keep_word.numel() == d.B * d.T * d.H
         if self.model_type == "vlmap_answer_full":
             if noise is None:
                 raise ValueError("vlmap_answer_full needs the reparameterisation noise [B, H] (make_noise)")
@@ -407,7 +457,7 @@ class FusionEngine:
             assert live.shape == (d.T,) and (np.diff(live) <= 0).all() and 0 <= live[-1] and live[0] <= d.B
         if keep_joint2 is not None:
             assert keep_joint2.dtype == torch.uint8 and keep_joint2.numel() == d.B * 2 * d.H
-        self._batch_keepalive = (batch, keep_att, keep_joint, keep_joint2, live, noise, keep_tile)
+        self._batch_keepalive = (batch, keep_att, keep_joint, keep_joint2, live, noise, keep_tile, keep_word)
         am = self._amask
         return _lib.Batch(
             table=self._table.data_ptr(), nbox_table=self._nbox.data_ptr(),
@@ -420,13 +470,16 @@ class FusionEngine:
             keep_joint2=keep_joint2.data_ptr() if keep_joint2 is not None else None,
             live_rows=live.ctypes.data if live is not None else None,
             noise=noise.data_ptr() if noise is not None else None,
-            keep_tile=keep_tile.data_ptr() if keep_tile is not None else None)
+            keep_tile=keep_tile.data_ptr() if keep_tile is not None else None,
+            keep_word=keep_word.data_ptr() if keep_word is not None else None)
 
-    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None, noise=None, keep_tile=None):
+    def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None, noise=None, keep_tile=None,
+                keep_word=None):
         """keep_joint2: vlmap_answer_noc only -- the keep-mask of l_joint (keep_joint is v_joint's);
         noise: vlmap_answer_full only -- standard-normal draws [B, H] of the reparameterisation (make_noise);
-        keep_tile: vlmap_answer_ent only -- keep-mask [B, num_marginal, 2H] of the pairings' dropout (make_keep_mask_tile)"""
-        self._bs = self._batch_struct(batch, keep_att, keep_joint, keep_joint2, noise, keep_tile)
+        keep_tile: vlmap_answer_ent only -- keep-mask [B, num_marginal, 2H] of the pairings' dropout (make_keep_mask_tile);
+        keep_word: vlmap_finetune / vlmap_only -- keep-mask [B, T, H] of the word attention's dropout (make_keep_mask_word)"""
+        self._bs = self._batch_struct(batch, keep_att, keep_joint, keep_joint2, noise, keep_tile, keep_word)
         _lib.check(self.lib.vqa_fusion_forward(C.byref(self.dims), C.byref(self._p_struct), C.byref(self._bs),
                                                C.c_void_p(self.workspace.data_ptr()), self.workspace.numel(),
                                                1 if want_dz else 0, self._stream()), "vqa_fusion_forward")
@@ -480,8 +533,10 @@ class FusionEngine:
                                           self.n_train, C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, lr_t,
                                           ADAM_B1, ADAM_B2, ADAM_EPS, self._stream()), "vqa_clip_adam")
 
-    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None, noise=None, keep_tile=None):
-        self.forward(batch, keep_att, keep_joint, want_dz=True, keep_joint2=keep_joint2, noise=noise, keep_tile=keep_tile)
+    def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None, noise=None, keep_tile=None,
+                   keep_word=None):
+        self.forward(batch, keep_att, keep_joint, want_dz=True, keep_joint2=keep_joint2, noise=noise, keep_tile=keep_tile,
+                     keep_word=keep_word)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(reducer=allreduce)          # bucketed, overlapped with the backward phases
         else:
@@ -535,6 +590,8 @@ class FusionEngine:
                 extra["noise"] = self.make_noise(seed, step)
             if self.model_type == "vlmap_answer_ent":
                 extra["keep_tile"] = self.make_keep_mask_tile(seed, step)
+            if self.model_type in BI_FAMILY:
+                extra["keep_word"] = self.make_keep_mask_word(seed, step)
             if g["exec"] is None:
                 sp = C.c_void_p(self._g_stream.cuda_stream)
                 _lib.check(self.lib.vqa_graph_capture_begin(sp), "vqa_graph_capture_begin")
@@ -648,6 +705,20 @@ class FusionEngine:
                                              off + Bg * d.R * d.H + row_offset * 2 * d.H, d.keep_joint,
                                              self._stream()), "vqa_dropout_mask")
         return self._keep_att, self._keep_joint
+
+    def make_keep_mask_word(self, seed, step, row_offset=0, global_rows=None):
+        """vlmap_finetune / vlmap_only: keep-mask [B, T, H] of the question self-attention's tf.nn.dropout(., 0.8)
+        (modules.hadamard_attention under scope word_attention), its own region of the (seed, step) stream"""
+        d = self.dims
+        Bg = int(global_rows) if global_rows is not None else d.B
+        per_row = d.T * d.H
+        n = d.B * per_row
+        if not hasattr(self, "_keep_word"):
+            self._keep_word = torch.empty(n, dtype=torch.uint8, device=self.device)
+        off = (3 << 40) + step * (Bg * per_row) + row_offset * per_row
+        _lib.check(self.lib.vqa_dropout_mask(C.c_void_p(self._keep_word.data_ptr()), n, seed, off, d.keep_att,
+                                             self._stream()), "vqa_dropout_mask")
+        return self._keep_word
 
     def make_keep_mask_tile(self, seed, step, row_offset=0, global_rows=None):
         """vlmap_answer_ent: keep-mask [B, num_marginal, 2H] of tf.nn.dropout(tile_joint, 0.5)

@@ -2,14 +2,15 @@
 
 The two models on the hot path and the variants of section 8f-4 -- standard_word2vec,
 standard_testmask, vlmap_answer_vqa_all, vlmap_answer_vqa_all2, vlmap_answer_noc = vlmap_answer_nocarch and the five older
-ablations vlmap_answer2 / _no_noise / _adapt / _full / _ent -- are built natively (13 of the 16 entries of
-vqa/importer.py:1-14); the three models of the bi-directional-GRU generation are listed so that a request for one fails
-with a precise message instead of an import error."""
+ablations vlmap_answer2 / _no_noise / _adapt / _full / _ent, and the two bi-directional-GRU models vlmap_finetune /
+vlmap_only -- are built natively (15 of the 16 entries of vqa/importer.py:1-14); the oldest model, `vqa` (an LSTM encoder
+over 512-d features of the retired model_vfeat pipeline scoring every answer's own LSTM code, vqa/model_vqa.py), is listed
+so that a request for it fails with a precise message instead of an import error."""
 
 _NATIVE = ("standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc", "vlmap_answer_nocarch",
            "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_adapt", "vlmap_answer_ent",
-           "vlmap_answer_full", "vlmap_answer_no_noise")
-_REFERENCE_ONLY = ("vqa", "vlmap_only", "vlmap_finetune")
+           "vlmap_answer_full", "vlmap_answer_no_noise", "vlmap_finetune", "vlmap_only")
+_REFERENCE_ONLY = ("vqa",)
 
 
 def get_model_types():
@@ -43,6 +44,10 @@ def get_model_class(model_type="vlmap_answer"):
         from .model_vlmap_answer_full import Model
     elif model_type == "vlmap_answer_no_noise":
         from .model_vlmap_answer_no_noise import Model
+    elif model_type == "vlmap_finetune":
+        from .model_vlmap_finetune import Model
+    elif model_type == "vlmap_only":
+        from .model_vlmap_only import Model
     elif model_type in _REFERENCE_ONLY:
         raise ValueError("model_type %r is an ablation variant of the reference that is out of scope of the "
                          "MI355X hot path (supported: %s)" % (model_type, ", ".join(_NATIVE)))

@@ -97,6 +97,19 @@ def word_weight_answer_init(answer_dict, input_dim, word_weights=None, default_b
     return weights, biases
 
 
+def word_weight_embed_init(vocab, word_weights=None, weight_name="v_word"):
+    """modules.WordWeightEmbed (vlmap/modules.py:393-412): rows of the question vocabulary found in the word-weight
+    directory's vocab.pkl get that directory's `weight_name` row, every other row starts at zero."""
+    w = np.zeros([len(vocab["vocab"]), W_DIM], np.float32)
+    if word_weights is not None and weight_name in word_weights and word_weights.get("vocab") is not None:
+        src, wd = word_weights[weight_name], word_weights["vocab"]["dict"]
+        for i, word in enumerate(vocab["vocab"]):
+            j = wd.get(word)
+            if j is not None and j < src.shape[0]:
+                w[i] = src[j]
+    return w
+
+
 def load_word_weight_dir(path):
     """word_weights_model-N/ written by export_word_weights: answer_dict.pkl + weights.hdf5 with class_weights /
     class_biases (vlmap/modules.py:598-601), read without h5py (hdf5_io); a weights.npz with the same keys is
@@ -104,7 +117,8 @@ def load_word_weight_dir(path):
     ad = _load_pickle(os.path.join(path, "answer_dict.pkl"))
     h5, npz = os.path.join(path, "weights.hdf5"), os.path.join(path, "weights.npz")
     # class_* of export_word_weights.py; v_class_* / l_class_* of export_noc_word_weights.py:72-75 (model_vlmap_answer_noc)
-    wanted = ("class_weights", "class_biases", "v_class_weights", "v_class_biases", "l_class_weights", "l_class_biases")
+    # v_word + vocab.pkl: modules.WordWeightEmbed of the bi-directional models (vlmap/modules.py:397-406)
+    wanted = ("class_weights", "class_biases", "v_class_weights", "v_class_biases", "l_class_weights", "l_class_biases", "v_word")
     if os.path.exists(h5):
         with hdf5_io.File(h5) as f:
             out = {k: np.array(f[k]) for k in wanted if k in f}
@@ -114,6 +128,8 @@ def load_word_weight_dir(path):
     else:
         raise FileNotFoundError("neither weights.hdf5 nor weights.npz under %s" % path)
     out["answer_dict"] = ad
+    vp = os.path.join(path, "vocab.pkl")
+    out["vocab"] = _load_pickle(vp) if os.path.exists(vp) else None
     return out
 
 
@@ -150,7 +166,7 @@ class Model(object):
         self.device = torch.device(getattr(config, "device", "cuda:0"))
 
         self.word_weight_dir = getattr(config, "vlmap_word_weight_dir", None)
-        if self.word_weight_dir is None and self.MODEL_TYPE in F.VLMAP_FAMILY:
+        if self.word_weight_dir is None and self.MODEL_TYPE in F.VLMAP_FAMILY + F.BI_FAMILY:
             log.warning("word_weight_dir is None")
 
         self.losses, self.report, self.mid_result = {}, {}, {}
@@ -209,6 +225,8 @@ class Model(object):
             if n == sc["embed"]:
                 p[n] = learn_glove_init(self.vocab, getattr(cfg, "glove", None),
                                         rng if getattr(cfg, "debug", 0) or getattr(cfg, "synthetic", 0) else None)
+            elif n == sc.get("embed2"):          # V_WordMap of the bi-directional models (:45-46)
+                p[n] = word_weight_embed_init(self.vocab, self._word_weights)
             elif n.endswith("/weights") or n.endswith("/kernel"):
                 lim = (6.0 / (s[0] + s[1])) ** 0.5            # layers.fully_connected: Xavier uniform
                 p[n] = ((torch.rand(s, generator=g) * 2 - 1) * lim).numpy()
@@ -216,7 +234,7 @@ class Model(object):
                 p[n] = np.ones(s, np.float32)                  # GRUCell gate bias 1.0, LN gamma 1
             else:
                 p[n] = np.zeros(s, np.float32)
-        if self.MODEL_TYPE in ("vlmap_answer",) + F.TWO_HEAD_FAMILY + F.ABLATION_FAMILY:      # the other heads keep their Xavier / zero initialisation
+        if self.MODEL_TYPE in ("vlmap_answer",) + F.TWO_HEAD_FAMILY + F.ABLATION_FAMILY + F.BI_FAMILY:      # the other heads keep their Xavier / zero initialisation
             w, b = word_weight_answer_init(self.answer_dict, 2 * L_DIM, self._word_weights)
             p[sc["head"] + "/fc/weights"], p[sc["head"] + "/fc/biases"] = w, b
         elif self.MODEL_TYPE in F.NOC_FAMILY:      # WordWeightAnswerV / L from v_class_* / l_class_* (:190-202)
