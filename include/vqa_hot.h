@@ -357,6 +357,8 @@ typedef struct {
                               * with train_mask * exist_mask > 0.5 (the train mask is a prefix, :44-46), rounded up by the
                               * caller as it likes (<= A); columns the masks exclude are ignored */
     float extra_weight;      /* 10: latent_loss_weight 0.1 (vqa/model_vlmap_answer_full.py:33); 11: W_ENTROPY 0.1 (:14) */
+    int32_t map_dim;         /* 13 only: MAP_DIM, the hidden width of L2V / V2L (vqa/model_vqa.py:12) */
+    int32_t La;              /* 13 only: padded token length of the candidate answers (batch.answer_intseq [A, La]) */
 } vqa_dims_t;
 /* model_type 7..11 = model_vlmap_answer (0) with ONE change each:
  *   7  vlmap_answer2          q_L_ft2 = fc_layer(q_L_ft, LN, tanh) feeds q_linear_l and is heavy_output['condition']
@@ -389,6 +391,15 @@ typedef struct {
  * scatter-added like the first table's (grads.embed2 pre-zeroed); embed_slice_sq receives the sum of squares of BOTH
  * tables' un-aggregated slices (the second one only when grads.embed2 != NULL). */
 #define VQA_MODEL_BI 12
+/* 13 = vqa (vqa/model_vqa.py:185-277, the registry's oldest model and vqa/trainer.py's default): a BasicLSTMCell
+ * (H = L_DIM units; one set of weights) encodes the questions and every candidate answer's token sequence
+ * (batch.answer_intseq [A, La]); L2V maps the question code to the D-wide features of the retired model_vfeat pipeline
+ * (D == vfeat_dim, 512), a DOT-PRODUCT attention pools V_ft, V2L maps the pooled feature back, and
+ * logit[b,a] = w . tanh(A1 answer_ft[a] + P1 pooled_map_L[b] + Q1 q_L_ft[b] + bq) + bc; loss = mean_B sum_A sigmoid-CE
+ * (no train-answer mask); report[0] = answer_loss, report[2] = answer_accuracy.  Embedding = GloVe_vocab: `glove_fixed`
+ * constant rows + the 3 trainable rows `glove_learn` (scatter-added: grads.glove_learn pre-zeroed; embed_slice_sq =
+ * sum of squares of the un-aggregated slices that reach it).  All of backward runs in phase 1. */
+#define VQA_MODEL_LEGACY_VQA 13
 #define VQA_FLAG_DETERMINISTIC 1   /* embedding-gradient scatter-add without atomics: bitwise reproducible steps */
 #define VQA_FLAG_FUSED_GATHER 2     /* no gather pass: v_linear_v's GEMM reads the table rows through image_idx
                                      * (vqa_gemm_f32_gather) and leaves V_ft behind as a by-product; default: a gather
@@ -428,6 +439,14 @@ typedef struct {
     vqa_fc_t q_att_key, q_att_query;    /* [H,H] + LayerNorm (over [T,H] / over [H]) */
     vqa_fc_t word_score;                /* word_attention/compute/score [H,1] */
     vqa_fc_t v_word_fc;                 /* [W,H] + LayerNorm over [T,H] */
+    /* model_type 13 (NULL otherwise) */
+    float* glove_fixed;                 /* constant GloVe rows [Vq-3, W] (a tf.constant: never a gradient) */
+    float* glove_learn;                 /* GloVe/learn [3, W]: the last three vocabulary entries */
+    float *lstm_k, *lstm_b;             /* encode_L/rnn/basic_lstm_cell/{kernel [W+H, 4H], bias [4H]} */
+    vqa_fc_t l2v[3];                    /* L2V/{fc_1 [H,M], fc_2 [M,M], Linear [M,D]} (ReLU, ReLU, none; no LayerNorm) */
+    vqa_fc_t v2l[3];                    /* V2L/{fc_1 [D,M], fc_2 [M,M], Linear [M,H]} (tanh, tanh, none) */
+    vqa_fc_t answer_layer1, pooled_layer1, q_layer1;   /* reasoning/... [H,H]; only q_layer1 has a bias */
+    vqa_fc_t classifier;                /* reasoning/classifier [H,1] + bias */
 } vqa_params_t;
 
 typedef struct {
@@ -448,6 +467,8 @@ typedef struct {
     const float* noise;                 /* model_type 10: [B,H] standard-normal draws of the reparameterisation */
     const uint8_t* keep_tile;           /* model_type 11: keep-mask of tf.nn.dropout(tile_joint, 0.5) [B,num_marginal,2H] or NULL */
     const uint8_t* keep_word;           /* model_type 12: keep-mask of the word attention's dropout [B,T,H] or NULL */
+    const int32_t* answer_intseq;       /* model_type 13: token ids of the candidate answers [A, La], zero padded */
+    const int32_t* answer_intseq_len;   /* model_type 13: [A] */
 } vqa_batch_t;
 
 int64_t vqa_fusion_workspace_bytes(const vqa_dims_t* dims);
@@ -681,6 +702,36 @@ int vqa_bi_dx_combine(const float* dx_fw, const float* dx_bw, const int32_t* len
 int vqa_gru_seq_bwd_outs(float* dh_T, const float* Wg_h, const float* Wc_h, const int32_t* len, const float* hs,
                          const float* r, const float* u, const float* c, const float* d_outs, float* dxp,
                          float* dh_scratch, int T, int B, int H, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Kernels of the oldest registry model, vqa/model_vqa.py (csrc/lstm_ops.hip); composed for model_type 13.
+ * ------------------------------------------------------------------------ */
+/* modules.GloVe_vocab lookup (vlmap/modules.py:451-467): x_tm[t,n,:] = id < Vq-3 ? fixed[id] : learn[id-(Vq-3)] for
+ * id = ids[n,t] (ids batch-major [N,T], rows time-major [T,N,W]); backward: scatter-add of the rows with id >= Vq-3 into
+ * dlearn [3,W] (float atomics) and slice_sq[0] += sum of squares of those rows. */
+int vqa_embed2_fwd(const float* fixed, const float* learn, const int32_t* ids, float* x_tm, int N, int T, int W, int Vq,
+                   void* stream);
+int vqa_embed2_bwd(const float* dx_tm, const int32_t* ids, float* dlearn, float* slice_sq, int N, int T, int W, int Vq,
+                   void* stream);
+/* One step of tf.contrib.rnn.BasicLSTMCell under dynamic_rnn(sequence_length): gates [N,4L] holds [x,h] K + b on entry
+ * (order i, j, f, o) and the activated gates (f with forget_bias 1.0 folded in) on return; c_new = c f + i j, h_new =
+ * tanh(c_new) o for rows with t < len, (c, h) carried through otherwise. */
+int vqa_lstm_step_fwd(float* gates, const float* c_prev, const float* h_prev, const int32_t* len, int t, float* c_new,
+                      float* h_new, int N, int L, void* stream);
+/* its backward: dh, dc wrt the step's (h, c) -> dgates [N,4L] wrt the pre-activations, dc_prev, and dh_carry (dh of the
+ * finished rows; the caller adds dgates K_h^T) */
+int vqa_lstm_step_bwd(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_new,
+                      const int32_t* len, int t, float* dgates, float* dc_prev, float* dh_carry, int N, int L, void* stream);
+int vqa_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int vqa_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int vqa_fill(float* x, int64_t n, float value, void* stream);
+/* vqa/model_vqa.py:232-257 without the [B,A,L] intermediate: z[b,a] = sum_k w[k] tanh(al[a,k] + pq[b,k]) + bias[0]
+ * (al = answer_layer1 [A,L], pq = pooled_layer1 + q_layer1 [B,L]); backward: d_al [A,L], d_pq [B,L] and the per-question
+ * partials part_dw [B,L] of the classifier weight gradient (reduce with vqa_colsum); L <= 1024. */
+int vqa_score_fwd(const float* al, const float* pq, const float* w, const float* bias, float* z, int B, int A, int L,
+                  void* stream);
+int vqa_score_bwd(const float* dz, const float* al, const float* pq, const float* w, float* d_al, float* d_pq,
+                  float* part_dw, int B, int A, int L, void* stream);
 
 /* ------------------------------------------------------------------------
  * Whole-step hipGraph capture / replay (csrc/graph.hip).  Every whole-model entry point, vqa_sumsq and

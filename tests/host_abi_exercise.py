@@ -37,13 +37,19 @@ names = [b"V_ft", b"num_V_ft", b"v_linear_v", b"condition", b"q_linear_v", b"att
 VARIANT_TENSORS = {4: [b"logit_fixed", b"logit_tuned", b"dlogit_tuned"], 6: [b"logit_fixed", b"logit_tuned", b"dlogit_tuned", b"logit_raw", b"rowmin"],
                    5: [b"l_joint", b"pre_jl"], 7: [b"q_L_ft2", b"pre_ft2", b"d_ft2"], 8: [b"q_L_mean", b"d_qm"], 9: [b"v_adapt", b"pre_va", b"d_va"],
                    10: [b"q_L_mean", b"q_L_log_sigma_sq", b"q_L_mean_noise", b"extra_row"],
-                   11: [b"tile_in", b"pre_tj", b"tile_joint", b"tile_z", b"marginal_prob", b"extra_row", b"d_tile_in"]}
-for mt in range(12):
+                   11: [b"tile_in", b"pre_tj", b"tile_joint", b"tile_z", b"marginal_prob", b"extra_row", b"d_tile_in"],
+                   12: [b"q_rev", b"hs_bw", b"q_L_map", b"q_L_ft", b"q_att_key", b"w_att_score", b"q_v_ft", b"pooled_q_v", b"d_e2", b"dxp_bw"],
+                   13: [b"lv_gq", b"lv_hsa", b"q_map_V", b"pooled_map_L", b"lv_al", b"lv_dga", b"q_L_ft", b"answer_ft"]}
+for mt in range(14):
     for (B, R, D, H, T, W, A, Vq, N) in ((1, 1, 4, 4, 1, 1, 1, 1, 1), (5, 6, 24, 16, 7, 12, 21, 30, 9),
                                          (7, 36, 64, 32, 3, 300, 50, 60, 16), (512, 36, 2048, 1024, 14, 300, 3000, 16384, 8192)):
+        if mt == 12 and H % 8:
+            continue                      # the bi-directional encoder needs two 16-byte-row halves
+        if mt == 13 and (W % 4 or Vq <= 3):
+            continue
         d = _lib.Dims(B=B, R=R, D=D, H=H, T=T, W=W, A=A, Vq=Vq, N_img=N, model_type=mt, keep_att=0.8, keep_joint=0.5,
                       inv_global_batch=1.0 / B, num_marginal=200 if mt == 11 else 0, ent_cols=min(A, 2272) if mt == 11 else 0,
-                      extra_weight=0.1)
+                      extra_weight=0.1, map_dim=H if mt == 13 else 0, La=4 if mt == 13 else 0)
         total = lib.vqa_fusion_workspace_bytes(C.byref(d))
         ok(total > 0, "workspace bytes %r" % ((mt, B),))
         for nm in names + VARIANT_TENSORS.get(mt, []):
@@ -52,7 +58,8 @@ for mt in range(12):
         ok(lib.vqa_fusion_tensor(C.byref(d), b"logit_tuned", C.byref(off), C.byref(n)) == (0 if mt in (4, 6) else -1), "variant tensor")
         ok(lib.vqa_fusion_tensor(C.byref(d), b"", C.byref(off), C.byref(n)) == -1, "empty name")
         ok(lib.vqa_fusion_tensor(C.byref(d), b"x" * 300, None, None) == -1, "long unknown name")
-for bad in (dict(B=0), dict(R=0), dict(model_type=12), dict(model_type=-1), dict(H=-4), dict(N_img=0),
+for bad in (dict(B=0), dict(R=0), dict(model_type=14), dict(model_type=-1), dict(H=-4), dict(N_img=0), dict(model_type=12, H=12),
+            dict(model_type=13), dict(model_type=13, map_dim=8), dict(model_type=13, map_dim=8, La=2, Vq=3),
             dict(model_type=11), dict(model_type=11, num_marginal=3), dict(model_type=11, num_marginal=3, ent_cols=5),
             dict(model_type=11, num_marginal=1 << 28, ent_cols=4), dict(model_type=11, num_marginal=2, ent_cols=4097, A=5000)):
     kw = dict(B=4, R=4, D=8, H=8, T=2, W=4, A=4, Vq=4, N_img=4, model_type=0)

@@ -62,7 +62,7 @@ def test_importer_registry():
     assert native == ["standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc",
                       "vlmap_answer_nocarch", "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2",
                       "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise", "vlmap_finetune",
-                      "vlmap_only"]
+                      "vlmap_only", "vqa"]
     assert importer.get_model_class("vlmap_answer_") is importer.get_model_class("vlmap_answer_vqa_all")      # vqa/importer.py:33
     assert importer.get_model_class("vlmap_answer_nocarch").__mro__[1] is importer.get_model_class("vlmap_answer_noc")
     for t in native:
@@ -71,10 +71,7 @@ def test_importer_registry():
     reference = ["vqa", "standard", "standard_testmask", "standard_word2vec", "vlmap_only", "vlmap_finetune", "vlmap_answer",
                  "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_noc", "vlmap_answer_nocarch",
                  "vlmap_answer_adapt", "vlmap_answer_ent", "vlmap_answer_full", "vlmap_answer_no_noise"]
-    assert set(native) <= set(reference)
-    for t in sorted(set(reference) - set(native)):
-        with pytest.raises(ValueError, match="out of scope"):
-            importer.get_model_class(t)
+    assert set(native) == set(reference)                                     # all 16 entries are native
     with pytest.raises(ValueError, match="Unknown model_type"):
         importer.get_model_class("nope")
 

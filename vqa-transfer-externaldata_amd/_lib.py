@@ -22,7 +22,8 @@ class Dims(C.Structure):
                 ("W", C.c_int32), ("A", C.c_int32), ("Vq", C.c_int32), ("N_img", C.c_int64),
                 ("model_type", C.c_int32), ("keep_att", C.c_float), ("keep_joint", C.c_float),
                 ("inv_global_batch", C.c_float), ("flags", C.c_int32),
-                ("num_marginal", C.c_int32), ("ent_cols", C.c_int32), ("extra_weight", C.c_float)]
+                ("num_marginal", C.c_int32), ("ent_cols", C.c_int32), ("extra_weight", C.c_float),
+                ("map_dim", C.c_int32), ("La", C.c_int32)]
 
 
 FLAG_DETERMINISTIC = 1
@@ -41,7 +42,10 @@ class Params(C.Structure):
                 ("joint_fc", Fc), ("head", Fc), ("answer_glove", C.c_void_p), ("head2", Fc), ("joint2", Fc),
                 ("q_L_ft2", Fc), ("q_L_mean", Fc), ("q_L_log_sigma_sq", Fc), ("v_adapt", Fc),
                 ("embed2", C.c_void_p), ("gru_bw_wg", C.c_void_p), ("gru_bw_bg", C.c_void_p), ("gru_bw_wc", C.c_void_p),
-                ("gru_bw_bc", C.c_void_p), ("q_att_key", Fc), ("q_att_query", Fc), ("word_score", Fc), ("v_word_fc", Fc)]
+                ("gru_bw_bc", C.c_void_p), ("q_att_key", Fc), ("q_att_query", Fc), ("word_score", Fc), ("v_word_fc", Fc),
+                ("glove_fixed", C.c_void_p), ("glove_learn", C.c_void_p), ("lstm_k", C.c_void_p), ("lstm_b", C.c_void_p),
+                ("l2v", Fc * 3), ("v2l", Fc * 3), ("answer_layer1", Fc), ("pooled_layer1", Fc), ("q_layer1", Fc),
+                ("classifier", Fc)]
 
 
 class Batch(C.Structure):
@@ -50,7 +54,7 @@ class Batch(C.Structure):
                 ("train_mask", C.c_void_p), ("obj_mask", C.c_void_p), ("attr_mask", C.c_void_p),
                 ("exist_mask", C.c_void_p), ("keep_att", C.c_void_p), ("keep_joint", C.c_void_p),
                 ("keep_joint2", C.c_void_p), ("live_rows", C.c_void_p), ("noise", C.c_void_p), ("keep_tile", C.c_void_p),
-                ("keep_word", C.c_void_p)]
+                ("keep_word", C.c_void_p), ("answer_intseq", C.c_void_p), ("answer_intseq_len", C.c_void_p)]
 
 
 class PtDims(C.Structure):
@@ -155,6 +159,15 @@ SIGNATURES = {
     "vqa_clip_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "vqa_dropout_mask": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
     "vqa_clip_adam_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _F, _F, _F, _P]),
+    "vqa_embed2_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_embed2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_lstm_step_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "vqa_lstm_step_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "vqa_relu_fwd": (_I, [_P, _P, _L, _P]),
+    "vqa_relu_bwd": (_I, [_P, _P, _P, _L, _P]),
+    "vqa_fill": (_I, [_P, _L, _F, _P]),
+    "vqa_score_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "vqa_score_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_reverse_tokens": (_I, [_P, _P, _P, _I, _I, _P]),
     "vqa_bi_outputs_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_bi_outputs_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -41,6 +41,8 @@ struct Layout {
 
 int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 
+void legacy_vqa_layout(Layout& L, const vqa_dims_t& d, int64_t& gw);      // csrc/legacy_vqa.inc (model_type 13)
+
 Layout make_layout(const vqa_dims_t& d) {
     Layout L;
     const int64_t B = d.B, R = d.R, D = d.D, H = d.H, T = d.T, W = d.W, A = d.A;
@@ -160,6 +162,7 @@ Layout make_layout(const vqa_dims_t& d) {
         const int64_t M = d.num_marginal, C = d.ent_cols;
         g(0, 0, B * M, 2 * H, H); g(0, 0, B * M, C, 2 * H); g(0, 1, B * M, 2 * H, C); g(0, 1, B * M, H, 2 * H);
     }
+    if (d.model_type == VQA_MODEL_LEGACY_VQA) legacy_vqa_layout(L, d, gw);
     L.add("gemm_ws", max64(gw, 4));
     L.add("gemm_ws1", max64(gw, 4));            // scratch of the side stream (v_linear_v branch)
     int64_t cw = 0;
@@ -168,6 +171,8 @@ Layout make_layout(const vqa_dims_t& d) {
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)A));
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)W));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(B * T), (int)H));
+    if (d.model_type == VQA_MODEL_LEGACY_VQA)
+        cw = max64(cw, max64(vqa_colsum_workspace_floats((int)(T * B), (int)(4 * H)), vqa_colsum_workspace_floats((int)(d.La * A), (int)(4 * H))));
     L.add("colsum_ws", max64(3 * cw, 4));    // x3: vqa_colsum3 reduces three partial matrices per launch
     L.add("colsum_ws1", max64(3 * cw, 4));
     L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
@@ -349,8 +354,10 @@ int colsum(const Ctx& c, const float* X, int64_t M, int64_t N, int ldx, float* o
 
 bool dims_ok(const vqa_dims_t* d) {
     if (!(d && d->B > 0 && d->R > 0 && d->D > 0 && d->H > 0 && d->T > 0 && d->W > 0 && d->A > 0 && d->Vq > 0 &&
-          d->N_img > 0 && d->model_type >= 0 && d->model_type <= VQA_MODEL_BI))
+          d->N_img > 0 && d->model_type >= 0 && d->model_type <= VQA_MODEL_LEGACY_VQA))
         return false;
+    if (d->model_type == VQA_MODEL_LEGACY_VQA)      // 16-byte rows everywhere; the scoring kernel keeps one H-row in LDS
+        return d->map_dim > 0 && d->La > 0 && d->H % 4 == 0 && d->D % 4 == 0 && d->map_dim % 4 == 0 && d->W % 4 == 0 && d->H <= 1024 && d->Vq > 3;
     if (d->model_type == VQA_MODEL_BI) return d->H % 8 == 0;      // two cells of H / 2 units, 16-byte rows each
     if (d->model_type == VQA_MODEL_ENT)       // the pairings' tensors are addressed with 32-bit element counts
         return d->num_marginal > 0 && d->ent_cols > 0 && d->ent_cols <= d->A && d->ent_cols <= 4096 &&
@@ -400,6 +407,8 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
     }
     return VQA_OK;
 }
+
+#include "legacy_vqa.inc"
 
 // ---- model_type 12: bi-directional question encoder + question self-attention (vqa/model_vlmap_finetune.py:119-150) ----
 struct BiGru { const float *wg, *bg, *wc, *bc; };
@@ -558,6 +567,15 @@ extern "C" int vqa_fusion_tensor(const vqa_dims_t* dims, const char* name, int64
     const char* key = name;
     if (strcmp(name, "condition") == 0 && dims->model_type == VQA_MODEL_ANSWER2) key = "q_L_ft2";   // model_vlmap_answer2.py:131
     else if (strcmp(name, "condition") == 0 && dims->model_type == VQA_MODEL_BI) key = "q_L_ft";  // concat of the two final states
+    else if (dims->model_type == VQA_MODEL_LEGACY_VQA && (strcmp(name, "q_L_ft") == 0 || strcmp(name, "answer_ft") == 0)) {
+        // final LSTM states: the last [N,H] block of the time-major state tapes
+        const bool q = name[0] == 'q';
+        const Entry* hsn = L.find(q ? "lv_hsq" : "lv_hsa");
+        const int64_t N = q ? dims->B : dims->A, Tn = q ? dims->T : dims->La;
+        if (offset_bytes) *offset_bytes = hsn->off + Tn * N * dims->H * 4;
+        if (n_elems) *n_elems = N * dims->H;
+        return VQA_OK;
+    }
     else if (strcmp(name, "condition") == 0) {  // heavy_output['condition'] = final GRU state = hs[T]
         const Entry* h = L.find("hs");
         if (offset_bytes) *offset_bytes = h->off + (int64_t)dims->T * dims->B * dims->H * 4;
@@ -593,6 +611,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
     VQA_REQUIRE(vqa_aligned16(workspace), VQA_ERR_ALIGN);
     ProbeScope ps_all("forward", c.st);
+    if (dims->model_type == VQA_MODEL_LEGACY_VQA) return legacy_vqa_forward(c, P, bt, want_dz);
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
 
     // visual branch (a1 + a2) on the side stream (VQA_HOT_OVERLAP=1 only), question branch (a3-a5) on the caller's
@@ -821,6 +840,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     Ctx c{*dims, L, static_cast<char*>(workspace), static_cast<hipStream_t>(stream), 0};
     VQA_REQUIRE(workspace_bytes >= c.L.total, VQA_ERR_WORKSPACE);
     ProbeScope ps_all("backward", c.st);
+    if (dims->model_type == VQA_MODEL_LEGACY_VQA) return (phases & 1) ? legacy_vqa_backward(c, P, G, bt, embed_slice_sq) : VQA_OK;
     const int64_t B = dims->B, R = dims->R, D = dims->D, H = dims->H, T = dims->T, W = dims->W, A = dims->A;
     const int64_t Wp = ((W + 1 + 3) / 4) * 4;      // row stride of x_tm (make_layout)
     const float* hs = c.f("hs");

@@ -55,6 +55,10 @@ FROZEN_TOP_SCOPES_ONLY = ("V_WordMap", "v_word_fc", "q_linear_v", "v_linear_v", 
                           "pooled_linear_l", "joint_fc", "WordWeightAnswer")                     # model_vlmap_only.py:64-76
 TRANSFER_TOP_SCOPES_BI = ("v_word_fc", "q_linear_v", "v_linear_v", "hadamard_attention", "q_linear_l", "pooled_linear_l",
                           "joint_fc")                                                            # model_vlmap_finetune.py:70-87
+# the registry's oldest model and the default of vqa/trainer.py: vqa/model_vqa.py (LSTM over questions and answers, L2V / V2L,
+# dot-product attention over model_vfeat's 512-d features, a broadcast tanh scoring layer)
+LEGACY_FAMILY = ("vqa",)
+LSTM_SCOPE = "encode_L/rnn/basic_lstm_cell"
 NUM_MARGINAL = 200            # vqa/model_vlmap_answer_ent.py:16
 W_ENTROPY = 0.1               # vqa/model_vlmap_answer_ent.py:14
 LATENT_LOSS_WEIGHT = 0.1      # vqa/model_vlmap_answer_full.py:33
@@ -69,6 +73,8 @@ def scope_names(model_type):
                 "q_linear_v": "q_linear_v", "score": "hadamard_attention/compute/score",
                 "pooled_linear_l": "pooled_linear_l", "q_linear_l": "q_linear_l",
                 "joint_fc": "joint_v", "joint2": "joint_l", "head": "WordWeightAnswerV", "head2": "WordWeightAnswerL"}
+    if model_type in LEGACY_FAMILY:
+        return {"embed": "GloVe/learn"}
     if model_type in BI_FAMILY:
         g = "encode_L_bi/bidirectional_rnn/%s/gru_cell/%s"
         return {"embed": "LearnGloVe/embed_map", "embed2": "V_WordMap/embed_map", "v_linear_v": "v_linear_v",
@@ -95,9 +101,20 @@ def scope_names(model_type):
             "q_L_ft2": "q_L_ft2", "q_L_mean": "q_L_mean", "q_L_log_sigma_sq": "q_L_log_sigma_sq", "v_adapt": "v_adapt"}
 
 
-def variable_shapes(model_type, Vq, W, D, H, A):
+def variable_shapes(model_type, Vq, W, D, H, A, map_dim=None):
     """name -> shape for every variable of the model."""
     sc = scope_names(model_type)
+    if model_type in LEGACY_FAMILY:      # vqa/model_vqa.py: H = L_DIM, D = V_DIM = vfeat_dim, map_dim = MAP_DIM (:10-13)
+        M = int(map_dim or H)
+        s = {"GloVe/learn": (3, W), LSTM_SCOPE + "/kernel": (W + H, 4 * H), LSTM_SCOPE + "/bias": (4 * H,)}
+        for scope, fin, fout, bias in (("L2V/fc_1", H, M, True), ("L2V/fc_2", M, M, True), ("L2V/Linear", M, D, True),
+                                       ("V2L/fc_1", D, M, True), ("V2L/fc_2", M, M, True), ("V2L/Linear", M, H, True),
+                                       ("reasoning/answer_layer1", H, H, False), ("reasoning/pooled_layer1", H, H, False),
+                                       ("reasoning/q_layer1", H, H, True), ("reasoning/classifier", H, 1, True)):
+            s[scope + "/fc/weights"] = (fin, fout)
+            if bias:
+                s[scope + "/fc/biases"] = (fout,)
+        return s
     s = {sc["embed"]: (Vq, W)}
 
     def fc(scope, fin, fout, ln):
@@ -157,8 +174,10 @@ def variable_shapes(model_type, Vq, W, D, H, A):
     return s
 
 
-def filter_train_vars(names, model_type):
-    """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names."""
+def filter_train_vars(names, model_type, ft_vlmap=False):
+    """vqa/model_vlmap_answer.py:81-89 / vqa/model_standard.py:80-84 on variable names (ft_vlmap: vqa/model_vqa.py:63-74)."""
+    if model_type in LEGACY_FAMILY:
+        return [n for n in names if ft_vlmap or n.split("/")[0] not in ("V2L", "L2V")]
     if model_type in STANDARD_FAMILY or model_type == "vlmap_finetune":      # model_vlmap_finetune.py:64-68: everything
         return list(names)
     if model_type == "vlmap_only":
@@ -173,6 +192,8 @@ def filter_transfer_vars(names, model_type):
         return [n for n in names if n.split("/")[0] in ("encode_L", "GloVe")]
     if model_type in BI_FAMILY:
         return [n for n in names if n.split("/")[0] in TRANSFER_TOP_SCOPES_BI]
+    if model_type in LEGACY_FAMILY:                                   # vqa/model_vqa.py:76-88
+        return [n for n in names if n.split("/")[0] in ("V2L", "L2V", "encode_L", "GloVe")]
     keep = TRANSFER_TOP_SCOPES_NOC if model_type in NOC_FAMILY else TRANSFER_TOP_SCOPES_VLMAP
     return [n for n in names if n.split("/")[0] in keep]
 
@@ -181,7 +202,7 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def flat_layout(model_type, shapes):
+def flat_layout(model_type, shapes, ft_vlmap=False):
     """Where every variable sits in the flat buffers (pure host arithmetic, no GPU): train_flat / grad_flat order =
     the order backward completes the gradients (vqa_fusion_backward_phases):
     [embedding | GRU candidate/* | GRU gates/* | everything else by name] (+ 4 tail floats in grad_flat), every
@@ -189,7 +210,7 @@ def flat_layout(model_type, shapes):
     bucketed reducer, in the order it starts them."""
     sc = scope_names(model_type)
     names = sorted(shapes)
-    train = filter_train_vars(names, model_type)
+    train = filter_train_vars(names, model_type, ft_vlmap)
     # scatter-added tables first (the bi-directional models have a second one, V_WordMap, trainable in vlmap_finetune):
     # they are zeroed before every backward and their norm is taken over the un-aggregated slices (tail slot)
     embeds = [sc["embed"]] + ([sc["embed2"]] if sc.get("embed2") in train else [])
@@ -227,18 +248,22 @@ class FusionEngine:
     MODEL_TYPE_ID = {"vlmap_answer": 0, "standard": 1, "standard_word2vec": 2, "standard_testmask": 3,
                      "vlmap_answer_vqa_all2": 4, "vlmap_answer_noc": 5, "vlmap_answer_nocarch": 5, "vlmap_answer_vqa_all": 6,
                      "vlmap_answer2": 7, "vlmap_answer_no_noise": 8, "vlmap_answer_adapt": 9, "vlmap_answer_full": 10,
-                     "vlmap_answer_ent": 11, "vlmap_finetune": 12, "vlmap_only": 12}
+                     "vlmap_answer_ent": 11, "vlmap_finetune": 12, "vlmap_only": 12, "vqa": 13}
 
     def __init__(self, *, model_type, B, R, D, H, T, W, A, Vq, N_img, params, device="cuda:0",
                  keep_att=0.8, keep_joint=0.5, global_batch=None, deterministic=None, answer_glove=None,
-                 fused_gather=False, num_marginal=NUM_MARGINAL, ent_cols=None):
+                 fused_gather=False, num_marginal=NUM_MARGINAL, ent_cols=None, map_dim=None, ft_vlmap=False,
+                 glove_fixed=None, answers=None):
         """deterministic=True: run-to-run bitwise reproducible steps (the embedding-gradient scatter-add switches
         from float atomics to an atomic-free kernel, ~30 us slower at bs 512).  Per engine: the choice travels in
         vqa_dims_t.flags with every call, no process-wide library state is touched.
         fused_gather=True: no feature-gather pass; v_linear_v's GEMM reads the table rows through image_idx
         (vqa_gemm_f32_gather).  Same step time as the default at bs 512, 151 MB less HBM traffic.
         num_marginal / ent_cols (vlmap_answer_ent): pairings per question, and how many leading head columns the
-        regulariser computes (None: from the answer masks at bind_inputs -- 1 + the last known training answer)."""
+        regulariser computes (None: from the answer masks at bind_inputs -- 1 + the last known training answer).
+        map_dim / ft_vlmap / glove_fixed / answers (model_type 'vqa', vqa/model_vqa.py): MAP_DIM of L2V / V2L; whether those
+        two train (config.ft_vlmap); the constant GloVe rows [Vq-3, W] of modules.GloVe_vocab; the candidate answers' token
+        sequences {'intseq': i32 [A, La], 'len': i32 [A]} (data_info.hdf5)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.VqaHotError("FusionEngine needs a GPU (no CPU fallback)")
@@ -255,8 +280,18 @@ class FusionEngine:
                               ent_cols=int(ent_cols or A) if model_type == "vlmap_answer_ent" else 0,
                               extra_weight={"vlmap_answer_ent": W_ENTROPY, "vlmap_answer_full": LATENT_LOSS_WEIGHT}.get(model_type, 0.0))
         self._ent_cols_given = ent_cols is not None
-        self.shapes = variable_shapes(model_type, Vq, W, D, H, A)
-        lay = flat_layout(model_type, self.shapes)
+        self.glove_fixed, self._answers = None, None
+        if model_type in LEGACY_FAMILY:
+            if glove_fixed is None or answers is None:
+                raise ValueError("model_type 'vqa' needs glove_fixed [Vq-3, W] and answers {'intseq' [A, La], 'len' [A]}")
+            to_t = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(device=self.device, dtype=dt).contiguous()
+            self.glove_fixed = to_t(glove_fixed, torch.float32)
+            self._answers = (to_t(answers["intseq"], torch.int32), to_t(answers["len"], torch.int32))
+            if tuple(self.glove_fixed.shape) != (Vq - 3, W) or self._answers[0].shape[0] != A or self._answers[1].numel() != A:
+                raise ValueError("glove_fixed must be [Vq-3, W], answers['intseq'] [A, La], answers['len'] [A]")
+            self.dims.map_dim, self.dims.La = int(map_dim or H), int(self._answers[0].shape[1])
+        self.shapes = variable_shapes(model_type, Vq, W, D, H, A, map_dim=map_dim)
+        lay = flat_layout(model_type, self.shapes, ft_vlmap=ft_vlmap)
         self.train_names, self.frozen_names = lay["train_names"], lay["frozen_names"]
         self._train_tab, self.n_train = lay["train_tab"], lay["n_train"]
         self._frozen_tab, self.n_frozen = lay["frozen_tab"], lay["n_frozen"]
@@ -349,6 +384,16 @@ class FusionEngine:
                            beta=ptr(scope + "/LayerNorm/beta") if ln else None,
                            gamma=ptr(scope + "/LayerNorm/gamma") if ln else None)
 
+        if self.model_type in LEGACY_FAMILY:
+            def plain(scope):
+                return _lib.Fc(w=ptr(scope + "/fc/weights"), b=ptr(scope + "/fc/biases") if scope + "/fc/biases" in self.shapes else None)
+            return _lib.Params(
+                glove_fixed=self.glove_fixed.data_ptr() if all_required else None, glove_learn=ptr("GloVe/learn"),
+                lstm_k=ptr(LSTM_SCOPE + "/kernel"), lstm_b=ptr(LSTM_SCOPE + "/bias"),
+                l2v=(_lib.Fc * 3)(plain("L2V/fc_1"), plain("L2V/fc_2"), plain("L2V/Linear")),
+                v2l=(_lib.Fc * 3)(plain("V2L/fc_1"), plain("V2L/fc_2"), plain("V2L/Linear")),
+                answer_layer1=plain("reasoning/answer_layer1"), pooled_layer1=plain("reasoning/pooled_layer1"),
+                q_layer1=plain("reasoning/q_layer1"), classifier=plain("reasoning/classifier"))
         return _lib.Params(
             embed=ptr(sc["embed"]), v_linear_v=fc(sc["v_linear_v"], True),
             gru_wg=ptr(sc["gru_gates"] + "/kernel"), gru_bg=ptr(sc["gru_gates"] + "/bias"),
@@ -471,7 +516,9 @@ class FusionEngine:
             live_rows=live.ctypes.data if live is not None else None,
             noise=noise.data_ptr() if noise is not None else None,
             keep_tile=keep_tile.data_ptr() if keep_tile is not None else None,
-            keep_word=keep_word.data_ptr() if keep_word is not None else None)
+            keep_word=keep_word.data_ptr() if keep_word is not None else None,
+            answer_intseq=self._answers[0].data_ptr() if self._answers is not None else None,
+            answer_intseq_len=self._answers[1].data_ptr() if self._answers is not None else None)
 
     def forward(self, batch, keep_att=None, keep_joint=None, want_dz=True, keep_joint2=None, noise=None, keep_tile=None,
                 keep_word=None):

@@ -2,15 +2,14 @@
 
 The two models on the hot path and the variants of section 8f-4 -- standard_word2vec,
 standard_testmask, vlmap_answer_vqa_all, vlmap_answer_vqa_all2, vlmap_answer_noc = vlmap_answer_nocarch and the five older
-ablations vlmap_answer2 / _no_noise / _adapt / _full / _ent, and the two bi-directional-GRU models vlmap_finetune /
-vlmap_only -- are built natively (15 of the 16 entries of vqa/importer.py:1-14); the oldest model, `vqa` (an LSTM encoder
-over 512-d features of the retired model_vfeat pipeline scoring every answer's own LSTM code, vqa/model_vqa.py), is listed
-so that a request for it fails with a precise message instead of an import error."""
+ablations vlmap_answer2 / _no_noise / _adapt / _full / _ent, the two bi-directional-GRU models vlmap_finetune / vlmap_only
+and the oldest model `vqa` (an LSTM encoder over the 512-d features of the model_vfeat pipeline that scores every
+answer's own LSTM code) -- are built natively: all 16 entries of vqa/importer.py:1-14."""
 
 _NATIVE = ("standard", "standard_testmask", "standard_word2vec", "vlmap_answer", "vlmap_answer_noc", "vlmap_answer_nocarch",
            "vlmap_answer_vqa_all", "vlmap_answer_vqa_all2", "vlmap_answer2", "vlmap_answer_adapt", "vlmap_answer_ent",
-           "vlmap_answer_full", "vlmap_answer_no_noise", "vlmap_finetune", "vlmap_only")
-_REFERENCE_ONLY = ("vqa",)
+           "vlmap_answer_full", "vlmap_answer_no_noise", "vlmap_finetune", "vlmap_only", "vqa")
+_REFERENCE_ONLY = ()
 
 
 def get_model_types():
@@ -44,6 +43,8 @@ def get_model_class(model_type="vlmap_answer"):
         from .model_vlmap_answer_full import Model
     elif model_type == "vlmap_answer_no_noise":
         from .model_vlmap_answer_no_noise import Model
+    elif model_type == "vqa":
+        from .model_vqa import Model
     elif model_type == "vlmap_finetune":
         from .model_vlmap_finetune import Model
     elif model_type == "vlmap_only":
