@@ -143,6 +143,20 @@ int vqa_ln_act_fwd(const float* pre, const float* gamma, const float* beta, cons
 int vqa_ln_act_bwd(const float* dy, const float* pre, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const uint8_t* keepmask, float keep_prob, float* dpre, float* part_dgamma,
                    float* part_dbeta, float* part_dbias, int G, int rows, int N, int act, void* stream);
+/* pooled_linear_l and q_linear_l meet in a product (joint_fc's input, vqa/model_vlmap_answer.py:163-177): ONE launch does
+ * LayerNorm + ReLU of both [G,N] pre-activations (one row per group) and z = y_a * y_b; the backward takes dz (+ add_b, an
+ * optional extra gradient wrt y_b, or NULL) to both pre-activations and, when asked, the per-row partials of
+ * d(gamma), d(beta), d(bias) [G,N] (both or neither of dgamma / dbeta per tensor).  N % 4 == 0, N <= 4096, 16-byte
+ * aligned pointers (vqa_ln_pair_mul_supported). */
+int vqa_ln_pair_mul_supported(int N, const void* const* ptrs, int n_ptrs);
+int vqa_ln_pair_mul_fwd(const float* pre_a, const float* pre_b, const float* gamma_a, const float* beta_a, const float* gamma_b,
+                        const float* beta_b, float* y_a, float* y_b, float* z, float* mean_a, float* rstd_a, float* mean_b,
+                        float* rstd_b, int G, int N, void* stream);
+int vqa_ln_pair_mul_bwd(const float* dz, const float* add_b, const float* pre_a, const float* pre_b, const float* mean_a,
+                        const float* rstd_a, const float* mean_b, const float* rstd_b, const float* gamma_a, const float* beta_a,
+                        const float* gamma_b, const float* beta_b, float* dpre_a, float* dpre_b, float* part_dgamma_a,
+                        float* part_dbeta_a, float* part_dbias_a, float* part_dgamma_b, float* part_dbeta_b, float* part_dbias_b,
+                        int G, int N, void* stream);
 /* y = tanh(x) ; dx = dy * (1 - y^2)   (tanh of the word-set embedding, same file :373-375) */
 int vqa_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 int vqa_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);

@@ -488,12 +488,13 @@ def test_fused_feature_gather_equals_gather_pass(cfg):
 def test_tuning_switches_of_the_step_keep_parity():
     """The A/B switches of the fused step are read once per process: the two-GEMM form of the x-projection
     (VQA_HOT_XCAT=0: per-kernel GEMMs + column sums for the GRU bias gradients) and the round-1 forward order
-    (VQA_HOT_VISUAL_LATE=0) must reproduce the golden vectors (forward, report, every gradient) like the shipped path."""
+    (VQA_HOT_VISUAL_LATE=0), the three-launch form of pooled_linear_l x l_linear_l (VQA_HOT_LN_PAIR=0) and the second packing of
+    the x rows in backward (VQA_HOT_REPACK=1) must reproduce the golden vectors (forward, report, every gradient) like the shipped path."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VQA_HOT_XCAT="0", VQA_HOT_VISUAL_LATE="0")
+    env = dict(os.environ, VQA_HOT_XCAT="0", VQA_HOT_VISUAL_LATE="0", VQA_HOT_LN_PAIR="0", VQA_HOT_REPACK="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_golden.py", "-m", "gpu", "-q", "-x", "-k",
                         "test_hip_matches_fusion_golden", "-p", "no:cacheprovider"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)

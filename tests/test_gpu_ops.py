@@ -813,3 +813,55 @@ def test_register_streamed_gru_step_kernels_equal_the_lds_tiled_ones(T, B):
     for name, a, b in zip(("hs", "r", "u", "c", "rh", "dxp"), outs[0], outs[1]):
         assert not torch.isnan(b).any(), name
         torch.testing.assert_close(b, a, rtol=2e-5, atol=5e-6, msg=lambda m: name + ": " + m)
+
+
+@pytest.mark.parametrize("G,N", [(7, 1024), (3, 2048), (5, 1000), (4, 16), (2, 4096), (6, 2052)])
+@pytest.mark.parametrize("params,extra", [(True, True), (False, False), (True, False)])
+def test_ln_pair_mul_fwd_bwd(G, N, params, extra):
+    """vqa_ln_pair_mul_*: LayerNorm + ReLU of two pre-activations and their product in one launch (pooled_linear_l x
+    l_linear_l, vqa/model_vlmap_answer.py:163-177), and its backward with an optional extra gradient on the second output"""
+    import ctypes as C
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(G * 7 + N)
+    a, b = rng.standard_normal((G, N)) * 2 + 0.3, rng.standard_normal((G, N)) * 0.5 - 0.1
+    ga, ba = 1 + 0.2 * rng.standard_normal(N), 0.2 * rng.standard_normal(N)
+    gb, bb = 1 + 0.2 * rng.standard_normal(N), 0.2 * rng.standard_normal(N)
+    lna, xa, ra = O.layer_norm_forward(a, ga, ba)
+    lnb, xb, rb = O.layer_norm_forward(b, gb, bb)
+    ya, yb = np.maximum(lna, 0), np.maximum(lnb, 0)
+    f = lambda x: dev(np.ascontiguousarray(x, np.float32))
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    d = {k: f(v) for k, v in dict(a=a, b=b, ga=ga, ba=ba, gb=gb, bb=bb).items()}
+    out = {k: torch.empty(G, N, device="cuda") for k in ("ya", "yb", "z", "da", "db", "pga", "pba", "pca", "pgb", "pbb", "pcb")}
+    st = {k: torch.empty(G, device="cuda") for k in ("ma", "ra", "mb", "rb")}
+    _lib.check(lib.vqa_ln_pair_mul_fwd(P(d["a"]), P(d["b"]), P(d["ga"]), P(d["ba"]), P(d["gb"]), P(d["bb"]), P(out["ya"]), P(out["yb"]),
+                                       P(out["z"]), P(st["ma"]), P(st["ra"]), P(st["mb"]), P(st["rb"]), G, N, None), "pair fwd")
+    torch.cuda.synchronize()
+    close(out["ya"], ya, 1e-4, 2e-5); close(out["yb"], yb, 1e-4, 2e-5); close(out["z"], ya * yb, 1e-4, 5e-5)
+    close(st["ra"], ra.reshape(G), 1e-5, 0); close(st["mb"], b.mean(1), 1e-5, 1e-6)
+    dz = rng.standard_normal((G, N))
+    add = rng.standard_normal((G, N)) if extra else None
+    dya, dyb = dz * yb, dz * ya + (add if extra else 0)
+
+    def ln_bwd(dy, ln, xh, rs, gam):
+        dln = dy * (ln > 0)
+        dxh = dln * gam
+        return rs * (dxh - dxh.mean(1, keepdims=True) - xh * (dxh * xh).mean(1, keepdims=True)), dln * xh, dln
+    da64, pga64, pba64 = ln_bwd(dya, lna, xa, ra, ga)
+    db64, pgb64, pbb64 = ln_bwd(dyb, lnb, xb, rb, gb)
+    pp = lambda k: P(out[k]) if params else None
+    _lib.check(lib.vqa_ln_pair_mul_bwd(P(f(dz)), P(f(add)) if extra else None, P(d["a"]), P(d["b"]), P(st["ma"]), P(st["ra"]), P(st["mb"]),
+                                       P(st["rb"]), P(d["ga"]), P(d["ba"]), P(d["gb"]), P(d["bb"]), P(out["da"]), P(out["db"]),
+                                       pp("pga"), pp("pba"), pp("pca"), pp("pgb"), pp("pbb"), pp("pcb"), G, N, None), "pair bwd")
+    torch.cuda.synchronize()
+    for got, want in ((out["da"], da64), (out["db"], db64)):
+        close(got, want, 1e-3, 2e-4 * np.abs(want).max())
+    if params:
+        close(out["pga"], pga64, 1e-3, 1e-4 * max(1, np.abs(pga64).max())); close(out["pba"], pba64, 1e-3, 1e-5)
+        close(out["pgb"], pgb64, 1e-3, 1e-4 * max(1, np.abs(pgb64).max())); close(out["pbb"], pbb64, 1e-3, 1e-5)
+        assert torch.equal(out["pca"], out["da"]) and torch.equal(out["pcb"], out["db"])          # d(bias) partial = d(pre)
+    # unsupported shapes are refused, not mis-computed
+    assert lib.vqa_ln_pair_mul_fwd(P(d["a"]), P(d["b"]), P(d["ga"]), P(d["ba"]), P(d["gb"]), P(d["bb"]), P(out["ya"]), P(out["yb"]),
+                                   P(out["z"]), P(st["ma"]), P(st["ra"]), P(st["mb"]), P(st["rb"]), 1, 4100, None) == -2
+    assert lib.vqa_ln_pair_mul_supported(1022, None, 0) == 0 and lib.vqa_ln_pair_mul_supported(1024, None, 0) == 1

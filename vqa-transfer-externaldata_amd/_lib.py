@@ -127,6 +127,9 @@ SIGNATURES = {
     "vqa_ln_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vqa_ln_act_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vqa_ln_act_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vqa_ln_pair_mul_supported": (_I, [_I, _P, _I]),
+    "vqa_ln_pair_mul_fwd": (_I, [_P] * 13 + [_I, _I, _P]),
+    "vqa_ln_pair_mul_bwd": (_I, [_P] * 20 + [_I, _I, _P]),
     "vqa_tanh_fwd": (_I, [_P, _P, _L, _P]),
     "vqa_tanh_bwd": (_I, [_P, _P, _P, _L, _P]),
     "vqa_softmax_ce_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),

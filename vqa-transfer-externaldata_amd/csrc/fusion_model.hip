@@ -380,6 +380,27 @@ int fc_ln_relu_fwd(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N
                            rows, (int)N, c.st);
 }
 
+// the FC half of the backward once d_pre is known: parameter gradients from the per-group partials (g.w == NULL => frozen
+// layer) and the optional dx = d_pre * W^T (+ dx)
+int fc_bwd_tail(const Ctx& c, const float* x, int64_t M, int64_t K, int64_t N, const vqa_fc_t& p, const vqa_fc_t* g, int rows,
+                const float* d_pre, const float* pa, const float* pb, const float* pc, float* dx, bool dx_accumulate) {
+    const bool train = g != nullptr && g->w != nullptr;
+    const int64_t G = M / rows;
+    if (train) {
+        {
+            ProbeScope ps(rows > 1 ? "v_linear_v.ln_bwd" : "fc.ln_bwd", c.st);
+            TRY(vqa_colsum3(pa, pb, pc, (int)G, (int)N, (int)N, g->gamma, g->beta, g->b, c.colsum_ws(), c.colsum_ws_floats(), c.st));
+        }
+        ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
+        TRY(gemm(c, 1, 0, K, N, M, x, (int)K, d_pre, (int)N, g->w, (int)N));  // dW = x^T * d_pre
+    }
+    if (dx != nullptr) {
+        ProbeScope ps("fc.dx_gemm", c.st);
+        TRY(gemm(c, 0, 1, M, K, N, d_pre, (int)N, p.w, (int)N, dx, (int)K, nullptr, dx_accumulate ? dx : nullptr, (int)K));
+    }
+    return VQA_OK;
+}
+
 // backward of the same block.  dy -> d_pre (named buffer); optional parameter
 // grads (g.w == NULL => frozen layer); optional dx = d_pre * W^T (+ dx_add).
 int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int64_t K, int64_t N, const vqa_fc_t& p,
@@ -392,20 +413,20 @@ int fc_ln_relu_bwd(const Ctx& c, const float* dy, const float* x, int64_t M, int
         TRY(vqa_ln_relu_bwd(dy, c.f(pre), c.f(mean), c.f(rstd), p.gamma, p.beta, keep, keep_prob, c.f(d_pre),
                             train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
                             train ? c.part(2) : nullptr, (int)G, rows, (int)N, c.st));
-        if (train)
-            TRY(vqa_colsum3(c.part(0), c.part(1), c.part(2), (int)G, (int)N, (int)N, g->gamma, g->beta, g->b,
-                            c.colsum_ws(), c.colsum_ws_floats(), c.st));
     }
-    if (train) {
-        ProbeScope ps(rows > 1 ? "v_linear_v.dw_gemm" : "fc.dw_gemm", c.st);
-        TRY(gemm(c, 1, 0, K, N, M, x, (int)K, c.f(d_pre), (int)N, g->w, (int)N));  // dW = x^T * d_pre
-    }
-    if (dx != nullptr) {
-        ProbeScope ps("fc.dx_gemm", c.st);
-        TRY(gemm(c, 0, 1, M, K, N, c.f(d_pre), (int)N, p.w, (int)N, dx, (int)K, nullptr,
-                 dx_accumulate ? dx : nullptr, (int)K));
-    }
-    return VQA_OK;
+    return fc_bwd_tail(c, x, M, K, N, p, g, rows, c.f(d_pre), c.part(0), c.part(1), c.part(2), dx, dx_accumulate);
+}
+
+// pooled_linear_l and q_linear_l finish in one launch that also forms their product (vqa_ln_pair_mul_*): two LayerNorm
+// launches and the element-wise one less per direction.  VQA_HOT_LN_PAIR=0 restores the three-launch form (A/B).
+inline bool ln_pair_enabled() {
+    static const bool v = [] { const char* e = getenv("VQA_HOT_LN_PAIR"); return e == nullptr || atoi(e) != 0; }();
+    return v;
+}
+bool ln_pair_ok(const vqa_dims_t& d, const vqa_params_t* P) {
+    if (!ln_pair_enabled() || d.model_type == 5) return false;       // vlmap_answer_noc has no product
+    const void* ptrs[4] = {P->pooled_linear_l.gamma, P->pooled_linear_l.beta, P->q_linear_l.gamma, P->q_linear_l.beta};
+    return vqa_ln_pair_mul_supported(d.H, ptrs, 4) != 0;
 }
 
 #include "legacy_vqa.inc"
@@ -739,9 +760,23 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
                           c.f("pooled_V_ft"), (int)B, (int)R, (int)H, (int)Dp, c.st));
     }
     // a8
+    const bool pair = ln_pair_ok(*dims, P);
+    if (pair) {
+        {
+            ProbeScope ps("fc.fwd_gemm", c.st);
+            TRY(gemm(c, 0, 0, B, H, Dp, c.f("pooled_V_ft"), (int)Dp, P->pooled_linear_l.w, (int)H, c.f("pre_pl"), (int)H,
+                     P->pooled_linear_l.b));
+            TRY(gemm(c, 0, 0, B, H, H, lin_in, (int)H, P->q_linear_l.w, (int)H, c.f("pre_ll"), (int)H, P->q_linear_l.b));
+        }
+        ProbeScope ps("fc.ln_fwd", c.st);
+        TRY(vqa_ln_pair_mul_fwd(c.f("pre_pl"), c.f("pre_ll"), P->pooled_linear_l.gamma, P->pooled_linear_l.beta, P->q_linear_l.gamma,
+                                P->q_linear_l.beta, c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), c.f("mean_pl"),
+                                c.f("rstd_pl"), c.f("mean_ll"), c.f("rstd_ll"), (int)B, (int)H, c.st));
+    } else {
     TRY(fc_ln_relu_fwd(c, c.f("pooled_V_ft"), B, Dp, H, P->pooled_linear_l, 1, "pre_pl", "pooled_linear_l", "mean_pl",
                        "rstd_pl", nullptr, 1.f));
     TRY(fc_ln_relu_fwd(c, lin_in, B, H, H, P->q_linear_l, 1, "pre_ll", "l_linear_l", "mean_ll", "rstd_ll", nullptr, 1.f));
+    }
     // a9
     if (dims->model_type == 5) {
         // vlmap_answer_noc (vqa/model_vlmap_answer_noc.py:177-188): no composition -- joint_v on pooled_linear_l and joint_l
@@ -752,7 +787,7 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         TRY(fc_ln_relu_fwd(c, c.f("l_linear_l"), B, H, 2 * H, P->joint2, 1, "pre_jl", "l_joint", "mean_jl", "rstd_jl",
                            bt->keep_joint2, dims->keep_joint));
     } else {
-    {
+    if (!pair) {
         ProbeScope ps("eltwise", c.st);
         TRY(vqa_mul(c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("joint_in"), B * H, c.st));
     }
@@ -849,6 +884,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     float* dxp = c.f("dxp");
     const int mt = dims->model_type;
     const int64_t Dp = pooled_dim(*dims);
+    const bool pair = ln_pair_ok(*dims, P);
 
     if (phases & 1) {
     {
@@ -897,7 +933,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     // joint_fc (dropout mask folded into the LN/ReLU backward)
     TRY(fc_ln_relu_bwd(c, c.f("d_joint"), c.f("joint_in"), B, H, 2 * H, P->joint_fc, &G->joint_fc, 1, "pre_j", "mean_j",
                        "rstd_j", bt->keep_joint, dims->keep_joint, "d_pre_j", c.f("d_joint_in"), false));
-    {
+    if (!pair) {
         ProbeScope ps("eltwise", c.st);
         TRY(vqa_mul_bwd(c.f("d_joint_in"), c.f("pooled_linear_l"), c.f("l_linear_l"), c.f("d_pl"), c.f("d_ll"), B * H,
                         c.st));
@@ -913,14 +949,36 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
                             P->joint_fc.beta, bt->keep_tile, dims->keep_joint, c.f("d_pre_tj"), nullptr, nullptr, nullptr,
                             (int)B, (int)M, (int)(2 * H), c.st));
         TRY(gemm(c, 0, 1, B * M, H, 2 * H, c.f("d_pre_tj"), (int)(2 * H), P->joint_fc.w, (int)(2 * H), c.f("d_tile_in"), (int)H));
-        TRY(vqa_tile_mul_bwd(c.f("d_tile_in"), c.f("pooled_linear_l"), c.f("d_ll"), (int)B, (int)M, (int)H, 1, c.st));
+        // (paired LayerNorm backward: d_ll holds only this extra gradient and is added inside that kernel)
+        TRY(vqa_tile_mul_bwd(c.f("d_tile_in"), c.f("pooled_linear_l"), c.f("d_ll"), (int)B, (int)M, (int)H, pair ? 0 : 1, c.st));
     }
+    // pooled_linear_l and q_linear_l: LayerNorm backward (paired with the product's, or each on its own), then the FC halves
+    const bool tr_pl = G->pooled_linear_l.w != nullptr, tr_ll = G->q_linear_l.w != nullptr;
+    if (pair) {
+        ProbeScope ps("fc.ln_bwd", c.st);
+        TRY(vqa_ln_pair_mul_bwd(c.f("d_joint_in"), mt == VQA_MODEL_ENT ? c.f("d_ll") : nullptr, c.f("pre_pl"), c.f("pre_ll"),
+                                c.f("mean_pl"), c.f("rstd_pl"), c.f("mean_ll"), c.f("rstd_ll"), P->pooled_linear_l.gamma,
+                                P->pooled_linear_l.beta, P->q_linear_l.gamma, P->q_linear_l.beta, c.f("d_pre_pl"), c.f("d_pre_ll"),
+                                tr_pl ? c.part(0) : nullptr, tr_pl ? c.part(1) : nullptr, tr_pl ? c.part(2) : nullptr,
+                                tr_ll ? c.f("part_a1") : nullptr, tr_ll ? c.f("part_b1") : nullptr, tr_ll ? c.f("part_c1") : nullptr,
+                                (int)B, (int)H, c.st));
+        TRY(fc_bwd_tail(c, c.f("pooled_V_ft"), B, Dp, H, P->pooled_linear_l, &G->pooled_linear_l, 1, c.f("d_pre_pl"), c.part(0),
+                        c.part(1), c.part(2), c.f("d_pooled"), false));
+    } else {
     TRY(fc_ln_relu_bwd(c, c.f("d_pl"), c.f("pooled_V_ft"), B, Dp, H, P->pooled_linear_l, &G->pooled_linear_l, 1, "pre_pl",
                        "mean_pl", "rstd_pl", nullptr, 1.f, "d_pre_pl", c.f("d_pooled"), false));
+    }
+    // q_linear_l's FC half (after its LayerNorm backward, unless the paired kernel did it): x = what the layer read
+    auto ll_bwd = [&](const float* x, float* dx) -> int {
+        if (pair)
+            return fc_bwd_tail(c, x, B, H, H, P->q_linear_l, &G->q_linear_l, 1, c.f("d_pre_ll"), c.f("part_a1"), c.f("part_b1"),
+                               c.f("part_c1"), dx, false);
+        return fc_ln_relu_bwd(c, c.f("d_ll"), x, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll", "rstd_ll", nullptr,
+                              1.f, "d_pre_ll", dx, false);
+    };
     if (mt == VQA_MODEL_ANSWER2) {
         // q_linear_l read q_L_ft2: back through it, then through tanh + LN + FC (trainable) into dh
-        TRY(fc_ln_relu_bwd(c, c.f("d_ll"), c.f("q_L_ft2"), B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll", "mean_ll",
-                           "rstd_ll", nullptr, 1.f, "d_pre_ll", c.f("d_ft2"), false));
+        TRY(ll_bwd(c.f("q_L_ft2"), c.f("d_ft2")));
         const bool train = G->q_L_ft2.w != nullptr;
         TRY(vqa_ln_act_bwd(c.f("d_ft2"), c.f("pre_ft2"), c.f("mean_ft2"), c.f("rstd_ft2"), P->q_L_ft2.gamma, P->q_L_ft2.beta,
                            nullptr, 1.f, c.f("d_pre_ft2"), train ? c.part(0) : nullptr, train ? c.part(1) : nullptr,
@@ -935,8 +993,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         // q_linear_l read q_L_mean (+ noise * sigma): linear layers on the GRU state
         const bool full = mt == VQA_MODEL_FULL;
         float* d_in = c.f(full ? "d_lin" : "d_qm");
-        TRY(fc_ln_relu_bwd(c, c.f("d_ll"), c.f(full ? "q_L_mean_noise" : "q_L_mean"), B, H, H, P->q_linear_l, &G->q_linear_l,
-                           1, "pre_ll", "mean_ll", "rstd_ll", nullptr, 1.f, "d_pre_ll", d_in, false));
+        TRY(ll_bwd(c.f(full ? "q_L_mean_noise" : "q_L_mean"), d_in));
         if (full)      // through x = mean + noise * sigma, plus the KL term's own gradient (weight / global batch)
             TRY(vqa_reparam_bwd(d_in, c.f("q_L_mean"), c.f("q_L_log_sigma_sq"), bt->noise,
                                 dims->extra_weight * dims->inv_global_batch, c.f("d_qm"), c.f("d_qs"), B * H, c.st));
@@ -953,8 +1010,7 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
             TRY(gemm(c, 0, 1, B, H, H, c.f("d_qs"), (int)H, P->q_L_log_sigma_sq.w, (int)H, dh, (int)H, nullptr, dh, (int)H));
         }
     } else {
-    TRY(fc_ln_relu_bwd(c, c.f("d_ll"), mt == VQA_MODEL_BI ? c.f("q_L_ft") : h, B, H, H, P->q_linear_l, &G->q_linear_l, 1, "pre_ll",
-                       "mean_ll", "rstd_ll", nullptr, 1.f, "d_pre_ll", dh, false));
+    TRY(ll_bwd(mt == VQA_MODEL_BI ? c.f("q_L_ft") : h, dh));
     }
     // attention + pooling
     {
@@ -1025,8 +1081,12 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     float* dx = c.f("dx_embed");
     {
     ProbeScope ps("gru.dx_gemm", c.st);
-    if (xcat_enabled()) {       // packed again here (one 3.7 MB kernel): no hidden dependence on the forward's copy
-        TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
+    if (xcat_enabled()) {
+        // wx_cat: the forward's packed copy of the x rows still sits in the workspace (backward follows the forward of the
+        // same step on the same weights: every gradient here is meaningless otherwise); VQA_HOT_REPACK=1 packs it again
+        static const bool repack = [] { const char* e = getenv("VQA_HOT_REPACK"); return e != nullptr && atoi(e) != 0; }();
+        if (repack)
+            TRY(vqa_gru_pack_wx(P->gru_wg, P->gru_wc, P->gru_bg, P->gru_bc, c.f("wx_cat"), c.f("bx_cat"), (int)W, (int)H, c.st));
         TRY(gemm(c, 0, 1, T * B, W, 3 * H, dxp, (int)(3 * H), c.f("wx_cat"), (int)(3 * H), dx, (int)W));
     } else {
         TRY(gemm(c, 0, 1, T * B, W, 2 * H, dxp, (int)(3 * H), P->gru_wg, (int)(2 * H), dx, (int)W));

@@ -395,7 +395,212 @@ Shape pick(const void* a, const void* b, const void* c, int rows, int N, bool ma
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// pooled_linear_l and q_linear_l end in the same place: joint_fc reads their PRODUCT (vqa/model_vlmap_answer.py:163-177).
+// One launch finishes both layers and forms the product -- LayerNorm + ReLU of two [B, N] pre-activations (one row per
+// group) and z = y_a * y_b -- instead of two LayerNorm launches and an element-wise one; the backward twin takes dz
+// (+ an optional extra gradient on y_b) back to both pre-activations.  One workgroup per sample, every value in registers.
+template <int VPT>
+__device__ __forceinline__ void pair_stats(const float4 (&a)[VPT], const float4 (&b)[VPT], int N, float* red, float& mean_a,
+                                           float& rstd_a, float& mean_b, float& rstd_b, const bool (&in)[VPT]) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+        if (in[i]) { sa += (a[i].x + a[i].y) + (a[i].z + a[i].w); sb += (b[i].x + b[i].y) + (b[i].z + b[i].w); }
+    const float invN = 1.f / (float)N;
+    mean_a = block_sum(sa, red) * invN;
+    mean_b = block_sum(sb, red) * invN;
+    float qa = 0.f, qb = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+        if (in[i]) {
+            const float a0 = a[i].x - mean_a, a1 = a[i].y - mean_a, a2 = a[i].z - mean_a, a3 = a[i].w - mean_a;
+            const float b0 = b[i].x - mean_b, b1 = b[i].y - mean_b, b2 = b[i].z - mean_b, b3 = b[i].w - mean_b;
+            qa += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            qb += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+        }
+    rstd_a = 1.f / sqrtf(block_sum(qa, red) * invN + LN_EPS);
+    rstd_b = 1.f / sqrtf(block_sum(qb, red) * invN + LN_EPS);
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_pair_mul_fwd_kernel(const float* __restrict__ pre_a, const float* __restrict__ pre_b,
+                                                              const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                                              const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+                                                              float* __restrict__ y_a, float* __restrict__ y_b,
+                                                              float* __restrict__ z, float* __restrict__ mean_a_out,
+                                                              float* __restrict__ rstd_a_out, float* __restrict__ mean_b_out,
+                                                              float* __restrict__ rstd_b_out, int N) {
+    __shared__ float red[16];
+    const int g = blockIdx.x;
+    const int64_t base = (int64_t)g * N;
+    float4 a[VPT], b[VPT];
+    bool in[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        in[i] = col < N;
+        const int cc = in[i] ? col : 0;
+        a[i] = *reinterpret_cast<const float4*>(pre_a + base + cc);
+        b[i] = *reinterpret_cast<const float4*>(pre_b + base + cc);
+    }
+    float ma, ra, mb, rb;
+    pair_stats<VPT>(a, b, N, red, ma, ra, mb, rb, in);
+    if (threadIdx.x == 0) { mean_a_out[g] = ma; rstd_a_out[g] = ra; mean_b_out[g] = mb; rstd_b_out[g] = rb; }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        if (!in[i]) continue;
+        const int col = (threadIdx.x + 256 * i) * 4;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma_a + col), ba = *reinterpret_cast<const float4*>(beta_a + col);
+        const float4 gb = *reinterpret_cast<const float4*>(gamma_b + col), bb = *reinterpret_cast<const float4*>(beta_b + col);
+        float4 ya, yb;
+        ya.x = fmaxf((a[i].x - ma) * ra * ga.x + ba.x, 0.f); ya.y = fmaxf((a[i].y - ma) * ra * ga.y + ba.y, 0.f);
+        ya.z = fmaxf((a[i].z - ma) * ra * ga.z + ba.z, 0.f); ya.w = fmaxf((a[i].w - ma) * ra * ga.w + ba.w, 0.f);
+        yb.x = fmaxf((b[i].x - mb) * rb * gb.x + bb.x, 0.f); yb.y = fmaxf((b[i].y - mb) * rb * gb.y + bb.y, 0.f);
+        yb.z = fmaxf((b[i].z - mb) * rb * gb.z + bb.z, 0.f); yb.w = fmaxf((b[i].w - mb) * rb * gb.w + bb.w, 0.f);
+        *reinterpret_cast<float4*>(y_a + base + col) = ya;
+        *reinterpret_cast<float4*>(y_b + base + col) = yb;
+        *reinterpret_cast<float4*>(z + base + col) = make_float4(ya.x * yb.x, ya.y * yb.y, ya.z * yb.z, ya.w * yb.w);
+    }
+}
+
+// one tensor's LayerNorm + ReLU backward on register-resident values: dy -> dpre (+ the per-sample partial rows)
+template <int VPT>
+__device__ __forceinline__ void pair_bwd_one(const float (&dy)[VPT][4], const float (&xh)[VPT][4], const float (&gam)[VPT][4],
+                                             const bool (&pos)[VPT][4], const bool (&in)[VPT], float rstd, int N, float* red,
+                                             float* __restrict__ dpre, float* __restrict__ pdg, float* __restrict__ pdb,
+                                             float* __restrict__ pdbias, int64_t base) {
+    float dxh[VPT][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dln = (in[i] && pos[i][j]) ? dy[i][j] : 0.f;
+            dxh[i][j] = dln * gam[i][j];
+            s1 += dxh[i][j];
+            s2 += dxh[i][j] * xh[i][j];
+        }
+    const float invN = 1.f / (float)N;
+    const float m1 = block_sum(s1, red) * invN;
+    const float m2 = block_sum(s2, red) * invN;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        if (!in[i]) continue;
+        const int col = (threadIdx.x + 256 * i) * 4;
+        float o[4], dl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = rstd * (dxh[i][j] - m1 - xh[i][j] * m2);
+            dl[j] = pos[i][j] ? dy[i][j] : 0.f;
+        }
+        *reinterpret_cast<float4*>(dpre + base + col) = make_float4(o[0], o[1], o[2], o[3]);
+        if (pdg != nullptr) {
+            *reinterpret_cast<float4*>(pdg + base + col) = make_float4(dl[0] * xh[i][0], dl[1] * xh[i][1], dl[2] * xh[i][2], dl[3] * xh[i][3]);
+            *reinterpret_cast<float4*>(pdb + base + col) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        }
+        if (pdbias != nullptr) *reinterpret_cast<float4*>(pdbias + base + col) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_pair_mul_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ add_b, const float* __restrict__ pre_a, const float* __restrict__ pre_b,
+    const float* __restrict__ mean_a, const float* __restrict__ rstd_a, const float* __restrict__ mean_b,
+    const float* __restrict__ rstd_b, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+    const float* __restrict__ gamma_b, const float* __restrict__ beta_b, float* __restrict__ dpre_a, float* __restrict__ dpre_b,
+    float* __restrict__ pdg_a, float* __restrict__ pdb_a, float* __restrict__ pdbias_a, float* __restrict__ pdg_b,
+    float* __restrict__ pdb_b, float* __restrict__ pdbias_b, int N) {
+    __shared__ float red[16];
+    const int g = blockIdx.x;
+    const int64_t base = (int64_t)g * N;
+    const float ma = mean_a[g], ra = rstd_a[g], mb = mean_b[g], rb = rstd_b[g];
+    float dya[VPT][4], dyb[VPT][4], xha[VPT][4], xhb[VPT][4], ga[VPT][4], gb[VPT][4];
+    bool pa[VPT][4], pb[VPT][4], in[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int col = (threadIdx.x + 256 * i) * 4;
+        in[i] = col < N;
+        const int cc = in[i] ? col : 0;
+        const float4 d = *reinterpret_cast<const float4*>(dz + base + cc);
+        const float4 a = *reinterpret_cast<const float4*>(pre_a + base + cc), b = *reinterpret_cast<const float4*>(pre_b + base + cc);
+        const float4 gA = *reinterpret_cast<const float4*>(gamma_a + cc), bA = *reinterpret_cast<const float4*>(beta_a + cc);
+        const float4 gB = *reinterpret_cast<const float4*>(gamma_b + cc), bB = *reinterpret_cast<const float4*>(beta_b + cc);
+        float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (add_b != nullptr) ad = *reinterpret_cast<const float4*>(add_b + base + cc);
+        const float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        const float gav[4] = {gA.x, gA.y, gA.z, gA.w}, bav[4] = {bA.x, bA.y, bA.z, bA.w};
+        const float gbv[4] = {gB.x, gB.y, gB.z, gB.w}, bbv[4] = {bB.x, bB.y, bB.z, bB.w}, adv[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xha[i][j] = (av[j] - ma) * ra;
+            xhb[i][j] = (bv[j] - mb) * rb;
+            const float lna = xha[i][j] * gav[j] + bav[j], lnb = xhb[i][j] * gbv[j] + bbv[j];
+            pa[i][j] = lna > 0.f;
+            pb[i][j] = lnb > 0.f;
+            const float ya = fmaxf(lna, 0.f), yb = fmaxf(lnb, 0.f);
+            dya[i][j] = dv[j] * yb;
+            dyb[i][j] = dv[j] * ya + adv[j];
+            ga[i][j] = gav[j];
+            gb[i][j] = gbv[j];
+        }
+    }
+    pair_bwd_one<VPT>(dya, xha, ga, pa, in, ra, N, red, dpre_a, pdg_a, pdb_a, pdbias_a, base);
+    pair_bwd_one<VPT>(dyb, xhb, gb, pb, in, rb, N, red, dpre_b, pdg_b, pdb_b, pdbias_b, base);
+}
+
 }  // namespace
+
+extern "C" int vqa_ln_pair_mul_supported(int N, const void* const* ptrs, int n_ptrs) {
+    if (N <= 0 || N % 4 != 0 || N > 4096) return 0;
+    for (int i = 0; i < n_ptrs; ++i)
+        if (ptrs[i] != nullptr && !vqa_aligned16(ptrs[i])) return 0;
+    return 1;
+}
+
+extern "C" int vqa_ln_pair_mul_fwd(const float* pre_a, const float* pre_b, const float* gamma_a, const float* beta_a,
+                                   const float* gamma_b, const float* beta_b, float* y_a, float* y_b, float* z, float* mean_a,
+                                   float* rstd_a, float* mean_b, float* rstd_b, int G, int N, void* stream) {
+    VQA_REQUIRE(pre_a && pre_b && gamma_a && beta_a && gamma_b && beta_b && y_a && y_b && z && mean_a && rstd_a && mean_b && rstd_b &&
+                    G >= 0,
+                VQA_ERR_ARG);
+    const void* ptrs[9] = {pre_a, pre_b, gamma_a, beta_a, gamma_b, beta_b, y_a, y_b, z};
+    VQA_REQUIRE(vqa_ln_pair_mul_supported(N, ptrs, 9), VQA_ERR_ALIGN);
+    if (G == 0) return VQA_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define VQA_LNP_FWD(v)                                                                                                         \
+    hipLaunchKernelGGL(ln_pair_mul_fwd_kernel<v>, dim3(G), dim3(256), 0, st, pre_a, pre_b, gamma_a, beta_a, gamma_b, beta_b, y_a, \
+                       y_b, z, mean_a, rstd_a, mean_b, rstd_b, N)
+    if (N <= 1024) VQA_LNP_FWD(1); else if (N <= 2048) VQA_LNP_FWD(2); else VQA_LNP_FWD(4);
+#undef VQA_LNP_FWD
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+extern "C" int vqa_ln_pair_mul_bwd(const float* dz, const float* add_b, const float* pre_a, const float* pre_b, const float* mean_a,
+                                   const float* rstd_a, const float* mean_b, const float* rstd_b, const float* gamma_a,
+                                   const float* beta_a, const float* gamma_b, const float* beta_b, float* dpre_a, float* dpre_b,
+                                   float* part_dgamma_a, float* part_dbeta_a, float* part_dbias_a, float* part_dgamma_b,
+                                   float* part_dbeta_b, float* part_dbias_b, int G, int N, void* stream) {
+    VQA_REQUIRE(dz && pre_a && pre_b && mean_a && rstd_a && mean_b && rstd_b && gamma_a && beta_a && gamma_b && beta_b && dpre_a &&
+                    dpre_b && G >= 0,
+                VQA_ERR_ARG);
+    VQA_REQUIRE((part_dgamma_a == nullptr) == (part_dbeta_a == nullptr) && (part_dgamma_b == nullptr) == (part_dbeta_b == nullptr),
+                VQA_ERR_ARG);
+    const void* ptrs[18] = {dz, add_b, pre_a, pre_b, gamma_a, beta_a, gamma_b, beta_b, dpre_a, dpre_b, part_dgamma_a, part_dbeta_a,
+                            part_dbias_a, part_dgamma_b, part_dbeta_b, part_dbias_b, nullptr, nullptr};
+    VQA_REQUIRE(vqa_ln_pair_mul_supported(N, ptrs, 16), VQA_ERR_ALIGN);
+    if (G == 0) return VQA_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define VQA_LNP_BWD(v)                                                                                                          \
+    hipLaunchKernelGGL(ln_pair_mul_bwd_kernel<v>, dim3(G), dim3(256), 0, st, dz, add_b, pre_a, pre_b, mean_a, rstd_a, mean_b, rstd_b, \
+                       gamma_a, beta_a, gamma_b, beta_b, dpre_a, dpre_b, part_dgamma_a, part_dbeta_a, part_dbias_a, part_dgamma_b, \
+                       part_dbeta_b, part_dbias_b, N)
+    if (N <= 1024) VQA_LNP_BWD(1); else if (N <= 2048) VQA_LNP_BWD(2); else VQA_LNP_BWD(4);
+#undef VQA_LNP_BWD
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
 
 extern "C" int vqa_ln_set_fast(int on) {
     g_ln_reg = on ? 1 : 0;
