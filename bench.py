@@ -686,6 +686,18 @@ def main():
         torch.cuda.empty_cache()
 
     if rank == 0:
+        # the WORST group that matters: lowest fraction of its own bound among the groups that take >= 5 % of the step, named
+        # beside the best big kernel so that `roofline.frac` cannot be read as the step's
+        worst = None
+        if groups:
+            cand = [(g["frac"], k) for k, g in groups.items()
+                    if g.get("frac") is not None and g["us_per_step"] >= 0.05 * groups_step_us]
+            if cand:
+                f_, k_ = min(cand)
+                g_ = groups[k_]
+                worst = {"group": k_, "frac": f_, "bound": g_["bound"], "achieved": g_["achieved"], "peak": g_["peak"],
+                         "unit": g_["unit"], "us_per_step": g_["us_per_step"], "share_of_step": g_["us_per_step"] / groups_step_us,
+                         "what": g_["what"]}
         kern_ms = float(np.mean(ms[:n.value])) if n.value else float("nan")
         # algorithmic FLOPs of the probed kernel: v_linear_v fwd = 2*B*R*D*H
         flops = 2.0 * cfg["B"] * cfg["R"] * cfg["D"] * cfg["H"]
@@ -726,6 +738,7 @@ def main():
                                   "frac_at_clock": (step_tflops / clock["f32_mfma_peak_at_clock"]) if clock else None},
                          "clock": clock,
                          "frac_at_clock": (achieved / clock["f32_mfma_peak_at_clock"]) if clock else None,
+                         "worst_group": worst,
                          "groups": groups,
                          "groups_note": ("per-group times from a separate pass of 10 steps with HIP events around every "
                                          "launch group (%.1f us per step in that pass, events included); `frac` of a group "
