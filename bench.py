@@ -174,7 +174,7 @@ def cpu_baseline(params, table, nbox, am, batch, cfg, steps=5):
 
 # v_linear_v forward GEMM: 128x64 tiles, 8 waves of 32x32 (cfg 20), NN layout, plain epilogue -> 144 x 16 = 2304 workgroups
 ROOFLINE_KERNEL = "gemm_f32_kernel<128,64,32,32,1,32,0,true,false,0,false,false,512,false>"
-PMC_TRAFFIC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
 def name_of(path):
@@ -729,7 +729,7 @@ def main():
                                             "this run)" % traffic_src) if traffic_src else None,
                          "kernel_ms": kern_ms, "samples": n.value,
                          "clock_note": "kernel_ms is measured live with HIP events on the kernel's stream in an unprofiled "
-                                       "run; under rocprofv3 the same kernel runs ~4-5 % longer (profiles/r3_trace_summary.txt: "
+                                       "run; under rocprofv3 the same kernel runs ~4-5 % longer (profiles/r4_trace_summary.txt: "
                                        "the profiler holds the GPU at a lower sustained clock), so frac recomputed from the "
                                        "committed trace is lower by that ratio",
                          # what the WHOLE step achieves against the same peak, and where its time goes

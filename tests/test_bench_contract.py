@@ -47,7 +47,7 @@ def test_committed_pmc_profile_names_the_roofline_kernel():
     assert 235e6 <= nbytes <= 2.5e9
     # the same kernel, with the same grid, is in the committed kernel trace
     want = bench.ROOFLINE_KERNEL.split(" (")[0].replace(" ", "")
-    with open(os.path.join(ROOT, "profiles", "r2_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r4_kernel_stats.csv")) as f:
         names = [r["Name"].replace(" ", "") for r in csv.DictReader(f)]
     assert any(want in n for n in names), want
 

@@ -851,7 +851,8 @@ def test_ln_pair_mul_fwd_bwd(G, N, params, extra):
     da64, pga64, pba64 = ln_bwd(dya, lna, xa, ra, ga)
     db64, pgb64, pbb64 = ln_bwd(dyb, lnb, xb, rb, gb)
     pp = lambda k: P(out[k]) if params else None
-    _lib.check(lib.vqa_ln_pair_mul_bwd(P(f(dz)), P(f(add)) if extra else None, P(d["a"]), P(d["b"]), P(st["ma"]), P(st["ra"]), P(st["mb"]),
+    dz_t, add_t = f(dz), (f(add) if extra else None)            # (kept alive: the call takes raw pointers)
+    _lib.check(lib.vqa_ln_pair_mul_bwd(P(dz_t), P(add_t), P(d["a"]), P(d["b"]), P(st["ma"]), P(st["ra"]), P(st["mb"]),
                                        P(st["rb"]), P(d["ga"]), P(d["ba"]), P(d["gb"]), P(d["bb"]), P(out["da"]), P(out["db"]),
                                        pp("pga"), pp("pba"), pp("pca"), pp("pgb"), pp("pbb"), pp("pcb"), G, N, None), "pair bwd")
     torch.cuda.synchronize()
