@@ -1,5 +1,7 @@
 """CPU tests of the pre-training stage's host side: dataset sampling contract
 (vlmap_memft/datasets/dataset_vlmap.py:128-236), batch padding, trainer flags (vlmap_memft/trainer.py:323-351)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,6 +149,43 @@ def test_export_word_weights_command_line(tmp_path):
     with pytest.raises(ValueError, match="class_feat_dim"):
         EW.run(EW.build_parser().parse_args(["--checkpoint", str(run / "model-13"), "--data_dir", str(data)]))
     assert EW.build_parser().parse_args(["--checkpoint", "x"]).class_feat_dim == 2048
+
+
+def test_export_noc_word_weights_command_line_feeds_the_noc_heads(tmp_path):
+    """vlmap_memft/export_noc_word_weights.py as a command: classifier_v / classifier_l of a checkpoint -> v_class_* / l_class_*
+    of weights.hdf5, in the form model_vlmap_answer_noc's two WordWeightAnswer heads look up by answer string (:190-202)"""
+    import pickle
+    import torch
+    from vqa_transfer_externaldata_amd import export_noc_word_weights as EN, hdf5_io, model_vlmap_answer as MV
+    F2, A, Vq, W = 16, 7, 11, 5
+    rng = np.random.default_rng(0)
+    sd = {name: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) for name, shape in (
+        ("V_GloVe/embed_map", (Vq, W)), ("L_GloVe/embed_map", (Vq, W)), ("LearnAnswerGloVe/embed_map", (A, W)),
+        ("classifier_v/fc/weights", (F2, A)), ("classifier_v/fc/biases", (A,)), ("classifier_l/fc/weights", (F2, A)),
+        ("classifier_l/fc/biases", (A,)))}
+    run, data = tmp_path / "noc_run", tmp_path / "data"
+    run.mkdir(); data.mkdir()
+    torch.save(sd, str(run / "model-7"))
+    vocab = {"vocab": ["w%d" % i for i in range(Vq)]}
+    adict = {"vocab": ["a%d" % i for i in range(A)], "dict": {"a%d" % i: i for i in range(A)}}
+    pickle.dump(vocab, open(str(data / "vocab.pkl"), "wb"), protocol=2)
+    pickle.dump(adict, open(str(data / "answer_dict.pkl"), "wb"), protocol=2)
+    args = ["--checkpoint", str(run / "model-7"), "--data_dir", str(data), "--class_feat_dim", str(F2)]
+    d = EN.run(EN.build_parser().parse_args(args))
+    got = hdf5_io.load_tree(os.path.join(d, "weights.hdf5"))
+    assert sorted(got) == ["l_answer_word", "l_class_biases", "l_class_weights", "l_word", "v_class_biases", "v_class_weights", "v_word"]
+    np.testing.assert_array_equal(got["l_class_weights"], sd["classifier_l/fc/weights"].numpy())
+    ww = MV.load_word_weight_dir(d)
+    # the VQA side: answers known to the directory get their column, the others weight 0 / bias -100
+    vqa_answers = {"vocab": ["a3", "zzz", "a0"]}
+    w, b = MV.word_weight_answer_init(vqa_answers, F2, ww, weight_name="v_class_weights", bias_name="v_class_biases")
+    np.testing.assert_array_equal(w[:, 0], sd["classifier_v/fc/weights"].numpy()[:, 3])
+    assert b[1] == -100.0 and not w[:, 1].any() and b[2] == float(sd["classifier_v/fc/biases"][0])
+    with pytest.raises(ValueError, match="Do not overwrite"):
+        EN.run(EN.build_parser().parse_args(args))
+    torch.save({k: v for k, v in sd.items() if not k.startswith("classifier_l/")}, str(run / "model-8"))
+    with pytest.raises(KeyError, match="classifier_l"):
+        EN.run(EN.build_parser().parse_args(["--checkpoint", str(run / "model-8"), "--data_dir", str(data), "--class_feat_dim", str(F2)]))
 
 
 def test_a_failing_producer_raises_in_the_consumer():
