@@ -218,6 +218,62 @@ def test_extractor_cli_from_images_on_disk_to_reference_hdf5(tmp_path):
         VX.run(cfg, blocks=blocks)
 
 
+def test_extractor_cli_with_decoding_processes_in_a_fresh_process(tmp_path):
+    """`vfeat_extractor --loader_processes 2`: the decoding workers must be forked BEFORE the process initialises the GPU
+    runtime (run() creates the input pipeline first; input_ops_vfeat._create_mp refuses once torch.cuda is initialised).  Run in
+    a fresh child process so that this test's own GPU state is not in the way; the table must equal the thread-pool run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from vqa_transfer_externaldata_amd import dataset_vfeat as DV, hdf5_io, model_vlmap_answer as MV
+    rng = np.random.default_rng(5)
+    img_dir, dc_dir, rec_dir = tmp_path / "images", tmp_path / "densecap", tmp_path / "tf_record_memft"
+    os.makedirs(img_dir / "val2014"); os.makedirs(dc_dir / "val2014"); os.makedirs(rec_dir)
+    paths, tree = [], {}
+    for i in range(5):
+        w, h = int(rng.integers(80, 160)), int(rng.integers(80, 160))
+        p = "val2014/COCO_val2014_%012d.jpg" % i
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(str(img_dir / p), quality=95)
+        n = int(rng.integers(2, 9))
+        tree[p.replace("/", "-")] = {"boxes": np.concatenate([rng.random((n, 2)) * [w / 2, h / 2],
+                                                              rng.random((n, 2)) * [w / 2, h / 2] + 4], 1).astype(np.float32)}
+        paths.append(p)
+    hdf5_io.write(str(dc_dir / "val2014" / DV.DENSECAP_FILENAME), tree)
+    ids = [p.replace("/", "-") for p in paths]
+    json.dump({"image_id2idx": {k: i for i, k in enumerate(ids)}, "image_path2idx": {p: i for i, p in enumerate(paths)},
+               "image_num2path": {str(i): p for i, p in enumerate(paths)}}, open(rec_dir / "image_info.json", "w"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from vqa_transfer_externaldata_amd import vfeat as VF, vfeat_extractor as VX\n"
+            "blocks = [(n, b // 2, 1, s) for (n, b, u, s) in VF.BLOCKS_R50_B3]\n"
+            "for name, procs in (('threads.hdf5', '0'), ('procs.hdf5', '2')):\n"
+            "    cfg = VX.build_parser().parse_args(['--tf_record_memft_dir', %r, '--image_dir', %r, '--densecap_dir', %r,\n"
+            "        '--pretrained_param_path', 'random:7', '--batch_size', '2', '--model_type', 'resnet', '--save_name', name,\n"
+            "        '--loader_processes', procs])\n"
+            "    VX.run(cfg, blocks=blocks)\n"
+            "print('extractor child ok')\n") % (root, str(rec_dir), str(img_dir), str(dc_dir))
+    # each run in a child process of its own (the decoders must be forked before that process touches the GPU)
+    r = subprocess.run([sys.executable, "-c", code.replace("(('threads.hdf5', '0'), ('procs.hdf5', '2'))", "(('procs.hdf5', '2'),)")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "extractor child ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-c", code.replace("(('threads.hdf5', '0'), ('procs.hdf5', '2'))", "(('threads.hdf5', '0'),)")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = MV.load_image_features(str(rec_dir / "threads.hdf5"))
+    b = MV.load_image_features(str(rec_dir / "procs.hdf5"))
+    np.testing.assert_array_equal(np.asarray(a[0]), np.asarray(b[0]))
+    np.testing.assert_array_equal(np.asarray(a[2]), np.asarray(b[2]))
+    # and once the GPU runtime is up in THIS process, forking decoders is refused by name
+    import torch
+    from vqa_transfer_externaldata_amd import input_ops_vfeat as IO
+    torch.zeros(1, device="cuda")
+    ds = DV.create_dataset(paths, str(img_dir), str(dc_dir))
+    with pytest.raises(RuntimeError, match="forked before this process initialises the GPU"):
+        list(IO.create(ds, 2, is_train=False, shuffle=False, prefetch=2, reuse_buffers=True, image_dtype=np.uint8, processes=2))
+
+
 @pytest.mark.parametrize("case", [
     dict(B=3, Hi=9, Wi=11, Ci=8, Co=12, k=1, stride=1, pad="none", relu=True, residual=True),      # bottleneck 1x1
     dict(B=2, Hi=10, Wi=9, Ci=8, Co=8, k=3, stride=1, pad="same", relu=True, residual=False),      # 3x3 conv2d_same, stride 1
