@@ -1,4 +1,4 @@
-"""The data-parallel path that SHIPS, on the GPU: two child processes share the one GPU
+"""The data-parallel path that SHIPS, on the GPU: two -- and four -- child processes share the one GPU
 of the box, talk over gloo, and each runs FusionEngine.train_step(allreduce=dp.BucketedAllReduce()) --
 vqa_fusion_backward_phases + one bucket reduction per phase -- on its shard (4 + 3 samples).  The reduced
 gradient buffer (tail slot = un-aggregated embedding-slice sum of squares included) and the parameters
@@ -54,11 +54,12 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_ranks_bucketed_allreduce_equals_one_process_full_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])      # 7 samples: shards 4 + 3 and 2 + 2 + 2 + 1 (at most 6 processes may share the card)
+def test_ranks_bucketed_allreduce_equals_one_process_full_batch(tmp_path, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out_path = str(tmp_path / "rank0.npz")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_path)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

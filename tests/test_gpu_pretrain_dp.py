@@ -68,11 +68,12 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_ranks_bucketed_allreduce_equals_one_process_full_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])      # 5 images: 3 + 2 and 2 + 2 + 1
+def test_ranks_bucketed_allreduce_equals_one_process_full_batch(tmp_path, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out_path = str(tmp_path / "rank0.npz")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_path)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:
