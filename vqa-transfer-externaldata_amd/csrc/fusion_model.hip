@@ -172,7 +172,8 @@ Layout make_layout(const vqa_dims_t& d) {
     cw = max64(cw, vqa_colsum_workspace_floats((int)B, (int)W));
     cw = max64(cw, vqa_colsum_workspace_floats((int)(B * T), (int)H));
     if (d.model_type == VQA_MODEL_LEGACY_VQA)
-        cw = max64(cw, max64(vqa_colsum_workspace_floats((int)(T * B), (int)(4 * H)), vqa_colsum_workspace_floats((int)(d.La * A), (int)(4 * H))));
+        cw = max64(cw, max64(max64(vqa_colsum_workspace_floats((int)(T * B), (int)(4 * H)), vqa_colsum_workspace_floats((int)(d.La * A), (int)(4 * H))),
+                             vqa_colsum_workspace_floats((int)A, 1)));
     L.add("colsum_ws", max64(3 * cw, 4));    // x3: vqa_colsum3 reduces three partial matrices per launch
     L.add("colsum_ws1", max64(3 * cw, 4));
     L.add("part_a1", B * H); L.add("part_b1", B * H); L.add("part_c1", B * H);
