@@ -270,6 +270,45 @@ def test_noc_variant_loads_its_two_heads_and_trains(tmp_path, model_type):
     assert not torch.equal(P["v_linear_v/fc/weights"], moving)
 
 
+def test_trainer_standard_clips_at_a_quarter_and_inference_restores_a_checkpoint(tmp_path):
+    """vqa/trainer_standard.py on the GPU: train / val only, global-norm clip 0.25 (the first update is far smaller than
+    under vqa/trainer.py's 20.0), run directory std_...; then vqa/inference.py: a model restored from the checkpoint
+    with its input pipelines, one batch through it"""
+    from vqa_transfer_externaldata_amd import inference, trainer, trainer_standard
+    c, Vq, A = _config(tmp_path, "standard")
+    ds = _datasets(Vq, A)
+    cs = trainer_standard.parse_config(["--batch_size", "32", "--max_train_iter", "9", "--train_average_iter", "4",
+                                        "--val_average_iter", "2", "--validation_step", "6", "--checkpoint_step", "6",
+                                        "--heavy_summary_step", "6", "--learning_rate", "0.002"])
+    cs.vocab, cs.answer_dict, cs.synthetic, cs.tf_record_dir = c.vocab, c.answer_dict, 1, c.tf_record_dir
+    cs.train_dir = str(tmp_path / "std_run")
+    ts = trainer_standard.Trainer(cs, datasets=ds, image_features=_features())
+    assert sorted(ts._iters) == ["train", "val"] and ts.model.engine.clip_norm == 0.25
+    t20 = trainer.Trainer(c, datasets=ds, image_features=_features())
+    assert t20.model.engine.clip_norm == 20.0
+    w0 = ts.model.engine.train_flat.clone()
+    assert torch.equal(w0, t20.model.engine.train_flat)                        # same seed, same initialisation
+    ts.run_train_step(False); t20.run_train_step(False)
+    norm = float(ts.model.engine.norm_sq[0]) ** 0.5
+    assert norm > 0.25                                                          # the clip is active
+    # Adam's first step has magnitude lr per coordinate whatever the scale -- compare the MOMENTS, which carry the clipped gradient
+    m_s, m_20 = ts.model.engine.m_flat, t20.model.engine.m_flat
+    ratio = float(m_s.abs().max() / m_20.abs().max())
+    assert abs(ratio - (0.25 / norm) / (20.0 / max(norm, 20.0))) <= 1e-3 * ratio
+    ts.train()
+    ckpt = os.path.join(cs.train_dir, "model-7")
+    assert os.path.exists(ckpt)
+    ic = inference.get_default_config()
+    ic.checkpoint, ic.model_type, ic.batch_size = ckpt, "standard", 32
+    ic.tf_record_dir, ic.vfeat_path, ic.vocab, ic.answer_dict, ic.synthetic = cs.tf_record_dir, None, c.vocab, c.answer_dict, 1
+    inf = inference.get_inference(ic, datasets=ds, image_features=_features())
+    sd = torch.load(ckpt, map_location="cpu")
+    for k in inf.model.engine.shapes:
+        assert torch.equal(inf.model.engine.params[k].cpu(), sd[k]), k
+    batch, model = inf.run("val")
+    assert model.output["pred"].shape[0] == len(batch["id"]) and np.isfinite(float(model.loss))
+
+
 def test_eval_multiple_model_sweeps_every_checkpoint_of_every_run(tmp_path):
     """vqa/eval_multiple_model.py:40-130: runs under --root_train_dir named vqa_<model>_d_<qa split>_tf_record_memft...,
     runs without checkpoints dropped, a run pointing at another feature file skipped, one results.pkl per checkpoint"""

@@ -113,3 +113,40 @@ def test_eval_collection_rescoring_against_pure_test_annotations(tmp_path):
     assert (run / "collect_eval_test_result.txt").read_text().splitlines()[1].startswith("00801 0.50000 00000004")
     with pytest.raises(ValueError, match="Set either"):
         EC.main(["--split", "test"])
+
+
+def test_eval_collection_vqa_all_rescoring_per_detail_split(tmp_path):
+    """vqa/eval_collection_vqa_all.py:36-41, 65-83 with synthetic test_qid2anno.pkl / test_detail_split.pkl: one triple of
+    re-scored means per subset of the detail split, worked out by hand"""
+    import pickle
+    from vqa_transfer_externaldata_amd import eval_collection_vqa_all as EA
+    anno = {10: {"answer_score": {"cat": 1.0}}, 11: {"answer_score": {"red": 0.6}}, 12: {"answer_score": {"two": 0.9}},
+            13: {"answer_score": {"big": 1.0}}}
+    res = {10: {"pred": "cat", "test_obj_max_score": 1.0, "test_attr_max_score": 0.0},
+           11: {"pred": "blue", "test_obj_max_score": 0.0, "test_attr_max_score": 0.6},
+           12: {"pred": "two", "test_obj_max_score": 0.9, "test_attr_max_score": 0.9},
+           13: {"pred": "big", "test_obj_max_score": 0.0, "test_attr_max_score": 1.0}}
+    detail = {"seen": [10, 11], "unseen": [12, 13]}
+    got = EA.rescore_detail(res, anno, detail)
+    assert got["new_seen_total_score"] == pytest.approx(0.5) and got["new_seen_obj_only_score"] == pytest.approx(1.0)
+    assert got["new_seen_attr_only_score"] == pytest.approx(0.0)
+    assert got["new_unseen_total_score"] == pytest.approx(0.95) and got["new_unseen_attr_only_score"] == pytest.approx(1.0)
+    assert np.isnan(got["new_unseen_obj_only_score"])                                     # no object-only question there
+    run = tmp_path / "vqa_run"
+    run.mkdir()
+    ed = run / "model-801_eval_test_20180101-000000"
+    ed.mkdir()
+    avg = {}
+    for k in ("testonly_score", "test_obj_only_score", "test_attr_only_score"):
+        avg[k], avg[k + "_num_point"] = 0.5, 4
+    pickle.dump({"qid2result": res, "avg_eval_report": avg}, open(ed / "results.pkl", "wb"))
+    qa = tmp_path / "qa_split"
+    qa.mkdir()
+    pickle.dump(anno, open(qa / "test_qid2anno.pkl", "wb"), protocol=2)
+    pickle.dump(detail, open(qa / "test_detail_split.pkl", "wb"), protocol=2)
+    out = EA.main(["--train_dirs", str(run), "--split", "test", "--qa_split_dir", str(qa)])[str(run)]
+    assert out["iter"] == [801] and out["new_seen_total_score"] == [pytest.approx(0.5)]
+    assert (run / "collect_eval_test_result.txt").read_text().splitlines()[1].startswith("00801 0.50000 00000004")
+    assert EA.build_parser().parse_args([]).qa_split_dir.endswith("_with_seen_answer_in_test")
+    with pytest.raises(ValueError, match="Do not set both"):
+        EA.main(["--root_train_dir", "x", "--train_dirs", "y"])

@@ -280,6 +280,8 @@ class FusionEngine:
                               ent_cols=int(ent_cols or A) if model_type == "vlmap_answer_ent" else 0,
                               extra_weight={"vlmap_answer_ent": W_ENTROPY, "vlmap_answer_full": LATENT_LOSS_WEIGHT}.get(model_type, 0.0))
         self._ent_cols_given = ent_cols is not None
+        self.clip_norm = CLIP_NORM       # tf.contrib.layers.optimize_loss(clip_gradients=...): 20.0 (vqa/trainer.py:111), 0.25 in
+                                         # vqa/trainer_standard.py:95 -- the caller's Trainer sets it
         self.glove_fixed, self._answers = None, None
         if model_type in LEGACY_FAMILY:
             if glove_fixed is None or answers is None:
@@ -577,7 +579,7 @@ class FusionEngine:
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         _lib.check(self.lib.vqa_clip_adam(C.c_void_p(self.train_flat.data_ptr()), C.c_void_p(self.grad_flat.data_ptr()),
                                           C.c_void_p(self.m_flat.data_ptr()), C.c_void_p(self.v_flat.data_ptr()),
-                                          self.n_train, C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, lr_t,
+                                          self.n_train, C.c_void_p(self.norm_sq.data_ptr()), float(self.clip_norm), lr_t,
                                           ADAM_B1, ADAM_B2, ADAM_EPS, self._stream()), "vqa_clip_adam")
 
     def train_step(self, batch, keep_att, keep_joint, lr, allreduce=None, keep_joint2=None, noise=None, keep_tile=None,
@@ -659,7 +661,7 @@ class FusionEngine:
                     _lib.check(self.lib.vqa_clip_adam_dev(
                         C.c_void_p(self.train_flat.data_ptr()), C.c_void_p(self.grad_flat.data_ptr()),
                         C.c_void_p(self.m_flat.data_ptr()), C.c_void_p(self.v_flat.data_ptr()), self.n_train,
-                        C.c_void_p(self.norm_sq.data_ptr()), CLIP_NORM, C.c_void_p(self._g_lr_t.data_ptr()), ADAM_B1, ADAM_B2,
+                        C.c_void_p(self.norm_sq.data_ptr()), float(self.clip_norm), C.c_void_p(self._g_lr_t.data_ptr()), ADAM_B1, ADAM_B2,
                         ADAM_EPS, sp), "vqa_clip_adam_dev")
                 except Exception:
                     self.lib.vqa_graph_capture_abort(sp)
