@@ -296,8 +296,8 @@ def test_trainer_standard_clips_at_a_quarter_and_inference_restores_a_checkpoint
     ratio = float(m_s.abs().max() / m_20.abs().max())
     assert abs(ratio - (0.25 / norm) / (20.0 / max(norm, 20.0))) <= 1e-3 * ratio
     ts.train()
-    ckpt = os.path.join(cs.train_dir, "model-7")
-    assert os.path.exists(ckpt)
+    ckpt = os.path.join(cs.train_dir, "model-8")            # s = 6 of the loop, one manual step before it
+    assert os.path.exists(ckpt) and os.path.exists(os.path.join(cs.train_dir, "model-2"))
     ic = inference.get_default_config()
     ic.checkpoint, ic.model_type, ic.batch_size = ckpt, "standard", 32
     ic.tf_record_dir, ic.vfeat_path, ic.vocab, ic.answer_dict, ic.synthetic = cs.tf_record_dir, None, c.vocab, c.answer_dict, 1
