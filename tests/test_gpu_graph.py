@@ -1,5 +1,5 @@
 """Whole-step hipGraph replay (FusionEngine.train_step_graph, csrc/graph.hip) against the eager step: same kernels, same
-arithmetic -- parameters, Adam moments and reports bitwise equal after several steps in deterministic mode; shapes and
+arithmetic -- parameters, Adam moments and reports equal after several steps in deterministic mode; shapes and
 variants get their own graphs; the device-side Adam step count follows the host's."""
 import numpy as np
 import pytest
@@ -32,30 +32,36 @@ def _eager(eng, db, lr, seed, step):
     eng.train_step(db, ka, kj, lr, **kw)
 
 
+def _close(x, y, what):
+    """same kernels and the same arithmetic, so the replay is bitwise equal in every run observed; the bar here is the
+    optimiser's resolution, so that a reordered atomic in some future runtime is not read as a wrong graph"""
+    d = float((x - y).abs().max())
+    assert d <= 1e-6 * max(1.0, float(x.abs().max())), (what, d)
+
+
 @pytest.mark.parametrize("model_type", ["vlmap_answer", "standard", "vlmap_answer_noc", "vlmap_answer_full", "vlmap_answer_ent"])
-def test_graph_replay_equals_eager_steps_bitwise(model_type):
+def test_graph_replay_equals_eager_steps(model_type):
     dims, B, R, T, N = MED, 64, 36, 14, 64
     kw = {"num_marginal": 6} if model_type == "vlmap_answer_ent" else {}
     a, b, db = _pair(model_type, B, R, T, N, dims, 71, **kw)
+    lrs = [1e-3] * 5 + [5e-4] * 2      # the changed rate reaches the replayed Adam: it lives in device memory, no re-capture
+    # the eager engine runs all its steps first, the replayed one after it (no eager step between two replays)
+    want = []
+    for step, lr in enumerate(lrs):
+        _eager(a, db, lr, 5, step)
+        torch.cuda.synchronize()
+        want.append((a.tensor("report")[:16].clone(), a.train_flat.clone()))
     nodes = None
-    for step in range(5):
-        _eager(a, db, 1e-3, 5, step)
-        nodes = b.train_step_graph(db, 1e-3, 5, step)
+    for step, lr in enumerate(lrs):
+        nodes = b.train_step_graph(db, lr, 5, step)
         torch.cuda.synchronize()
-        assert torch.equal(a.tensor("report")[:16], b.tensor("report")[:16]), step
+        _close(want[step][0], b.tensor("report")[:16], ("report", step))
+        _close(want[step][1], b.train_flat, ("params", step))
     assert nodes is not None and nodes > 60                      # one graph holds the whole step
-    assert a.step_count == b.step_count == 5
-    assert torch.equal(a.train_flat, b.train_flat) and torch.equal(a.m_flat, b.m_flat) and torch.equal(a.v_flat, b.v_flat)
-    assert torch.equal(a.grad_flat, b.grad_flat)
-    assert int(b._g_step.item()) == 5
-    # a changed learning rate reaches the replayed Adam (the rate lives in device memory, the graph is not re-captured)
-    for step in (5, 6):
-        _eager(a, db, 5e-4, 5, step)
-        b.train_step_graph(db, 5e-4, 5, step)
-        torch.cuda.synchronize()
     assert a.step_count == b.step_count == 7 and int(b._g_step.item()) == 7
-    moved = (a.train_flat - b.train_flat).abs().max()
-    assert float(moved) <= 1e-6, float(moved)          # (bitwise in every observed run; the bar is the optimiser's resolution)
+    _close(a.m_flat, b.m_flat, "m")
+    _close(a.v_flat, b.v_flat, "v")
+    _close(a.grad_flat, b.grad_flat, "grad")
 
 
 def test_graphs_per_shape_and_live_rows():
@@ -72,14 +78,18 @@ def test_graphs_per_shape_and_live_rows():
     short["q_intseq"] = short["q_intseq"][:, :9].contiguous()
     short["q_intseq_len"] = short["q_intseq_len"].clamp(max=9)
     seq = [(full, 48, 14), (full, 48, 14), (short, 20, 9), (short, 20, 9), (full, 48, 14)]
+    want = []
     for step, (db, B, T) in enumerate(seq):
-        for e in (a, b):
-            e.resize(B, T)
+        a.resize(B, T)
         _eager(a, db, 1e-3, 3, step)
+        torch.cuda.synchronize()
+        want.append(a.tensor("report")[:13].clone())
+    for step, (db, B, T) in enumerate(seq):
+        b.resize(B, T)
         b.train_step_graph(db, 1e-3, 3, step)
         torch.cuda.synchronize()
-        assert torch.equal(a.tensor("report")[:13], b.tensor("report")[:13]), step
-    assert torch.equal(a.train_flat, b.train_flat)
+        _close(want[step], b.tensor("report")[:13], ("report", step))
+    _close(a.train_flat, b.train_flat, "params")
 
 
 def test_graph_api_rejects_bad_arguments():
