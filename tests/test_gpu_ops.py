@@ -670,6 +670,56 @@ def test_persistent_gru_forward_equals_stepwise(T, B, H):
                                           P(outs[0][4]), T, B, 300, P(torch.zeros(64, dtype=torch.int32, device="cuda")), None) == -4
 
 
+@pytest.mark.parametrize("T,B", [(14, 512), (5, 300), (3, 40), (4, 20), (1, 512), (7, 481)])
+def test_weight_stationary_gru_forward_equals_stepwise(T, B):
+    """vqa_gru_seq_fwd_ws (csrc/gru_ws.hip: one launch, recurrent weights resident in registers and LDS, eight
+    XCD-local chains of two 32-row half-chains in anti-phase) computes the recurrence of the per-step kernels -- hs, r, u,
+    c, r*h to rounding, every counter at its final value, no barrier time-out -- with full chains, ragged last chains,
+    a single half-chain (B <= 32 rows in a chain), empty chains, rows of length 0 and T, and twice in a row on the same
+    workspace (the fragment buffers and counters of one call must not leak into the next)."""
+    import ctypes as C
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    H = 1024
+    if lib.vqa_gru_ws_supported(T, B, H) != 1:
+        pytest.skip("the weight-stationary recurrence does not apply on this device")
+    g = torch.Generator(device="cuda").manual_seed(T * 1000 + B)
+    Wg = torch.randn(H, 2 * H, device="cuda", generator=g) * 0.04
+    Wc = torch.randn(H, H, device="cuda", generator=g) * 0.04
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ws = torch.full((int(lib.vqa_gru_ws_workspace_bytes(T)) // 4,), float("nan"), device="cuda")
+    for rep in range(2):
+        xp = torch.randn(T, B, 3 * H, device="cuda", generator=g) * 0.3
+        ln = torch.randint(0, T + 1, (B,), dtype=torch.int32, device="cuda", generator=g)
+        ln[0], ln[1] = T, 0
+        h0 = torch.randn(B, H, device="cuda", generator=g) * 0.1
+        outs = []
+        for stationary in (False, True):
+            hs = torch.full((T + 1, B, H), float("nan"), device="cuda")
+            hs[0] = h0
+            r, u, c, rh = (torch.full((T, B, H), float("nan"), device="cuda") for _ in range(4))
+            if stationary:
+                _lib.check(lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(ws), None), "ws")
+                torch.cuda.synchronize()
+                words = ws[:512].view(torch.int32)
+                assert int(words[256]) == 0                                   # no barrier time-out
+                for chain in range(8):
+                    rows = min(max(B - 64 * chain, 0), 64)
+                    for half in range(2):
+                        want = 32 * (1 + 2 * T) if rows > 32 * half else 0    # 32 CUs x (h_0 + 2 sub-phases per step)
+                        assert int(words[16 * (2 * chain + half)]) == want, (chain, half)
+            else:
+                _lib.check(lib.vqa_gru_seq_fwd(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, None), "stepwise")
+                torch.cuda.synchronize()
+            outs.append((hs, r, u, c, rh))
+        for name, a, b in zip(("hs", "r", "u", "c", "rh"), outs[0], outs[1]):
+            assert not torch.isnan(b).any(), name
+            torch.testing.assert_close(b, a, rtol=1e-5, atol=2e-6, msg=lambda m: name + ": " + m)
+    assert lib.vqa_gru_ws_supported(T, B, 512) == 0 and lib.vqa_gru_ws_supported(T, 513, H) == 0 and lib.vqa_gru_ws_supported(0, B, H) == 0
+    assert lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, 513, H, P(ws), None) == -4
+    assert lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, None, None) == -1
+
+
 def test_experimental_bf16x3_gemm_is_f32_equivalent():
     """csrc/gemm_bf16x3.hip (experiment, not on the default path): three-way bf16 splits + six bf16 MFMA products per
     a*b.  Its error against float64 must be of the order of the exact-f32 MFMA kernel's own (a few f32 ulps of the

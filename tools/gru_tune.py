@@ -88,6 +88,38 @@ if os.environ.get("PERSIST") == "1":
         print("  forward: stepwise %.1f us   persistent %.1f us" % (tm(fwd), tm(fwd_persistent)), flush=True)
     sys.exit(0)
 
+if os.environ.get("WS") == "1":
+    # weight-stationary persistent forward (csrc/gru_ws.hip) against the step kernels: results, phase stamps, time
+    if lib.vqa_gru_ws_supported(T, B, H) != 1:
+        print("weight-stationary recurrence does not apply here"); sys.exit(0)
+    ws = torch.empty(int(lib.vqa_gru_ws_workspace_bytes(T)) // 4, dtype=torch.float32, device="cuda").fill_(float("nan"))
+
+    def fwd_ws():
+        _lib.check(lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(ws), None), "fwd_ws")
+
+    fwd(); torch.cuda.synchronize()
+    ref = [x.clone() for x in (hs, r, u, c, rh)]
+    for x in (r, u, c, rh):
+        x.fill_(float("nan"))
+    hs[1:].fill_(float("nan"))
+    stamps = torch.zeros(3 * 4 * T + 16, dtype=torch.int64, device="cuda")
+    lib.vqa_gru_ws_set_stamps(P(stamps)); fwd_ws(); torch.cuda.synchronize(); lib.vqa_gru_ws_set_stamps(None)
+    words = ws[:512].view(torch.int32)
+    print("ws: counters", words[0:256:16].tolist(), "error word", int(words[256]), flush=True)
+    for name, a, b in zip(("hs", "r", "u", "c", "rh"), ref, (hs, r, u, c, rh)):
+        print("  max |%s - stepwise| = %.3e  (max |.| %.3e)" % (name, float((a - b).abs().max()), float(a.abs().max())), flush=True)
+    st = stamps.cpu().numpy().astype("float64") / 100.0
+    nsub = 4 if B > 32 else 2
+    t0 = st[0]
+    names = ["G0", "G1", "C0", "C1"] if nsub == 4 else ["G0", "C0"]
+    for k in range(min(nsub * T, 12)):
+        a0, a1, a2 = st[3 * k: 3 * k + 3]
+        print("    %s t=%d  start %7.2f  compute %6.2f  reduce+epilogue+arrive %6.2f" % (names[k % nsub], k // nsub, a0 - t0, a1 - a0, a2 - a1))
+    print("    ... last sub-phase ends at %.2f us" % (st[3 * (nsub * T - 1) + 2] - t0), flush=True)
+    for rep in range(3):
+        print("  forward: stepwise %.1f us   weight-stationary %.1f us" % (tm(fwd), tm(fwd_ws)), flush=True)
+    sys.exit(0)
+
 if os.environ.get("GRAPH") == "1":
     # does replaying the 28-kernel chain from a captured graph shorten the gaps between its dependent kernels?
     def on_stream(fn_name, args):

@@ -115,6 +115,11 @@ SIGNATURES = {
     "vqa_gru_persistent_sync_bytes": (_L, []),
     "vqa_gru_set_persistent": (_I, [_I]),
     "vqa_gru_persistent_set_census": (_I, [_P]),
+    "vqa_gru_seq_fwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "vqa_gru_ws_supported": (_I, [_I, _I, _I]),
+    "vqa_gru_ws_workspace_bytes": (_L, [_I]),
+    "vqa_gru_ws_set_mode": (_I, [_I]),
+    "vqa_gru_ws_set_stamps": (_I, [_P]),
     "vqa_gru_seq_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
