@@ -674,7 +674,7 @@ def test_persistent_gru_forward_equals_stepwise(T, B, H):
 def test_weight_stationary_gru_forward_equals_stepwise(T, B):
     """vqa_gru_seq_fwd_ws (csrc/gru_ws.hip: one launch, recurrent weights resident in registers and LDS, eight
     XCD-local chains of two 32-row half-chains in anti-phase) computes the recurrence of the per-step kernels -- hs, r, u,
-    c, r*h to rounding, every counter at its final value, no barrier time-out -- with full chains, ragged last chains,
+    c, r*h to rounding, every flag at its final epoch, no barrier time-out -- with full chains, ragged last chains,
     a single half-chain (B <= 32 rows in a chain), empty chains, rows of length 0 and T, and twice in a row on the same
     workspace (the fragment buffers and counters of one call must not leak into the next)."""
     import ctypes as C
@@ -701,13 +701,17 @@ def test_weight_stationary_gru_forward_equals_stepwise(T, B):
             if stationary:
                 _lib.check(lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(ws), None), "ws")
                 torch.cuda.synchronize()
-                words = ws[:512].view(torch.int32)
-                assert int(words[256]) == 0                                   # no barrier time-out
-                for chain in range(8):
-                    rows = min(max(B - 64 * chain, 0), 64)
+                words = ws[:1024].view(torch.int32)
+                assert int(words[512]) == 0                                   # no barrier time-out
+                assert words[576:584].tolist() == [32] * 8                    # every XCD hosted 32 of the 256 workgroups
+                for chain in range(8):      # a flag per (half-chain, CU): h_0 + 2 sub-phases per step handed off
+                    if B > 256:             # chains of 64 rows; a live chain runs both of its half-chains
+                        want = [1 + 2 * T if B > 64 * chain else 0] * 2
+                    else:                   # chains of 32 rows, one half-chain each
+                        want = [1 + 2 * T if B > 32 * chain else 0, 0]
                     for half in range(2):
-                        want = 32 * (1 + 2 * T) if rows > 32 * half else 0    # 32 CUs x (h_0 + 2 sub-phases per step)
-                        assert int(words[16 * (2 * chain + half)]) == want, (chain, half)
+                        line = words[32 * (2 * chain + half): 32 * (2 * chain + half) + 32].tolist()
+                        assert line == [want[half]] * 32, (chain, half, line)
             else:
                 _lib.check(lib.vqa_gru_seq_fwd(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, None), "stepwise")
                 torch.cuda.synchronize()

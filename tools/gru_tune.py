@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -97,25 +98,44 @@ if os.environ.get("WS") == "1":
     def fwd_ws():
         _lib.check(lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(ws), None), "fwd_ws")
 
+    lib.vqa_gru_ws_set_form(int(os.environ.get("WS_FORM", 0)))      # 1: plain sub-phase order (stamps only there)
     fwd(); torch.cuda.synchronize()
     ref = [x.clone() for x in (hs, r, u, c, rh)]
     for x in (r, u, c, rh):
         x.fill_(float("nan"))
     hs[1:].fill_(float("nan"))
-    stamps = torch.zeros(3 * 4 * T + 16, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(2048, dtype=torch.int64, device="cuda")
     lib.vqa_gru_ws_set_stamps(P(stamps)); fwd_ws(); torch.cuda.synchronize(); lib.vqa_gru_ws_set_stamps(None)
-    words = ws[:512].view(torch.int32)
-    print("ws: counters", words[0:256:16].tolist(), "error word", int(words[256]), flush=True)
+    words = ws[:1024].view(torch.int32)
+    print("ws: flags (min, max per half-chain)", [(int(words[32 * i: 32 * i + 32].min()), int(words[32 * i: 32 * i + 32].max())) for i in range(16)],
+          "error word", int(words[512]), "workgroups per XCD", words[576:584].tolist(), flush=True)
     for name, a, b in zip(("hs", "r", "u", "c", "rh"), ref, (hs, r, u, c, rh)):
         print("  max |%s - stepwise| = %.3e  (max |.| %.3e)" % (name, float((a - b).abs().max()), float(a.abs().max())), flush=True)
     st = stamps.cpu().numpy().astype("float64") / 100.0
-    nsub = 4 if B > 32 else 2
+    nsub = 4 if B > 256 else 2
     t0 = st[0]
     names = ["G0", "G1", "C0", "C1"] if nsub == 4 else ["G0", "C0"]
-    for k in range(min(nsub * T, 12)):
+    for k in range(min(nsub * T, 12) if (st[2] > 0 and (B <= 256 or os.environ.get("WS_FORM") == "1")) else 0):
         a0, a1, a2 = st[3 * k: 3 * k + 3]
         print("    %s t=%d  start %7.2f  compute %6.2f  reduce+epilogue+arrive %6.2f" % (names[k % nsub], k // nsub, a0 - t0, a1 - a0, a2 - a1))
-    print("    ... last sub-phase ends at %.2f us" % (st[3 * (nsub * T - 1) + 2] - t0), flush=True)
+    if st[2] > 0 and (B <= 256 or os.environ.get("WS_FORM") == "1"):
+        print("    ... last sub-phase ends at %.2f us" % (st[3 * (nsub * T - 1) + 2] - t0), flush=True)
+    elif st[2] > 0:     # the spliced form stamps the start of every matrix stream (G0 G1 C0 C1 per step) and the end:
+        raw = stamps.cpu().numpy().astype("float64")            # (100 MHz wall clock, shader clock) pairs
+        wall, cyc = raw[0:8 * T + 2:2] / 100.0, raw[1:8 * T + 2:2]
+        d, dc = wall[1:] - wall[:-1], cyc[1:] - cyc[:-1]
+        for t in range(T):
+            print("    t=%2d  G0 %5.2f  G1 %5.2f  C0 %5.2f  C1 %5.2f us  (step %5.2f us)   cycles %6d %6d %6d %6d   clock %.2f GHz" % (
+                (t,) + tuple(d[4 * t: 4 * t + 4]) + (d[4 * t: 4 * t + 4].sum(),) + tuple(int(x) for x in dc[4 * t: 4 * t + 4]) +
+                (dc[4 * t: 4 * t + 4].sum() / d[4 * t: 4 * t + 4].sum() / 1e3,)))
+        print("    all streams %.2f us; a gate stream is 256 MFMAs per wave = 16384 cycles, a candidate stream 8192" % (wall[-1] - wall[0]), flush=True)
+        sl = stamps[1024:1536].cpu().numpy().astype("int64")
+        if sl.any():        # a -DWS_SLOTS=1 build: cycles per slot of step 5 (a slot = 2 MFMAs in G streams, 1 in C streams)
+            for si, nm in enumerate(("G0", "G1", "C0", "C1")):
+                d = np.diff(sl[128 * si: 128 * si + 128])
+                print("    %s slot cycles (slot 1..127; tail micro-step k runs in slot k + 4):" % nm)
+                for r0 in range(0, 127, 16):
+                    print("      %3d: %s" % (r0 + 1, " ".join("%4d" % x for x in d[r0: r0 + 16])))
     for rep in range(3):
         print("  forward: stepwise %.1f us   weight-stationary %.1f us" % (tm(fwd), tm(fwd_ws)), flush=True)
     sys.exit(0)

@@ -119,6 +119,7 @@ SIGNATURES = {
     "vqa_gru_ws_supported": (_I, [_I, _I, _I]),
     "vqa_gru_ws_workspace_bytes": (_L, [_I]),
     "vqa_gru_ws_set_mode": (_I, [_I]),
+    "vqa_gru_ws_set_form": (_I, [_I]),
     "vqa_gru_ws_set_stamps": (_I, [_P]),
     "vqa_gru_seq_fwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "vqa_gru_seq_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

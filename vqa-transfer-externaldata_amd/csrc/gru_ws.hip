@@ -33,6 +33,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// timing-only builds (results are garbage): tail micro-steps switched off by group -- 1 LDS spill / barrier / fetch,
+// 2 gate math, 4 stores, 8 arrival + peek + settle, 16 xp fetch (tools/gru_tune.py WS=1 with VQA_HOT_LIB)
+#ifndef WS_DBG
+#define WS_DBG 0
+#endif
+// operand fragments in flight per wave in the spliced form (its tails' stores and slow loads sit in the same in-order
+// queue as the fragment loads: the deeper ring is their cover)
+#ifndef WS_SLOTS
+#define WS_SLOTS 0      // timing study: shader-clock stamp in every slot of step 5's four streams (tools/gru_tune.py WS_SLOTS=1)
+#endif
+#ifndef WS_RING2
+#define WS_RING2 8      // (8 or 16: the ring carries over from stream to stream, so its depth divides the 32 octets)
+#endif
+
 namespace {
 
 constexpr int WS_H = 1024;
@@ -44,9 +58,6 @@ constexpr int WS_SC1 = 16;
 // of each flavour), and the 32 consumers of the same XCD then fetch it at the cross-XCD rate -- measured: the k loops
 // ran at half the matrix rate.  A plain store keeps the line in this L2, where every consumer of the chain reads it;
 // the bytes still leave for memory, so a workgroup that was ever placed on another XCD misses and reads them there.
-#ifndef WS_HANDOFF_SC1
-#define WS_HANDOFF_SC1 false
-#endif
 constexpr int WS_FRAG_T = WS_CHAINS * 2 * 128 * 256;      // floats of one time step's fragment buffer (2 MB)
 constexpr size_t WS_LDS = (32768 + 8192) * sizeof(float); // candidate slab + reduction scratch = 160 KB
 
@@ -58,10 +69,13 @@ struct WsArgs {
     float *hs, *r, *u, *c, *rh;   // hs [T+1,B,H] (hs[0] given), tape [T,B,H]
     float* hF;            // [T+1] fragment-order copies of h_t      (hand-off)
     float* rhF;           // [T]   fragment-order copies of r * h    (hand-off)
-    unsigned* sync;       // counters at [16 * (2 * chain + half)], error word at [256]
+    unsigned* sync;       // flags at [32 * (2 * chain + half) + slab], error word at [512], placement counters at [576 + xcd]
     int T, B;
+    int chain_rows;       // 64: two 32-row half-chains per XCD (B > 256); 32: one (B <= 256, all eight XCDs busy)
     unsigned spin_limit;
     unsigned long long* stamps;   // optional timing study: workgroup 0 records (wait, compute, done) per sub-phase
+    int handoff_sc1;      // tuning: hand-offs as write-through stores (drops the line from the XCD's L2)
+    int dbg;              // timing study (results garbage): 1 tape stores dropped, 2 hand-off stores dropped, 4 xp loads dropped
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rs(const float* p, int64_t bytes) {
@@ -79,23 +93,70 @@ __device__ __forceinline__ void ws_store(__amdgpu_buffer_rsrc_t rs, unsigned off
     if (sc1) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, WS_SC1);
     else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
 }
-__device__ __forceinline__ void ws_arrive(unsigned* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Arrival and wait.  A half-chain has one 128-byte line of 32 flags, one per column slab (= CU of the chain's XCD); a
+// workgroup's flag holds how many of the half-chain's sub-phases it has handed off: 1 after h_0, then +1 per sub-phase.
+//   arrive: every wave has drained its stores, workgroup barrier, ONE plain 4-byte store (completes at the XCD's L2).
+//   wait:   wave 0 loads the 32 flags in one L1-bypassing (sc1) request, all of them must have reached the epoch.
+// No atomic in the steady state: a global atomic executes at the memory side (MI355X_MICROARCH.md), and since a wave's
+// vector-memory operations complete in order, a 1-2 us atomic in the queue held up every later wait for an operand
+// fragment -- the sub-phase tails cost as much inside the matrix stream as outside it until the counters became flags.
+__device__ __forceinline__ void ws_flag_store(unsigned* line, int slab, unsigned epoch) {
+    if (threadIdx.x == 0) __hip_atomic_store(line + slab, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void ws_wait(unsigned* ctr, unsigned target, unsigned* err, unsigned limit) {
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+__device__ __forceinline__ unsigned ws_flag_load(const unsigned* line) {      // lanes 0..31 of a wave: one flag each
+    return __hip_atomic_load(line + (threadIdx.x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ws_flags_reached(unsigned v, unsigned epoch) {
+    return __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;
+}
+__device__ __forceinline__ void ws_spin(const unsigned* line, unsigned epoch, unsigned* err, unsigned limit) {   // wave 0
+    unsigned spins = 0;
+    while (!ws_flags_reached(ws_flag_load(line), epoch)) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
         }
     }
+}
+__device__ __forceinline__ void ws_arrive(unsigned* line, int slab, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ws_flag_store(line, slab, epoch);
+}
+__device__ __forceinline__ void ws_wait(const unsigned* line, unsigned epoch, unsigned* err, unsigned limit) {
+    if (threadIdx.x < 64) ws_spin(line, epoch, err, limit);
+    __syncthreads();
+}
+
+// Which chain and which column slab a workgroup is: chain = the XCD it RUNS on (hardware id), slab = the order in which
+// the workgroups of that XCD get here (one atomic per workgroup).  All 8 x 32 workgroups are resident at once and a CU
+// holds one of them (160 KB of LDS each), so every XCD hosts exactly 32: a chain's hand-offs, counters and plain
+// loads / stores then stay inside one L2 by construction, whatever order the dispatcher dealt the workgroups in.
+__device__ __forceinline__ void ws_place(unsigned* sync, int* place, int& chain, int& slab) {      // place: 2 words of LDS
+    if (threadIdx.x == 0) {
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);      // HW_REG_XCC_ID[3:0]
+        place[0] = xcc;
+        place[1] = (int)__hip_atomic_fetch_add(sync + 576 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    chain = __builtin_amdgcn_readfirstlane(place[0]);
+    slab = __builtin_amdgcn_readfirstlane(place[1]);
+    __syncthreads();
+}
+
+// Gate math on the hardware's own exp2 and reciprocal (1 ulp each): a wave's vector-ALU instructions do NOT run in the
+// shadow of its own MFMAs -- each costs its 5-8 issue cycles on top of the matrix stream (tools/micro/mfma_gap.hip:
+// 64.0 cycles per MFMA alone, 87.3 with 8 independent v_fma per MFMA pair; LDS writes and s_nop ride for free) -- so
+// the tails are priced by their VALU count: 6 instructions for a sigmoid instead of the ~30 of expf() and an IEEE
+// division, 7 for a tanh.  Values within ~2e-7 of sigmoidf_stable() / tanhf() (the per-step kernels' forms).
+__device__ __forceinline__ float ws_sigmoid(float x) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * __builtin_fabsf(x));      // exp(-|x|) in (0, 1]
+    return (x >= 0.f ? 1.f : e) * __builtin_amdgcn_rcpf(1.f + e);
+}
+__device__ __forceinline__ float ws_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * __builtin_fabsf(x));      // exp(-2|x|)
+    return __builtin_copysignf((1.f - e) * __builtin_amdgcn_rcpf(1.f + e), x);
 }
 
 #define WS_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -105,7 +166,9 @@ __device__ __forceinline__ void ws_wait(unsigned* ctr, unsigned target, unsigned
 // does not see an MFMA in the asm, so the read-after-MFMA wait states are spelled out where the tile is first read.
 #define WS_MFMA_AGPR_B(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define WS_MFMA_VGPR_B(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define WS_MFMA_AGPR_B0(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))   // C = 0
 constexpr int WS_AG_OCT = 28;       // octets of a wave's k quarter whose fragments sit in AGPRs (8 each); the rest in VGPRs
+// (all 32 would fill the 256 AGPRs to the last one; the allocator then spills to find itself a temporary)
 #define WS_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
@@ -114,11 +177,12 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
     float* S = smem + 32768;            // reduction scratch (8192 floats)
     constexpr int H = WS_H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int chain = blockIdx.x & 7, j = blockIdx.x >> 3;       // XCD, column slab
+    int chain, j;                       // XCD, column slab
+    ws_place(a.sync, reinterpret_cast<int*>(S), chain, j);
     const int B = a.B, T = a.T;
-    const int row_base = chain * 64;
-    const int halves = (B - row_base > 32) ? 2 : 1;              // 32-row half-chains with any row in the batch
-    unsigned* err = a.sync + 256;
+    const int row_base = chain * a.chain_rows;
+    const int halves = (a.chain_rows == 64 && B - row_base > 32) ? 2 : 1;      // 32-row half-chains with any row in the batch
+    unsigned* err = a.sync + 512;
     if (row_base >= B) return;          // a chain with no rows: nobody waits for it (counters are per chain)
 
     // ---- recurrent weights, once: gate slabs into registers, candidate slab into LDS
@@ -166,10 +230,10 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
         h_own[hf] = ok[hf] ? ws_load(rs_hs, o_std[hf]) : (f32x4n)(0.f);
         u_own[hf] = (f32x4n)(0.f);
         len_own[hf] = ok[hf] ? a.len[grow] : 0;
-        if (hf < halves) ws_store(rs_hF, frag_st(0, hf), h_own[hf], WS_HANDOFF_SC1);
+        if (hf < halves) ws_store(rs_hF, frag_st(0, hf), h_own[hf], a.handoff_sc1 != 0);
     }
     __syncthreads();                    // the candidate slab is in LDS
-    for (int hf = 0; hf < halves; ++hf) ws_arrive(a.sync + 16 * (2 * chain + hf));
+    for (int hf = 0; hf < halves; ++hf) ws_arrive(a.sync + 32 * (2 * chain + hf), j, 1u);
 
     f32x4n ring[WS_RING];
     auto fill = [&](__amdgpu_buffer_rsrc_t rs, unsigned base) {
@@ -179,7 +243,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
     unsigned long long* stamp = (a.stamps != nullptr && blockIdx.x == 0 && tid == 0) ? a.stamps : nullptr;
 
     // the first sub-phase's operand: G(0, 0) needs every CU's share of h_0
-    ws_wait(a.sync + 16 * (2 * chain), WS_CU, err, a.spin_limit);
+    ws_wait(a.sync + 32 * (2 * chain), 1u, err, a.spin_limit);
     fill(rs_hF, frag_ld(0, 0));
 
     for (int t = 0; t < T; ++t) {
@@ -187,7 +251,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             if (hf < halves) {
-                unsigned* ctr = a.sync + 16 * (2 * chain + hf);
+                unsigned* ctr = a.sync + 32 * (2 * chain + hf);
                 const unsigned base = frag_ld(t, hf);
                 const unsigned oxp = ok[hf] ? (unsigned)((((int64_t)t * B + row_base + 32 * hf + e_row) * 3 * H + 32 * j + e_col) * 4) : 0xFFFFFFF0u;
                 const f32x4n xr = ws_load(rs_xp, oxp), xu = ws_load(rs_xp, ok[hf] ? oxp + H * 4 : 0xFFFFFFF0u);
@@ -217,8 +281,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
                 if (stamp) stamp[1] = wall_clock64();
                 // ---- what comes next on this CU: G(1,t) after G(0,t); C(0,t) after G(1,t) (or after G(0,t) alone)
                 if (halves == 2) {      // its producers finished a sub-phase ago: fetch its first fragments now
-                    if (hf == 0) { ws_wait(a.sync + 16 * (2 * chain + 1), WS_CU * (1 + 2 * t), err, a.spin_limit); fill(rs_hF, frag_ld(t, 1)); }
-                    else { ws_wait(a.sync + 16 * (2 * chain), WS_CU * (2 + 2 * t), err, a.spin_limit); fill(rs_rhF, frag_ld(t, 0)); }
+                    if (hf == 0) { ws_wait(a.sync + 32 * (2 * chain + 1), 1u + 2 * t, err, a.spin_limit); fill(rs_hF, frag_ld(t, 1)); }
+                    else { ws_wait(a.sync + 32 * (2 * chain), 2u + 2 * t, err, a.spin_limit); fill(rs_rhF, frag_ld(t, 0)); }
                 }
                 // ---- the four k quarters meet in LDS: S[wave][row][64], float4 slots XOR-swizzled by row
 #pragma unroll
@@ -246,20 +310,20 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
                 f32x4n rhv;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    rv[i] = sigmoidf_stable(rv[i]);
-                    uv[i] = sigmoidf_stable(uv[i]);
+                    rv[i] = ws_sigmoid(rv[i]);
+                    uv[i] = ws_sigmoid(uv[i]);
                     rhv[i] = rv[i] * h_own[hf][i];
                 }
                 u_own[hf] = uv;
-                ws_store(rs_rhF, frag_st(t, hf), rhv, WS_HANDOFF_SC1);
+                ws_store(rs_rhF, frag_st(t, hf), rhv, a.handoff_sc1 != 0);
                 if (ok[hf]) {
                     const unsigned o = (unsigned)(t * BH * 4) + o_std[hf];
                     ws_store(rs_r, o, rv, false);
                     ws_store(rs_u, o, uv, false);
                     ws_store(rs_rh, o, rhv, false);
                 }
-                ws_arrive(ctr);         // (its barrier also frees the scratch for the next sub-phase)
-                if (halves == 1) { ws_wait(ctr, WS_CU * (2 + 2 * t), err, a.spin_limit); fill(rs_rhF, frag_ld(t, 0)); }
+                ws_arrive(ctr, j, 2u + 2 * t);          // (its barrier also frees the scratch for the next sub-phase)
+                if (halves == 1) { ws_wait(ctr, 2u + 2 * t, err, a.spin_limit); fill(rs_rhF, frag_ld(t, 0)); }
                 if (stamp) { stamp[2] = wall_clock64(); stamp += 3; }
             }
         }
@@ -267,7 +331,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             if (hf < halves) {
-                unsigned* ctr = a.sync + 16 * (2 * chain + hf);
+                unsigned* ctr = a.sync + 32 * (2 * chain + hf);
                 const unsigned base = frag_ld(t, hf);
                 const f32x4n xc = ws_load(rs_xp, ok[hf] ? (unsigned)((((int64_t)t * B + row_base + 32 * hf + e_row) * 3 * H + 2 * H + 32 * j + e_col) * 4) : 0xFFFFFFF0u);
                 if (stamp) stamp[0] = wall_clock64();
@@ -295,8 +359,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
                 if (stamp) stamp[1] = wall_clock64();
                 // ---- next on this CU: C(1,t) after C(0,t); G(0,t+1) after C(1,t) (or after C(0,t) alone)
                 if (halves == 2) {
-                    if (hf == 0) { ws_wait(a.sync + 16 * (2 * chain + 1), WS_CU * (2 + 2 * t), err, a.spin_limit); fill(rs_rhF, frag_ld(t, 1)); }
-                    else if (t + 1 < T) { ws_wait(a.sync + 16 * (2 * chain), WS_CU * (3 + 2 * t), err, a.spin_limit); fill(rs_hF, frag_ld(t + 1, 0)); }
+                    if (hf == 0) { ws_wait(a.sync + 32 * (2 * chain + 1), 2u + 2 * t, err, a.spin_limit); fill(rs_rhF, frag_ld(t, 1)); }
+                    else if (t + 1 < T) { ws_wait(a.sync + 32 * (2 * chain), 3u + 2 * t, err, a.spin_limit); fill(rs_hF, frag_ld(t + 1, 0)); }
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
@@ -317,21 +381,383 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
                 f32x4n hn;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    cv[i] = tanhf(cv[i]);
+                    cv[i] = ws_tanh(cv[i]);
                     hn[i] = (t < len_own[hf]) ? (u_own[hf][i] * h_own[hf][i] + (1.f - u_own[hf][i]) * cv[i]) : h_own[hf][i];
                 }
                 h_own[hf] = hn;
-                ws_store(rs_hF, frag_st(t + 1, hf), hn, WS_HANDOFF_SC1);
+                ws_store(rs_hF, frag_st(t + 1, hf), hn, a.handoff_sc1 != 0);
                 if (ok[hf]) {
                     ws_store(rs_c, (unsigned)(t * BH * 4) + o_std[hf], cv, false);
                     ws_store(rs_hs, (unsigned)((t + 1) * BH * 4) + o_std[hf], hn, false);
                 }
-                ws_arrive(ctr);
-                if (halves == 1 && t + 1 < T) { ws_wait(ctr, WS_CU * (3 + 2 * t), err, a.spin_limit); fill(rs_hF, frag_ld(t + 1, 0)); }
+                ws_arrive(ctr, j, 3u + 2 * t);
+                if (halves == 1 && t + 1 < T) { ws_wait(ctr, 3u + 2 * t, err, a.spin_limit); fill(rs_hF, frag_ld(t + 1, 0)); }
                 if (stamp) { stamp[2] = wall_clock64(); stamp += 3; }
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two-half form with the epilogues INSIDE the matrix stream.  In the kernel above a sub-phase is
+// compute -> (poll, reduce, gate math, stores, drain, barrier, atomic) and the second part -- 1.4-2.3 us of every
+// 5.4-10.9 us sub-phase -- leaves the matrix cores idle.  A 32x32x2 MFMA occupies its SIMD's matrix core for 64 cycles
+// and the wave's issue port for 4, so here the tail of sub-phase X runs in the issue gaps of sub-phase X+1 (the other
+// half-chain), a few instructions per octet of k:
+//     octet 1  partial tiles of X -> LDS          octet 3  barrier, partial tiles back (one float4 per thread)
+//     octet 5  sums, gate math, stores            octet 9  drain the hand-off store, barrier, X's arrival
+//     octet 12 peek at the counter X+2 waits for  octet 22 (spin if it is not there yet,) barrier
+//     octets 24..31  the ring slots that X+1 has used up are refilled with the first fragments of X+2
+// so the operand ring never drains and a barrier never waits on memory (plain s_barrier: __syncthreads() would add
+// s_waitcnt vmcnt(0) and stall the stream for an L2 round trip each time).  X's arrival moves ~1-2 us into X+1; its
+// consumers are X+2 on every CU, which looks for it at octet 22 of X+1: no wait cycle (every CU passes octet 9 of
+// X+1 without waiting for anything later than X-1).
+__device__ __forceinline__ unsigned ws_uni(unsigned x) { return __builtin_amdgcn_readfirstlane(x); }      // a scalar offset
+__device__ __forceinline__ void ws_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void ws_bar() { asm volatile("s_barrier" ::: "memory"); }
+
+// loads / stores with the uniform part of the address in the scalar offset (one VGPR of per-lane offset serves a whole
+// stream; left in the vector offset, the loop-invariant sums are hoisted into dozens of VGPRs and the weights spill)
+__device__ __forceinline__ f32x4n ws_load2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    f32x4n o;
+    o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
+    return o;
+}
+__device__ __forceinline__ void ws_store2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, f32x4n x, bool sc1) {
+    u32x4 v;
+    v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y); v.z = __float_as_uint(x.z); v.w = __float_as_uint(x.w);
+    if (sc1) __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, WS_SC1);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, 0);
+}
+
+__global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;
+    float* S = smem + 32768;
+    constexpr int H = WS_H;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int chain, j;
+    ws_place(a.sync, reinterpret_cast<int*>(S), chain, j);
+    const int B = a.B, T = a.T;
+    const int row_base = chain * 64;
+    unsigned* err = a.sync + 512;
+    if (row_base >= B) return;
+    unsigned* ctr0 = a.sync + 32 * (2 * chain);     // the two half-chains' flag lines
+    unsigned* ctr1 = ctr0 + 32;
+
+    float wg[2][32][4];
+    {
+        const float* p = a.Wg + (int64_t)(256 * w + 4 * (lane >> 5)) * (2 * H) + 32 * j + (lane & 31);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wg[cb][m][i] = p[(int64_t)(8 * m + i) * (2 * H) + cb * H];
+    }
+    for (int idx = tid; idx < 128 * 64; idx += WS_NT) {
+        const int oct = idx >> 6, l = idx & 63;
+        const float* p = a.Wc + (int64_t)(8 * oct + 4 * (l >> 5)) * H + 32 * j + (l & 31);
+        f32x4n v;
+        v.x = p[0]; v.y = p[H]; v.z = p[2 * H]; v.w = p[3 * H];
+        *reinterpret_cast<f32x4n*>(Wl + idx * 4) = v;
+    }
+
+    const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
+    const int64_t BH = (int64_t)B * H;
+    const __amdgpu_buffer_rsrc_t rs_hF = ws_rs(a.hF, (int64_t)(T + 1) * WS_FRAG_T * 4);
+    const __amdgpu_buffer_rsrc_t rs_rhF = ws_rs(a.rhF, (int64_t)T * WS_FRAG_T * 4);
+    const __amdgpu_buffer_rsrc_t rs_xp = ws_rs(a.xp, (int64_t)T * B * 3 * H * 4);
+    const __amdgpu_buffer_rsrc_t rs_hs = ws_rs(a.hs, (T + 1) * BH * 4);
+    const __amdgpu_buffer_rsrc_t rs_r = ws_rs(a.r, T * BH * 4), rs_u = ws_rs(a.u, T * BH * 4);
+    const __amdgpu_buffer_rsrc_t rs_c = ws_rs(a.c, T * BH * 4), rs_rh = ws_rs(a.rh, T * BH * 4);
+    // fragment buffers: uniform (scalar) part of the offsets; the per-lane part is lane * 16
+    auto frag_ld = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 32 * w) * 1024); };
+    auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + w) * 1024); };
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    f32x4n h_own[2], u_own[2];
+    int len_own[2];
+    bool ok[2];
+    unsigned o_std[2], o_xp[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int grow = row_base + 32 * hf + e_row;
+        ok[hf] = grow < B;
+        o_std[hf] = (unsigned)(((int64_t)grow * H + 32 * j + e_col) * 4);
+        o_xp[hf] = (unsigned)(((int64_t)grow * 3 * H + 32 * j + e_col) * 4);
+        if (!ok[hf]) { o_std[hf] = 0xFFFFFFF0u; o_xp[hf] = 0xFFFFFFF0u; }       // past the end: loads give 0, stores vanish
+        h_own[hf] = ws_load(rs_hs, o_std[hf]);
+        u_own[hf] = (f32x4n)(0.f);
+        len_own[hf] = ok[hf] ? a.len[grow] : 0;
+        ws_store2(rs_hF, lane16, frag_st(0, hf), h_own[hf], a.handoff_sc1 != 0);
+    }
+    __syncthreads();
+    ws_arrive(ctr0, j, 1u);
+    ws_arrive(ctr1, j, 1u);
+    const unsigned lane16_st = (a.dbg & 2) ? 0xFFFFFFF0u : (unsigned)lane * 16u;
+    if (a.dbg & 1) { o_std[0] = 0xFFFFFFF0u; o_std[1] = 0xFFFFFFF0u; }
+    if (a.dbg & 4) { o_xp[0] = 0xFFFFFFF0u; o_xp[1] = 0xFFFFFFF0u; }
+
+    const unsigned xp_step = (unsigned)((int64_t)B * 3 * H * 4), bh_step = (unsigned)(BH * 4);
+    auto xp_soff = [&](int t, int part) { return (unsigned)t * xp_step + (unsigned)(part * H * 4); };
+    // LDS addresses of the partial-tile spills: accumulator register q of lane l is row rq + 4 (l >> 5), rq = (q & 3) +
+    // 8 (q >> 2), column l & 31.  The XOR swizzles below split into a per-lane part with four variants and a constant
+    // part, so four base registers per tile shape serve all sixteen q (sixteen independent addresses would be hoisted
+    // out of the time loop into as many VGPRs).
+    //   gate tiles  S[w][row][64]: slot (col >> 2 [+ 8 for u]) ^ (row & 15);  row & 15 = (q & 3) | hl << 2 | (q >> 2 & 1) << 3
+    //   cand tiles  S[w][row][32]: slot (col >> 2) ^ (row >> 1 & 7);           row >> 1 & 7 = (q >> 1 & 1) | hl << 1 | (q >> 2 & 1) << 2
+    int gbase[4], cbase[4];
+    {
+        const int hl = lane >> 5, cs = (lane & 31) >> 2, c3 = lane & 3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            gbase[v] = w * 2048 + (4 * hl) * 64 + (((cs ^ (hl << 2)) ^ v) << 2) + c3;
+            cbase[v] = w * 1024 + (4 * hl) * 32 + (((cs ^ (hl << 1)) ^ ((v & 1) | ((v >> 1) << 2))) << 2) + c3;
+        }
+    }
+    const int gfetch = e_row * 64 + (((e_col >> 2) ^ (e_row & 15)) << 2);           // u: the same slot ^ 8
+    const int cfetch = e_row * 32 + (((e_col >> 2) ^ ((e_row >> 1) & 7)) << 2);
+
+    // ---- the tail of a sub-phase, cut into micro-steps k = 0, 1, ... of a few instructions each; micro-step k runs in
+    // slot 4 + k of the NEXT sub-phase's matrix stream (a slot = the issue gap behind one MFMA of a candidate stream
+    // or behind a pair of a gate stream: 64 / 128 cycles in which the wave's other instructions are free to issue).
+    // An MFMA stalls at issue until the matrix core is free and everything behind it in program order waits with it,
+    // so work that is not cut up and placed between the MFMAs does not overlap with them at all.
+    //    (the xp values the tail adds are fetched in slot 100 of the tail's OWN stream: from the Infinity Cache they take
+    //     longer than the few slots of a candidate stream in front of the sums)
+    //    1..8     partial tile registers -> LDS (swizzled scratch), two accumulator registers per step
+    //    9        LDS drained, workgroup barrier
+    //    10..13   the four k quarters' partial float4s back from LDS
+    //    15, 16   sums (+ xp)
+    //    17..31   odd steps: one sigmoid / tanh each
+    //    33..39   rest of the gate math; the stores one per odd step, the hand-off store LAST
+    //    54       arrival (by then >= 2 younger vector-memory operations follow the hand-off store: vmcnt(2) covers it)
+    //    76       wave 0 loads the flags the sub-phase after this one waits for (the arrivals of slot 58 have landed)
+    //    92       settle them (spin only if some CU lags), barrier; slots 99.. fetch that sub-phase's first fragments
+    f32x4n va, vb, va2;
+    f32x4n xr[2], xu[2], xc[2];       // xp values of the running step (see xp_fetch)
+    f32x4n p0[4], p1[4];
+    // (no branches in the micro-steps: a row outside the batch, the tail that does not exist in front of the first
+    // step and the operand ring's look-ahead behind the last one all address past the end of their buffers, where a
+    // buffer store is dropped and a buffer load returns zeros)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto g_tail = [&](int k, int t, int hf, const f32x16& R, const f32x16& U, unsigned* ctr) {
+        if (!(WS_DBG & 1) && k >= 1 && k <= 8) {
+#pragma unroll
+            for (int q = 2 * (k - 1); q < 2 * k; ++q) {
+                const int rq = (q & 3) + 8 * (q >> 2), hi = (q >> 2) & 1;
+                S[gbase[q & 3] + rq * 64 + hi * 32] = R[q];
+                S[gbase[q & 3] + rq * 64 + (hi ^ 1) * 32] = U[q];
+            }
+        }
+        if (!(WS_DBG & 1) && k == 9) ws_lds_barrier();
+        if (!(WS_DBG & 1) && k >= 10 && k <= 13) {
+            const int g = k - 10;
+            p0[g] = *reinterpret_cast<const f32x4n*>(S + g * 2048 + gfetch);
+            p1[g] = *reinterpret_cast<const f32x4n*>(S + g * 2048 + (gfetch ^ 32));
+        }
+        if (!(WS_DBG & 2) && k == 15) va = xr[hf] + p0[0] + p0[1] + p0[2] + p0[3];
+        if (!(WS_DBG & 2) && k == 16) vb = xu[hf] + p1[0] + p1[1] + p1[2] + p1[3];
+        if (!(WS_DBG & 2) && k >= 17 && k <= 31 && (k & 1)) {
+            const int i = (k - 17) >> 1;
+            if (i < 4) va[i] = ws_sigmoid(va[i]);
+            else vb[i - 4] = ws_sigmoid(vb[i - 4]);
+        }
+        // the four stores one at a time, two slots apart: issued together, 16 KB per CU and 512 KB per XCD arrive at the
+        // L2 in one burst from all CUs in lockstep, the store queue fills and the wave (and its MFMAs) wait at the issue
+        if (!(WS_DBG & 4) && k == 33) { va2 = va * h_own[hf]; u_own[hf] = vb; ws_store2(rs_r, o_std[hf], ws_uni((unsigned)t * bh_step), va, false); }
+        if (!(WS_DBG & 4) && k == 35) ws_store2(rs_u, o_std[hf], ws_uni((unsigned)t * bh_step), vb, false);
+        if (!(WS_DBG & 4) && k == 37) ws_store2(rs_rh, o_std[hf], ws_uni((unsigned)t * bh_step), va2, false);
+        if (!(WS_DBG & 4) && k == 39) ws_store2(rs_rhF, lane16_st, ws_uni(frag_st(t, hf)), va2, a.handoff_sc1 != 0);      // hand-off LAST
+        if (!(WS_DBG & 8) && k == 54) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            ws_flag_store(ctr, j, 2u + 2 * t);
+        }
+    };
+    auto c_tail = [&](int k, int t, int hf, const f32x16& A0, unsigned* ctr, bool live) {
+        if (!(WS_DBG & 1) && k >= 1 && k <= 8) {
+#pragma unroll
+            for (int q = 2 * (k - 1); q < 2 * k; ++q) {
+                const int rq = (q & 3) + 8 * (q >> 2);
+                S[cbase[((q >> 1) & 1) | (((q >> 2) & 1) << 1)] + rq * 32] = A0[q];
+            }
+        }
+        if (!(WS_DBG & 1) && k == 9) ws_lds_barrier();
+        if (!(WS_DBG & 1) && k >= 10 && k <= 13) {
+            const int g = k - 10;
+            p0[g] = *reinterpret_cast<const f32x4n*>(S + g * 1024 + cfetch);
+        }
+        if (!(WS_DBG & 2) && k == 15) va = xc[hf] + p0[0] + p0[1] + p0[2] + p0[3];
+        if (!(WS_DBG & 2) && k >= 17 && k <= 23 && (k & 1)) {
+            const int i = (k - 17) >> 1;
+            va[i] = ws_tanh(va[i]);
+        }
+        if (!(WS_DBG & 4) && k == 33) {
+            const bool run = live && t < len_own[hf];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                va2[i] = run ? (u_own[hf][i] * h_own[hf][i] + (1.f - u_own[hf][i]) * va[i]) : h_own[hf][i];
+            h_own[hf] = va2;
+            // (the tail that does not exist in front of step 0: vector offset past the end, the scalar one is then irrelevant)
+            ws_store2(rs_c, live ? o_std[hf] : OOB, ws_uni((unsigned)t * bh_step), va, false);
+        }
+        if (!(WS_DBG & 4) && k == 35) ws_store2(rs_hs, live ? o_std[hf] : OOB, ws_uni((unsigned)(t + 1) * bh_step), va2, false);
+        if (!(WS_DBG & 4) && k == 39) ws_store2(rs_hF, live ? lane16_st : OOB, ws_uni(frag_st(t + 1, hf)), va2, a.handoff_sc1 != 0);
+        if (!(WS_DBG & 8) && k == 54) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            if (live) ws_flag_store(ctr, j, 3u + 2 * t);
+        }
+    };
+    // xp (from the Infinity Cache / HBM) is slow and a wave's vector-memory operations return IN ORDER: a fragment load
+    // issued behind an xp load cannot be seen complete before it.  So all xp a step needs is fetched at the head of the
+    // step's two GATE streams, where 8 octets of look-ahead are 4096 cycles (2048 in a candidate stream: measured, one xp
+    // load there cost 0.5 us of matrix time).
+    auto xp_fetch = [&](int k, int t, int hf) {
+        if (!(WS_DBG & 16) && k == 0) {
+            xr[hf] = ws_load2(rs_xp, o_xp[hf], xp_soff(t, 0));
+            xu[hf] = ws_load2(rs_xp, o_xp[hf], xp_soff(t, 1));
+            xc[hf] = ws_load2(rs_xp, o_xp[hf], xp_soff(t, 2));
+        }
+    };
+    unsigned peek = 0;
+    auto way_in = [&](int k, const unsigned* line, unsigned epoch) {      // towards the sub-phase after the running one
+        if (!(WS_DBG & 8) && k == 76 && w == 0) peek = ws_flag_load(line);
+        if (!(WS_DBG & 8) && k == 92) {
+            if (w == 0 && !ws_flags_reached(peek, epoch)) ws_spin(line, epoch, err, a.spin_limit);
+            ws_bar();
+        }
+    };
+
+    f32x4n ring[WS_RING2];
+    ws_wait(ctr0, 1u, err, a.spin_limit);
+#pragma unroll
+    for (int m = 0; m < WS_RING2; ++m) ring[m] = ws_load2(rs_hF, lane16, frag_ld(0, 0) + m * 1024);
+
+    // one sub-phase's matrix stream: 32 octets of this wave's k quarter, HOOK(slot - 4) in every slot
+    // (cur: this sub-phase's fragments; nxt: the next one's, fetched into the ring slots as they fall free)
+#define WS_GATE_STREAM(accR, accU, rs_cur, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                         \
+    _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                           \
+        const f32x4n av = ring[m % WS_RING2];                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            if (m == 0 && i == 0) {                                                                            \
+                WS_MFMA_AGPR_B0(accR, av[i], wg[0][m][i]);                                                     \
+                WS_MFMA_AGPR_B0(accU, av[i], wg[1][m][i]);                                                     \
+            } else if (m < WS_AG_OCT) {                                                                        \
+                WS_MFMA_AGPR_B(accR, av[i], wg[0][m][i]);                                                      \
+                WS_MFMA_AGPR_B(accU, av[i], wg[1][m][i]);                                                      \
+            } else {                                                                                           \
+                WS_MFMA_VGPR_B(accR, av[i], wg[0][m][i]);                                                      \
+                WS_MFMA_VGPR_B(accU, av[i], wg[1][m][i]);                                                      \
+            }                                                                                                  \
+            if (i == 3) {                                                                                      \
+                if (m + WS_RING2 < 32) ring[m % WS_RING2] = ws_load2(rs_cur, lane16, (base_cur) + (m + WS_RING2) * 1024);  \
+                else ring[m % WS_RING2] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + WS_RING2 - 32) * 1024); \
+            }                                                                                                  \
+            HOOK(4 * m + i - 4);                                                                               \
+            if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();              \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                      \
+    }
+#define WS_CAND_STREAM(acc0, acc1, rs_cur, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                          \
+    {                                                                                                          \
+        f32x4n bq[2];                                                                                          \
+        bq[0] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w) * 64 + lane) * 4);                             \
+        bq[1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + 1) * 64 + lane) * 4);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                       \
+            const f32x4n av = ring[m % WS_RING2];                                                               \
+            const f32x4n bv = bq[m & 1];                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+                if (m & 1) acc1 = WS_MFMA(av[i], bv[i], acc1);                                                 \
+                else acc0 = WS_MFMA(av[i], bv[i], acc0);                                                       \
+                if (i == 1 && m + 2 < 32)                                                                      \
+                    bq[m & 1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + m + 2) * 64 + lane) * 4);     \
+                if (i == 3) {                                                                                  \
+                    if (m + WS_RING2 < 32) ring[m % WS_RING2] = ws_load2(rs_cur, lane16, (base_cur) + (m + WS_RING2) * 1024); \
+                    else ring[m % WS_RING2] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + WS_RING2 - 32) * 1024); \
+                }                                                                                              \
+                HOOK(4 * m + i - 4);                                                                           \
+                if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();          \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    f32x16 gR0, gU0, gR1, gU1, cA0, cA1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cA1[q] = 0.f;
+    unsigned long long* stamp = (a.stamps != nullptr && blockIdx.x == 0 && tid == 0) ? a.stamps : nullptr;
+    long long* slots = (WS_SLOTS && stamp != nullptr) ? reinterpret_cast<long long*>(a.stamps) + 1024 : nullptr;      // 4 x 128 slot stamps of step 5
+
+    for (int t = 0; t < T; ++t) {
+        const unsigned n = (unsigned)(2 * t);
+        // ---------------- G(0,t); in its gaps: the tail of C(1,t-1), then the way into G(1,t)
+        if (stamp) { *stamp++ = wall_clock64(); *stamp++ = clock64(); }
+        {
+            const bool tail = t > 0;
+            auto hook = [&](int k) {
+                c_tail(k, t - 1, 1, cA1, ctr1, tail);
+                way_in(k, ctr1, 1u + n);
+                xp_fetch(k, t, 0);
+            };
+#define SLOT_BASE 0
+            WS_GATE_STREAM(gR0, gU0, rs_hF, frag_ld(t, 0), rs_hF, frag_ld(t, 1), lane16, hook)
+        }
+        // ---------------- G(1,t); tail of G(0,t); way into C(0,t)
+        if (stamp) { *stamp++ = wall_clock64(); *stamp++ = clock64(); }
+        {
+            auto hook = [&](int k) {
+                g_tail(k, t, 0, gR0, gU0, ctr0);
+                way_in(k, ctr0, 2u + n);
+                xp_fetch(k, t, 1);
+            };
+#undef SLOT_BASE
+#define SLOT_BASE 128
+            WS_GATE_STREAM(gR1, gU1, rs_hF, frag_ld(t, 1), rs_rhF, frag_ld(t, 0), lane16, hook)
+        }
+        // ---------------- C(0,t); tail of G(1,t); way into C(1,t)
+        if (stamp) { *stamp++ = wall_clock64(); *stamp++ = clock64(); }
+        {
+            f32x16 cB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { cA0[q] = 0.f; cB[q] = 0.f; }
+            auto hook = [&](int k) {
+                g_tail(k, t, 1, gR1, gU1, ctr1);
+                way_in(k, ctr1, 2u + n);
+            };
+#undef SLOT_BASE
+#define SLOT_BASE 256
+            WS_CAND_STREAM(cA0, cB, rs_rhF, frag_ld(t, 0), rs_rhF, frag_ld(t, 1), lane16, hook)
+            cA0 += cB;
+        }
+        // ---------------- C(1,t); tail of C(0,t); way into G(0,t+1)
+        if (stamp) { *stamp++ = wall_clock64(); *stamp++ = clock64(); }
+        {
+            f32x16 cB;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { cA1[q] = 0.f; cB[q] = 0.f; }
+            const bool more = t + 1 < T;
+            auto hook = [&](int k) {
+                c_tail(k, t, 0, cA0, ctr0, true);
+                way_in(k, ctr0, more ? 3u + n : 0u);      // (behind the last step: nothing to wait for)
+            };
+#undef SLOT_BASE
+#define SLOT_BASE 384
+            WS_CAND_STREAM(cA1, cB, rs_rhF, frag_ld(t, 1), rs_hF, more ? frag_ld(t + 1, 0) : 0u, more ? lane16 : OOB, hook)
+            cA1 += cB;
+        }
+    }
+    // ---------------- the tail of C(1,T-1), on its own
+    if (stamp) { *stamp++ = wall_clock64(); *stamp++ = clock64(); }
+#pragma unroll
+    for (int k = 1; k <= 39; ++k) c_tail(k, T - 1, 1, cA1, ctr1, true);
+    ws_arrive(ctr1, j, 1u + 2 * T);
+#undef SLOT_BASE
+#undef WS_GATE_STREAM
+#undef WS_CAND_STREAM
 }
 
 struct WsDevice { int cus = 0, blocks = -1; };
@@ -347,20 +773,29 @@ const WsDevice& ws_device() {
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return d;
         d.cus = prop.multiProcessorCount;
         int n = 0;
+        int n2 = 0;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_ws_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WS_LDS) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_ws_fwd_kernel, WS_NT, WS_LDS) == hipSuccess)
-            d.blocks = n;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gru_ws_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)WS_LDS) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_ws_fwd_kernel, WS_NT, WS_LDS) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gru_ws_fwd2_kernel, WS_NT, WS_LDS) == hipSuccess)
+            d.blocks = n < n2 ? n : n2;
     }
     return d;
 }
 int g_ws_mode = -1;                     // -1 automatic, 0 off, 1 on wherever it applies
+int g_ws_form = 0;                      // tuning: 1 = the plain sub-phase order also for two half-chains (A/B of the splice)
 unsigned long long* g_ws_stamps = nullptr;
 
 }  // namespace
 
 extern "C" int vqa_gru_ws_set_mode(int mode) {
     g_ws_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return VQA_OK;
+}
+extern "C" int vqa_gru_ws_set_form(int form) {
+    g_ws_form = form & 0x73;        // bit 0: plain sub-phase order; bit 1: write-through hand-offs; bits 4-6: timing study
     return VQA_OK;
 }
 extern "C" int vqa_gru_ws_set_stamps(unsigned long long* dev_words) {
@@ -379,12 +814,12 @@ extern "C" int vqa_gru_ws_supported(int T, int B, int H) {
 
 // device memory the call needs besides the tape: fragment-order hand-off buffers and the counters
 extern "C" int64_t vqa_gru_ws_workspace_bytes(int T) {
-    return T < 0 ? 0 : ((int64_t)(2 * T + 1) * WS_FRAG_T + 512) * (int64_t)sizeof(float);
+    return T < 0 ? 0 : ((int64_t)(2 * T + 1) * WS_FRAG_T + 1024) * (int64_t)sizeof(float);
 }
 
 // Whole forward recurrence in one launch; same tape contract as vqa_gru_seq_fwd (xp [T,B,3H] read only, hs [T+1,B,H]
 // with hs[0] given, r,u,c,rh [T,B,H]).  `ws`: vqa_gru_ws_workspace_bytes(T) of device memory (contents irrelevant).
-// After the stream has run, a non-zero word at ((unsigned*)ws)[256] reports a barrier time-out (results invalid).
+// After the stream has run, a non-zero word at ((unsigned*)ws)[512] reports a barrier time-out (results invalid).
 extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
                                   float* r, float* u, float* c, float* rh, int T, int B, int H, void* ws, void* stream) {
     VQA_REQUIRE(xp && Wg_h && Wc_h && len && hs && r && u && c && rh && ws, VQA_ERR_ARG);
@@ -393,14 +828,22 @@ extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     WsArgs a;
     a.sync = static_cast<unsigned*>(ws);
-    if (hipMemsetAsync(a.sync, 0, 512 * sizeof(unsigned), st) != hipSuccess) return VQA_ERR_LAUNCH;
-    a.hF = static_cast<float*>(ws) + 512;
+    if (hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return VQA_ERR_LAUNCH;
+    a.hF = static_cast<float*>(ws) + 1024;
     a.rhF = a.hF + (int64_t)(T + 1) * WS_FRAG_T;
     a.xp = xp; a.Wg = Wg_h; a.Wc = Wc_h; a.len = len; a.hs = hs; a.r = r; a.u = u; a.c = c; a.rh = rh;
     a.T = T; a.B = B;
     a.spin_limit = 2000000u;
     a.stamps = g_ws_stamps;
-    hipLaunchKernelGGL(gru_ws_fwd_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
+    a.handoff_sc1 = (g_ws_form & 2) ? 1 : 0;
+    a.dbg = (g_ws_form >> 4) & 7;
+    // more than 256 rows: chains of 64 rows = two half-chains in anti-phase, tails inside the matrix stream; up to 256
+    // rows: chains of 32 rows so that all eight XCDs work (one half-chain each, the plain sub-phase order)
+    a.chain_rows = B > 256 ? 64 : 32;
+    if (a.chain_rows == 64 && !(g_ws_form & 1))
+        hipLaunchKernelGGL(gru_ws_fwd2_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
+    else
+        hipLaunchKernelGGL(gru_ws_fwd_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
