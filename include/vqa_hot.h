@@ -252,6 +252,14 @@ int vqa_gru_persistent_set_census(unsigned* dev_words);   /* placement study (to
 int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,
                        float* u, float* c, float* rh, int T, int B, int H, void* ws, void* stream);
 int vqa_gru_ws_supported(int T, int B, int H);
+/* The back-propagation through time in the same frame (one launch, W_g^T / W_c^T slabs resident): dxp [T,B,3H] =
+ * (dr_pre | du_pre | dc_pre) from dh_T [B,H] -- read only here, unlike vqa_gru_seq_bwd -- and the forward tape; d_outs
+ * [T,B,H] or NULL as in vqa_gru_seq_bwd_outs.  256 < B <= 512, H = 1024 (vqa_gru_ws_bwd_supported); `ws` as above (one
+ * buffer may serve both directions). */
+int vqa_gru_seq_bwd_ws(const float* dh_T, const float* d_outs, const float* Wg_h, const float* Wc_h, const int32_t* len,
+                       const float* hs, const float* r, const float* u, const float* c, float* dxp, int T, int B, int H,
+                       void* ws, void* stream);
+int vqa_gru_ws_bwd_supported(int T, int B, int H);
 int64_t vqa_gru_ws_workspace_bytes(int T);
 int vqa_gru_ws_set_mode(int mode);      /* -1 automatic, 0 never, 1 whenever supported */
 int vqa_gru_ws_set_form(int form);      /* tuning: 0 = sub-phase tails inside the next matrix stream (default), 1 = plain order */

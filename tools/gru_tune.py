@@ -140,6 +140,28 @@ if os.environ.get("WS") == "1":
         print("  forward: stepwise %.1f us   weight-stationary %.1f us" % (tm(fwd), tm(fwd_ws)), flush=True)
     sys.exit(0)
 
+if os.environ.get("WSB") == "1":
+    # weight-stationary back-propagation through time (csrc/gru_ws.hip) against the step kernels
+    if lib.vqa_gru_ws_bwd_supported(T, B, H) != 1:
+        print("weight-stationary back-propagation does not apply here"); sys.exit(0)
+    ws = torch.empty(int(lib.vqa_gru_ws_workspace_bytes(T)) // 4, dtype=torch.float32, device="cuda").fill_(float("nan"))
+    dxp_ws = torch.full_like(dxp, float("nan"))
+
+    def bwd_ws():
+        _lib.check(lib.vqa_gru_seq_bwd_ws(P(dhT0), None, P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(dxp_ws), T, B, H, P(ws), None), "bwd_ws")
+
+    fwd(); bwd(); torch.cuda.synchronize()
+    bwd_ws(); torch.cuda.synchronize()
+    words = ws[:1024].view(torch.int32)
+    print("ws: flags (min, max per half-chain)", [(int(words[32 * i: 32 * i + 32].min()), int(words[32 * i: 32 * i + 32].max())) for i in range(16)],
+          "error word", int(words[512]), flush=True)
+    for nm, lo in (("dr_pre", 0), ("du_pre", H), ("dc_pre", 2 * H)):
+        a_, b_ = dxp[:, :, lo:lo + H], dxp_ws[:, :, lo:lo + H]
+        print("  max |%s - stepwise| = %.3e  (max |.| %.3e)  nan %d" % (nm, float((a_ - b_).abs().max()), float(a_.abs().max()), int(torch.isnan(b_).sum())), flush=True)
+    for rep in range(3):
+        print("  backward: stepwise %.1f us   weight-stationary %.1f us" % (tm(bwd), tm(bwd_ws)), flush=True)
+    sys.exit(0)
+
 if os.environ.get("GRAPH") == "1":
     # does replaying the 28-kernel chain from a captured graph shorten the gaps between its dependent kernels?
     def on_stream(fn_name, args):

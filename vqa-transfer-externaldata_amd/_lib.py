@@ -117,6 +117,8 @@ SIGNATURES = {
     "vqa_gru_persistent_set_census": (_I, [_P]),
     "vqa_gru_seq_fwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "vqa_gru_ws_supported": (_I, [_I, _I, _I]),
+    "vqa_gru_seq_bwd_ws": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "vqa_gru_ws_bwd_supported": (_I, [_I, _I, _I]),
     "vqa_gru_ws_workspace_bytes": (_L, [_I]),
     "vqa_gru_ws_set_mode": (_I, [_I]),
     "vqa_gru_ws_set_form": (_I, [_I]),

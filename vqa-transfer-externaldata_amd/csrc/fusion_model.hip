@@ -57,6 +57,8 @@ Layout make_layout(const vqa_dims_t& d) {
     L.add("wx_cat", W * 3 * H); L.add("bx_cat", 3 * H); L.add("dwx_cat", Wp * 3 * H);
     L.add("hs", (T + 1) * B * H);
     L.add("gru_r", T * B * H); L.add("gru_u", T * B * H); L.add("gru_c", T * B * H); L.add("gru_rh", T * B * H);
+    // hand-off buffers and flags of the weight-stationary recurrence (csrc/gru_ws.hip), where its shape limits hold
+    if (H == 1024 && B <= 512) L.add("gru_ws", vqa_gru_ws_workspace_bytes((int)T) / 4);
     L.add("pre_qv", B * H); L.add("q_linear_v", B * H); L.add("mean_qv", B); L.add("rstd_qv", B);
     L.add("att_score", B * R);
     const int64_t Dp = d.model_type == VQA_MODEL_ADAPT ? H : D;      // width of what the attention pools (pooled_dim)
@@ -619,6 +621,10 @@ inline bool visual_late_enabled() {       // VQA_HOT_VISUAL_LATE=0: the round-1 
 }  // namespace
 
 namespace {
+inline bool gru_ws_on() {          // VQA_HOT_GRU_WS=0: the per-step recurrence kernels (A/B)
+    static const bool v = [] { const char* e = getenv("VQA_HOT_GRU_WS"); return e == nullptr || atoi(e) != 0; }();
+    return v;
+}
 inline bool xcat_enabled() {       // VQA_HOT_XCAT=0: the two-GEMM form (A/B)
     static const bool v = [] { const char* e = getenv("VQA_HOT_XCAT"); return e == nullptr || atoi(e) != 0; }();
     return v;
@@ -714,6 +720,10 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
         if (bt->live_rows != nullptr) {          // rows sorted by length: skip finished sequences
             TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
                                      c.f("gru_c"), c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
+        } else if (gru_ws_on() && vqa_gru_ws_supported((int)T, (int)B, (int)H) == 1) {
+            // one launch, recurrent weights resident in registers and LDS, eight XCD-local chains (csrc/gru_ws.hip)
+            TRY(vqa_gru_seq_fwd_ws(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), c.f("gru_rh"),
+                                   (int)T, (int)B, (int)H, c.f("gru_ws"), c.st));
         } else {                                  // independent row chains in anti-phase (gru_chains)
             float* gr = c.f("gru_r"); float* gu = c.f("gru_u"); float* gc = c.f("gru_c"); float* grh = c.f("gru_rh");
             TRY(run_chains(c, B, [&](int, int64_t row0, int64_t rows, hipStream_t st) {
@@ -1069,6 +1079,9 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
         if (bt->live_rows != nullptr) {
             TRY(vqa_gru_seq_bwd_live(dh, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
                                      c.f("gru_c"), dxp, c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
+        } else if (gru_ws_on() && vqa_gru_ws_bwd_supported((int)T, (int)B, (int)H) == 1) {
+            TRY(vqa_gru_seq_bwd_ws(dh, nullptr, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), dxp,
+                                   (int)T, (int)B, (int)H, c.f("gru_ws"), c.st));
         } else {
             const float* gr = c.f("gru_r"); const float* gu = c.f("gru_u"); const float* gc = c.f("gru_c");
             float* dh1 = c.f("d_h1");

@@ -760,7 +760,317 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
 #undef WS_CAND_STREAM
 }
 
-struct WsDevice { int cus = 0, blocks = -1; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Back-propagation through time in the same frame (two 32-row half-chains per XCD, tails inside the streams).
+// Per step t (vlmap/modules.py:124-140 differentiated; the formulas of rowops.hip gru_bwd_a / gru_bwd_b):
+//     g      = dL/dh_t                                     (this thread's float4 of its row, carried in registers)
+//     dc_pre = g (1 - u)(1 - c^2),  du_pre = g (h_prev - c) u (1 - u),  acc = g u          [t < len; else 0, 0, g]
+//   A(hf,t)  drh = dc_pre W_c^T            K = 1024   slab W_c[32 j .. +32, :] in LDS        (as the candidate stream)
+//            dr_pre = drh h_prev r (1 - r),  acc += drh r
+//   B(hf,t)  dL/dh_{t-1} = (dr_pre | du_pre) W_g^T + acc   K = 2048   slab W_g[32 j .. +32, :] in registers
+//            (64 octets per wave: waves 0, 1 read dr_pre's fragments, waves 2, 3 du_pre's), then the first half of
+//            step t - 1 in its tail.  B(hf,0) does not exist (h_0 is not a parameter).
+// dxp[t] = (dr_pre | du_pre | dc_pre) is the only output.  CU j owns the 32 state columns [32 j, 32 j + 32) of every
+// product's RESULT, i.e. rows of W_c and W_g: the slabs are read transposed, once.
+struct WsBwdArgs {
+    const float* dh_T;    // [B,H]   dL/d(final state)
+    const float* d_outs;  // [T,B,H] or null: dL/d(output of step t), added to g before step t is differentiated
+    const float* Wg;      // [H,2H]
+    const float* Wc;      // [H,H]
+    const int32_t* len;
+    const float *hs, *r, *u, *c;
+    float* dxp;           // [T,B,3H]
+    float *dcF, *drF, *duF;       // [T] fragment-order hand-offs
+    unsigned* sync;
+    int T, B;
+    unsigned spin_limit;
+    unsigned long long* stamps;
+};
+
+#define WS_MFMA_VGPR_B0(acc, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
+constexpr int WS_BW_AG_OCT = 56;    // of a wave's 64 octets of W_g^T: fragments in AGPRs (4 each); the rest in VGPRs
+
+__global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                   // W_c^T slab, fragment order
+    float* S = smem + 32768;
+    constexpr int H = WS_H;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int chain, j;
+    ws_place(a.sync, reinterpret_cast<int*>(S), chain, j);
+    const int B = a.B, T = a.T;
+    const int row_base = chain * 64;
+    unsigned* err = a.sync + 512;
+    if (row_base >= B) return;
+    unsigned* ctr0 = a.sync + 32 * (2 * chain);
+    unsigned* ctr1 = ctr0 + 32;
+
+    // B fragment of octet m, k pair i: lane l supplies W^T[k = 8 m + 4 (l >> 5) + i][column l & 31] = W[32 j + (l & 31)][k]
+    float wq[64][4];
+    {
+        const float* p = a.Wg + (int64_t)(32 * j + (lane & 31)) * (2 * H) + 512 * w + 4 * (lane >> 5);
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const f32x4n v = *reinterpret_cast<const f32x4n*>(p + 8 * m);
+            wq[m][0] = v.x; wq[m][1] = v.y; wq[m][2] = v.z; wq[m][3] = v.w;
+        }
+    }
+    for (int idx = tid; idx < 128 * 64; idx += WS_NT) {
+        const int oct = idx >> 6, l = idx & 63;
+        *reinterpret_cast<f32x4n*>(Wl + idx * 4) =
+            *reinterpret_cast<const f32x4n*>(a.Wc + (int64_t)(32 * j + (l & 31)) * H + 8 * oct + 4 * (l >> 5));
+    }
+
+    const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
+    const int64_t BH = (int64_t)B * H;
+    const __amdgpu_buffer_rsrc_t rs_dcF = ws_rs(a.dcF, (int64_t)T * WS_FRAG_T * 4);
+    const __amdgpu_buffer_rsrc_t rs_drF = ws_rs(a.drF, (int64_t)T * WS_FRAG_T * 4);
+    const __amdgpu_buffer_rsrc_t rs_duF = ws_rs(a.duF, (int64_t)T * WS_FRAG_T * 4);
+    const __amdgpu_buffer_rsrc_t rs_bF = ws_rs(w < 2 ? a.drF : a.duF, (int64_t)T * WS_FRAG_T * 4);      // this wave's B-stream operand
+    const __amdgpu_buffer_rsrc_t rs_dxp = ws_rs(a.dxp, (int64_t)T * B * 3 * H * 4);
+    const __amdgpu_buffer_rsrc_t rs_hs = ws_rs(a.hs, (T + 1) * BH * 4);
+    const __amdgpu_buffer_rsrc_t rs_r = ws_rs(a.r, T * BH * 4), rs_u = ws_rs(a.u, T * BH * 4), rs_c = ws_rs(a.c, T * BH * 4);
+    const __amdgpu_buffer_rsrc_t rs_dh = ws_rs(a.dh_T, BH * 4);
+    const __amdgpu_buffer_rsrc_t rs_do = ws_rs(a.d_outs != nullptr ? a.d_outs : a.dh_T, a.d_outs != nullptr ? T * BH * 4 : 0);
+    // fragment buffers: scalar parts of the offsets (the per-lane part is lane * 16)
+    auto frag_a = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 32 * w) * 1024); };          // A stream: 32 octets
+    auto frag_b = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 64 * (w & 1)) * 1024); };    // B stream: 64 octets
+    auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + w) * 1024); };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned bh_step = (unsigned)(BH * 4), xp_step = (unsigned)((int64_t)B * 3 * H * 4);
+
+    f32x4n acc_own[2], hp_own[2];       // running dL/dh_{t-1} (partial), h_{t-1} of the step being differentiated
+    int len_own[2];
+    unsigned o_std[2], o_xp[2];
+    int gbase_unused = 0; (void)gbase_unused;
+    int cbase[4];
+    {
+        const int hl = lane >> 5, cs = (lane & 31) >> 2, c3 = lane & 3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            cbase[v] = w * 1024 + (4 * hl) * 32 + (((cs ^ (hl << 1)) ^ ((v & 1) | ((v >> 1) << 2))) << 2) + c3;
+    }
+    const int cfetch = e_row * 32 + (((e_col >> 2) ^ ((e_row >> 1) & 7)) << 2);
+
+    // first half of a step from g (= dL/dh_t of this thread's float4): dc_pre, du_pre out, acc_own / hp_own updated
+    auto half_step = [&](int t, int hf, f32x4n g, f32x4n uv, f32x4n cv, f32x4n hp, f32x4n& dc, f32x4n& du) {
+        const bool run = t < len_own[hf];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dc[i] = run ? g[i] * (1.f - uv[i]) * (1.f - cv[i] * cv[i]) : 0.f;
+            du[i] = run ? g[i] * (hp[i] - cv[i]) * uv[i] * (1.f - uv[i]) : 0.f;
+            acc_own[hf][i] = run ? g[i] * uv[i] : g[i];
+        }
+        hp_own[hf] = hp;
+    };
+
+    // ---- step T-1's first half from dL/d(final state)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int grow = row_base + 32 * hf + e_row;
+        const bool ok = grow < B;
+        o_std[hf] = ok ? (unsigned)(((int64_t)grow * H + 32 * j + e_col) * 4) : OOB;
+        o_xp[hf] = ok ? (unsigned)(((int64_t)grow * 3 * H + 32 * j + e_col) * 4) : OOB;
+        len_own[hf] = ok ? a.len[grow] : 0;
+        const int t = T - 1;
+        f32x4n g = ws_load2(rs_dh, o_std[hf], 0u);
+        if (a.d_outs != nullptr) g += ws_load2(rs_do, o_std[hf], (unsigned)t * bh_step);
+        const f32x4n uv = ws_load2(rs_u, o_std[hf], (unsigned)t * bh_step), cv = ws_load2(rs_c, o_std[hf], (unsigned)t * bh_step);
+        const f32x4n hp = ws_load2(rs_hs, o_std[hf], (unsigned)t * bh_step);
+        f32x4n dc, du;
+        half_step(t, hf, g, uv, cv, hp, dc, du);
+        ws_store2(rs_dxp, o_xp[hf], (unsigned)t * xp_step + 2 * H * 4, dc, false);
+        ws_store2(rs_dxp, o_xp[hf], (unsigned)t * xp_step + H * 4, du, false);
+        ws_store2(rs_duF, lane16, frag_st(t, hf), du, false);
+        ws_store2(rs_dcF, lane16, frag_st(t, hf), dc, false);
+    }
+    __syncthreads();                    // the W_c^T slab is in LDS
+    ws_arrive(ctr0, j, 1u);
+    ws_arrive(ctr1, j, 1u);
+
+    // ---- tails (micro-step schedule of the forward kernel)
+    f32x4n va, vb, vc, vd, ve;          // tail temporaries / prefetched tape values
+    f32x4n p0[4];
+    auto spill_fetch = [&](int k, const f32x16& P) {
+        if (k >= 1 && k <= 8) {
+#pragma unroll
+            for (int q = 2 * (k - 1); q < 2 * k; ++q) {
+                const int rq = (q & 3) + 8 * (q >> 2);
+                S[cbase[((q >> 1) & 1) | (((q >> 2) & 1) << 1)] + rq * 32] = P[q];
+            }
+        }
+        if (k == 9) ws_lds_barrier();
+        if (k >= 10 && k <= 13) p0[k - 10] = *reinterpret_cast<const f32x4n*>(S + (k - 10) * 1024 + cfetch);
+    };
+    // tail of A(hf,t): dr_pre out, acc_own += drh r           (vd = r[t], fetched at k = 0)
+    auto a_tail = [&](int k, int t, int hf, const f32x16& P, unsigned* ctr, unsigned epoch) {
+        if (k == 0) vd = ws_load2(rs_r, o_std[hf], ws_uni((unsigned)t * bh_step));
+        spill_fetch(k, P);
+        if (k == 15) va = p0[0] + p0[1] + p0[2] + p0[3];                       // drh
+        if (k == 17) {
+            acc_own[hf] += va * vd;
+            vb = va * hp_own[hf] * vd * ((f32x4n)(1.f) - vd);                   // dr_pre
+        }
+        if (k == 33) ws_store2(rs_dxp, o_xp[hf], ws_uni((unsigned)t * xp_step), vb, false);
+        if (k == 39) ws_store2(rs_drF, lane16, ws_uni(frag_st(t, hf)), vb, false);
+        if (k == 54) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            ws_flag_store(ctr, j, epoch);
+        }
+    };
+    // tail of B(hf,t), t > 0: g = dL/dh_{t-1}, then the first half of step t-1      (vc, vd, ve = u, c, h_prev of step t-1)
+    auto b_tail = [&](int k, int t, int hf, const f32x16& P, unsigned* ctr, unsigned epoch, bool live) {
+        const unsigned so = ws_uni((unsigned)(t - 1) * bh_step);
+        if (k == 0) {
+            vc = ws_load2(rs_u, live ? o_std[hf] : OOB, so);
+            vd = ws_load2(rs_c, live ? o_std[hf] : OOB, so);
+            ve = ws_load2(rs_hs, live ? o_std[hf] : OOB, so);
+        }
+        if (k == 2 && a.d_outs != nullptr) vb = ws_load2(rs_do, live ? o_std[hf] : OOB, so);
+        spill_fetch(k, P);
+        if (k == 15) {
+            va = p0[0] + p0[1] + p0[2] + p0[3] + acc_own[hf];
+            if (a.d_outs != nullptr) va += vb;
+        }
+        if (k == 17 && live) half_step(t - 1, hf, va, vc, vd, ve, va, vb);      // va = dc_pre, vb = du_pre afterwards
+        if (k == 33) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + 2 * H * 4), va, false);
+        if (k == 35) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + H * 4), vb, false);
+        if (k == 37) ws_store2(rs_duF, live ? lane16 : OOB, ws_uni(frag_st(t - 1, hf)), vb, false);
+        if (k == 39) ws_store2(rs_dcF, live ? lane16 : OOB, ws_uni(frag_st(t - 1, hf)), va, false);
+        if (k == 54) {
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            if (live) ws_flag_store(ctr, j, epoch);
+        }
+    };
+    unsigned peek = 0;
+    auto way_in = [&](int k, const unsigned* line, unsigned epoch) {
+        if (k == 76 && w == 0) peek = ws_flag_load(line);
+        if (k == 92) {
+            if (w == 0 && !ws_flags_reached(peek, epoch)) ws_spin(line, epoch, err, a.spin_limit);
+            ws_bar();
+        }
+    };
+
+    f32x4n ring[8];
+    ws_wait(ctr0, 1u, err, a.spin_limit);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) ring[m] = ws_load2(rs_dcF, lane16, frag_a(T - 1, 0) + m * 1024);
+
+    // A stream: 32 octets against the LDS slab (128 slots of one MFMA); B stream: 64 octets against the register slab
+    // (128 slots of two MFMAs).  HOOK(slot - 4) in every slot; the ring's last 8 refills fetch the NEXT stream's head.
+#define WS_A_STREAM(acc0, acc1, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                                    \
+    {                                                                                                          \
+        f32x4n bq[2];                                                                                          \
+        bq[0] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w) * 64 + lane) * 4);                             \
+        bq[1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + 1) * 64 + lane) * 4);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                       \
+            const f32x4n av = ring[m % 8];                                                                     \
+            const f32x4n bv = bq[m & 1];                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+                if (m & 1) acc1 = WS_MFMA(av[i], bv[i], acc1);                                                 \
+                else acc0 = WS_MFMA(av[i], bv[i], acc0);                                                       \
+                if (i == 1 && m + 2 < 32)                                                                      \
+                    bq[m & 1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + m + 2) * 64 + lane) * 4);     \
+                if (i == 3) {                                                                                  \
+                    if (m + 8 < 32) ring[m % 8] = ws_load2(rs_dcF, lane16, (base_cur) + (m + 8) * 1024);        \
+                    else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 32) * 1024);          \
+                }                                                                                              \
+                HOOK(4 * m + i - 4);                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define WS_B_STREAM(accA, accB, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                                    \
+    _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                           \
+        const f32x4n av = ring[m % 8];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+            if (m < 2) {                                                                                       \
+                if (i == 0) { if (m == 0) WS_MFMA_AGPR_B0(accA, av[i], wq[m][i]); else WS_MFMA_AGPR_B0(accB, av[i], wq[m][i]); } \
+                else { if (m == 0) WS_MFMA_AGPR_B(accA, av[i], wq[m][i]); else WS_MFMA_AGPR_B(accB, av[i], wq[m][i]); } \
+            } else if (m < WS_BW_AG_OCT) {                                                                     \
+                if (m & 1) WS_MFMA_AGPR_B(accB, av[i], wq[m][i]); else WS_MFMA_AGPR_B(accA, av[i], wq[m][i]);   \
+            } else {                                                                                           \
+                if (m & 1) WS_MFMA_VGPR_B(accB, av[i], wq[m][i]); else WS_MFMA_VGPR_B(accA, av[i], wq[m][i]);   \
+            }                                                                                                  \
+            if (i == 3) {                                                                                      \
+                if (m + 8 < 64) ring[m % 8] = ws_load2(rs_bF, lane16, (base_cur) + (m + 8) * 1024);            \
+                else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 64) * 1024);             \
+            }                                                                                                  \
+            if (i & 1) {                                                                                       \
+                HOOK(2 * m + (i >> 1) - 4);                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
+    f32x16 pA0, pA1, pB0, pB1;          // summed result tiles of A(0,.), A(1,.), B(0,.), B(1,.), pending their tails
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pB1[q] = 0.f;
+
+    for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+        const unsigned n = (unsigned)(2 * s);
+        const bool more = t > 0;        // the B streams of this step exist
+        // ---------------- A(0,t); in its gaps: the tail of B(1,t+1), then the way into A(1,t)
+        {
+            f32x16 x;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { pA0[q] = 0.f; x[q] = 0.f; }
+            auto hook = [&](int k) {
+                b_tail(k, t + 1, 1, pB1, ctr1, 1u + n, s > 0);
+                way_in(k, ctr1, 1u + n);
+            };
+            WS_A_STREAM(pA0, x, frag_a(t, 0), rs_dcF, frag_a(t, 1), lane16, hook)
+            pA0 += x;
+        }
+        // ---------------- A(1,t); tail of A(0,t); way into B(0,t)
+        {
+            f32x16 x;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { pA1[q] = 0.f; x[q] = 0.f; }
+            auto hook = [&](int k) {
+                a_tail(k, t, 0, pA0, ctr0, 2u + n);
+                way_in(k, ctr0, more ? 2u + n : 0u);
+            };
+            WS_A_STREAM(pA1, x, frag_a(t, 1), rs_bF, more ? frag_b(t, 0) : 0u, more ? lane16 : OOB, hook)
+            pA1 += x;
+        }
+        if (!more) break;
+        // ---------------- B(0,t); tail of A(1,t); way into B(1,t)
+        {
+            f32x16 x;
+            auto hook = [&](int k) {
+                a_tail(k, t, 1, pA1, ctr1, 2u + n);
+                way_in(k, ctr1, 2u + n);
+            };
+            WS_B_STREAM(pB0, x, frag_b(t, 0), rs_bF, frag_b(t, 1), lane16, hook)
+            WS_MFMA_DRAIN();
+            pB0 += x;
+        }
+        // ---------------- B(1,t); tail of B(0,t); way into A(0,t-1)
+        {
+            f32x16 x;
+            auto hook = [&](int k) {
+                b_tail(k, t, 0, pB0, ctr0, 3u + n, true);
+                way_in(k, ctr0, 3u + n);
+            };
+            WS_B_STREAM(pB1, x, frag_b(t, 1), rs_dcF, frag_a(t - 1, 0), lane16, hook)
+            WS_MFMA_DRAIN();
+            pB1 += x;
+        }
+    }
+    // ---------------- the tail of A(1,0), on its own
+#pragma unroll
+    for (int k = 0; k <= 39; ++k) a_tail(k, 0, 1, pA1, ctr1, 2u * T);
+    ws_arrive(ctr1, j, 2u * T);
+#undef WS_A_STREAM
+#undef WS_B_STREAM
+}
+
+struct WsDevice { int cus = 0, blocks = -1, blocks_bwd = -1; };
 const WsDevice& ws_device() {
     static WsDevice per_dev[64];
     static bool known[64] = {};
@@ -779,8 +1089,14 @@ const WsDevice& ws_device() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(gru_ws_fwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WS_LDS) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gru_ws_fwd_kernel, WS_NT, WS_LDS) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gru_ws_fwd2_kernel, WS_NT, WS_LDS) == hipSuccess)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, gru_ws_fwd2_kernel, WS_NT, WS_LDS) == hipSuccess) {
             d.blocks = n < n2 ? n : n2;
+            int n3 = 0;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_ws_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)WS_LDS) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, gru_ws_bwd2_kernel, WS_NT, WS_LDS) == hipSuccess)
+                d.blocks_bwd = n3;
+        }
     }
     return d;
 }
@@ -814,7 +1130,7 @@ extern "C" int vqa_gru_ws_supported(int T, int B, int H) {
 
 // device memory the call needs besides the tape: fragment-order hand-off buffers and the counters
 extern "C" int64_t vqa_gru_ws_workspace_bytes(int T) {
-    return T < 0 ? 0 : ((int64_t)(2 * T + 1) * WS_FRAG_T + 1024) * (int64_t)sizeof(float);
+    return T < 0 ? 0 : ((int64_t)(3 * T + 1) * WS_FRAG_T + 1024) * (int64_t)sizeof(float);      // forward 2 T + 1, backward 3 T
 }
 
 // Whole forward recurrence in one launch; same tape contract as vqa_gru_seq_fwd (xp [T,B,3H] read only, hs [T+1,B,H]
@@ -844,6 +1160,41 @@ extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const floa
         hipLaunchKernelGGL(gru_ws_fwd2_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
     else
         hipLaunchKernelGGL(gru_ws_fwd_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
+    VQA_CHECK_LAUNCH();
+    return VQA_OK;
+}
+
+// 1 when the weight-stationary back-propagation applies: as the forward form, and more than 256 rows (it exists in the
+// two-half form only)
+extern "C" int vqa_gru_ws_bwd_supported(int T, int B, int H) {
+    if (g_ws_mode == 0) return 0;
+    if (T <= 0 || H != WS_H || B <= 256 || B > WS_CHAINS * 64) return 0;
+    const WsDevice& d = ws_device();
+    return (d.cus == WS_CHAINS * WS_CU && d.blocks_bwd >= 1) ? 1 : 0;
+}
+
+// Whole back-propagation through time in one launch: dxp [T,B,3H] = (dr_pre | du_pre | dc_pre) from dh_T [B,H] (read
+// only, unlike vqa_gru_seq_bwd) and the forward tape; d_outs [T,B,H] or NULL as in vqa_gru_seq_bwd_outs.  `ws` as in
+// vqa_gru_seq_fwd_ws (the same buffer may serve both: the calls do not overlap on a stream).
+extern "C" int vqa_gru_seq_bwd_ws(const float* dh_T, const float* d_outs, const float* Wg_h, const float* Wc_h,
+                                  const int32_t* len, const float* hs, const float* r, const float* u, const float* c,
+                                  float* dxp, int T, int B, int H, void* ws, void* stream) {
+    VQA_REQUIRE(dh_T && Wg_h && Wc_h && len && hs && r && u && c && dxp && ws, VQA_ERR_ARG);
+    VQA_REQUIRE(vqa_gru_ws_bwd_supported(T, B, H) == 1, VQA_ERR_UNSUPPORTED);
+    VQA_REQUIRE((int64_t)T * B * 3 * H * 4 < 0x7FFFFFF0ll && vqa_aligned16(ws) && vqa_aligned16(Wg_h) && vqa_aligned16(Wc_h),
+                VQA_ERR_UNSUPPORTED);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WsBwdArgs a;
+    a.sync = static_cast<unsigned*>(ws);
+    if (hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return VQA_ERR_LAUNCH;
+    a.dcF = static_cast<float*>(ws) + 1024;
+    a.drF = a.dcF + (int64_t)T * WS_FRAG_T;
+    a.duF = a.drF + (int64_t)T * WS_FRAG_T;
+    a.dh_T = dh_T; a.d_outs = d_outs; a.Wg = Wg_h; a.Wc = Wc_h; a.len = len; a.hs = hs; a.r = r; a.u = u; a.c = c; a.dxp = dxp;
+    a.T = T; a.B = B;
+    a.spin_limit = 2000000u;
+    a.stamps = g_ws_stamps;
+    hipLaunchKernelGGL(gru_ws_bwd2_kernel, dim3(WS_CHAINS * WS_CU), dim3(WS_NT), WS_LDS, st, a);
     VQA_CHECK_LAUNCH();
     return VQA_OK;
 }
