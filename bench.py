@@ -428,7 +428,7 @@ def step_groups(cfg):
                       "work": 2.0 * B * R * D * H * 2 + 2.0 * H * 3 * H * T * B,
                       "what": "v_linear_v forward and weight gradient (K 2048 / M 18432), GRU recurrent weight gradients"},
         "recurrence": {"bound": "mfma", "labels": ["gru.fwd", "gru.bwd"], "work": 2 * 2.0 * B * H * 3 * H * T,
-                       "what": "28 + 28 fused GRU step kernels, forward and back-propagation through time"},
+                       "what": "GRU recurrence, forward and back-propagation through time: one weight-stationary persistent launch per direction (csrc/gru_ws.hip; the 28 + 28 fused step kernels where it does not apply)"},
         "k300_gemms": {"bound": "mfma", "labels": ["gru.xp_gemm", "gru.dx_gemm", "gru.dwx_gemm"],
                        "work": 2.0 * T * B * 3 * H * (2 * W + Wp),
                        "what": "packed x-projection of all time steps, its dx and its weight gradient (K or N = 300)"},

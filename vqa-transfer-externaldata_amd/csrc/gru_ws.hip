@@ -841,6 +841,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned bh_step = (unsigned)(BH * 4), xp_step = (unsigned)((int64_t)B * 3 * H * 4);
 
+    f32x4n tr[2], tu[2], tc[2], th[2], td[2];      // tape values a half-chain's next tails need (see tape_fetch)
     f32x4n acc_own[2], hp_own[2];       // running dL/dh_{t-1} (partial), h_{t-1} of the step being differentiated
     int len_own[2];
     unsigned o_std[2], o_xp[2];
@@ -885,14 +886,29 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         ws_store2(rs_dxp, o_xp[hf], (unsigned)t * xp_step + H * 4, du, false);
         ws_store2(rs_duF, lane16, frag_st(t, hf), du, false);
         ws_store2(rs_dcF, lane16, frag_st(t, hf), dc, false);
+        tr[hf] = ws_load2(rs_r, o_std[hf], (unsigned)t * bh_step);
     }
     __syncthreads();                    // the W_c^T slab is in LDS
     ws_arrive(ctr0, j, 1u);
     ws_arrive(ctr1, j, 1u);
 
     // ---- tails (micro-step schedule of the forward kernel)
-    f32x4n va, vb, vc, vd, ve;          // tail temporaries / prefetched tape values
+    f32x4n va, vb;                      // tail temporaries
     f32x4n p0[4];
+    // The tape comes from HBM (it was written a millisecond ago) and a wave's loads return in order: a tape load holds back
+    // every fragment load issued behind it.  All tape values a half-chain needs next -- u, c, h_prev (d_outs) of step t-1
+    // for the tail of B(hf,t), r of step t-1 for the tail of A(hf,t-1) -- are fetched at the head of the B(hf,t) stream,
+    // where the operand ring is 16 deep: 16 octets of 256 cycles are the cover a 2 us load needs (the A streams keep 8).
+    auto tape_fetch = [&](int k, int t, int hf) {
+        if (k == -4) {
+            const unsigned so = ws_uni((unsigned)(t - 1) * bh_step);
+            tu[hf] = ws_load2(rs_u, o_std[hf], so);
+            tc[hf] = ws_load2(rs_c, o_std[hf], so);
+            th[hf] = ws_load2(rs_hs, o_std[hf], so);
+            tr[hf] = ws_load2(rs_r, o_std[hf], so);
+            if (a.d_outs != nullptr) td[hf] = ws_load2(rs_do, o_std[hf], so);
+        }
+    };
     auto spill_fetch = [&](int k, const f32x16& P) {
         if (k >= 1 && k <= 8) {
 #pragma unroll
@@ -904,14 +920,13 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         if (k == 9) ws_lds_barrier();
         if (k >= 10 && k <= 13) p0[k - 10] = *reinterpret_cast<const f32x4n*>(S + (k - 10) * 1024 + cfetch);
     };
-    // tail of A(hf,t): dr_pre out, acc_own += drh r           (vd = r[t], fetched at k = 0)
+    // tail of A(hf,t): dr_pre out, acc_own += drh r
     auto a_tail = [&](int k, int t, int hf, const f32x16& P, unsigned* ctr, unsigned epoch) {
-        if (k == 0) vd = ws_load2(rs_r, o_std[hf], ws_uni((unsigned)t * bh_step));
         spill_fetch(k, P);
         if (k == 15) va = p0[0] + p0[1] + p0[2] + p0[3];                       // drh
         if (k == 17) {
-            acc_own[hf] += va * vd;
-            vb = va * hp_own[hf] * vd * ((f32x4n)(1.f) - vd);                   // dr_pre
+            acc_own[hf] += va * tr[hf];
+            vb = va * hp_own[hf] * tr[hf] * ((f32x4n)(1.f) - tr[hf]);           // dr_pre
         }
         if (k == 33) ws_store2(rs_dxp, o_xp[hf], ws_uni((unsigned)t * xp_step), vb, false);
         if (k == 39) ws_store2(rs_drF, lane16, ws_uni(frag_st(t, hf)), vb, false);
@@ -920,21 +935,14 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             ws_flag_store(ctr, j, epoch);
         }
     };
-    // tail of B(hf,t), t > 0: g = dL/dh_{t-1}, then the first half of step t-1      (vc, vd, ve = u, c, h_prev of step t-1)
+    // tail of B(hf,t), t > 0: g = dL/dh_{t-1}, then the first half of step t-1
     auto b_tail = [&](int k, int t, int hf, const f32x16& P, unsigned* ctr, unsigned epoch, bool live) {
-        const unsigned so = ws_uni((unsigned)(t - 1) * bh_step);
-        if (k == 0) {
-            vc = ws_load2(rs_u, live ? o_std[hf] : OOB, so);
-            vd = ws_load2(rs_c, live ? o_std[hf] : OOB, so);
-            ve = ws_load2(rs_hs, live ? o_std[hf] : OOB, so);
-        }
-        if (k == 2 && a.d_outs != nullptr) vb = ws_load2(rs_do, live ? o_std[hf] : OOB, so);
         spill_fetch(k, P);
         if (k == 15) {
             va = p0[0] + p0[1] + p0[2] + p0[3] + acc_own[hf];
-            if (a.d_outs != nullptr) va += vb;
+            if (a.d_outs != nullptr) va += td[hf];
         }
-        if (k == 17 && live) half_step(t - 1, hf, va, vc, vd, ve, va, vb);      // va = dc_pre, vb = du_pre afterwards
+        if (k == 17 && live) half_step(t - 1, hf, va, tu[hf], tc[hf], th[hf], va, vb);      // va = dc_pre, vb = du_pre afterwards
         if (k == 33) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + 2 * H * 4), va, false);
         if (k == 35) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + H * 4), vb, false);
         if (k == 37) ws_store2(rs_duF, live ? lane16 : OOB, ws_uni(frag_st(t - 1, hf)), vb, false);
@@ -953,14 +961,14 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         }
     };
 
-    f32x4n ring[8];
+    f32x4n ring[16];                    // the A streams use slots 0..7
     ws_wait(ctr0, 1u, err, a.spin_limit);
 #pragma unroll
     for (int m = 0; m < 8; ++m) ring[m] = ws_load2(rs_dcF, lane16, frag_a(T - 1, 0) + m * 1024);
 
     // A stream: 32 octets against the LDS slab (128 slots of one MFMA); B stream: 64 octets against the register slab
     // (128 slots of two MFMAs).  HOOK(slot - 4) in every slot; the ring's last 8 refills fetch the NEXT stream's head.
-#define WS_A_STREAM(acc0, acc1, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                                    \
+#define WS_A_STREAM(acc0, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                                    \
     {                                                                                                          \
         f32x4n bq[2];                                                                                          \
         bq[0] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w) * 64 + lane) * 4);                             \
@@ -970,22 +978,26 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             const f32x4n av = ring[m % 8];                                                                     \
             const f32x4n bv = bq[m & 1];                                                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-                if (m & 1) acc1 = WS_MFMA(av[i], bv[i], acc1);                                                 \
-                else acc0 = WS_MFMA(av[i], bv[i], acc0);                                                       \
+                acc0 = WS_MFMA(av[i], bv[i], acc0);      /* one chain: 66 against 64.6 cycles per MFMA, 16 registers saved */ \
                 if (i == 1 && m + 2 < 32)                                                                      \
                     bq[m & 1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + m + 2) * 64 + lane) * 4);     \
                 if (i == 3) {                                                                                  \
-                    if (m + 8 < 32) ring[m % 8] = ws_load2(rs_dcF, lane16, (base_cur) + (m + 8) * 1024);        \
-                    else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 32) * 1024);          \
+                    if (m + 8 < 32) ring[m % 8] = ws_load2(rs_dcF, lane16, (base_cur) + (m + 8) * 1024);       \
+                    else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 32) * 1024);         \
                 }                                                                                              \
                 HOOK(4 * m + i - 4);                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                                  \
         }                                                                                                      \
     }
-#define WS_B_STREAM(accA, accB, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                                    \
+    // B stream: 16 fragments ahead.  TOPUP: entered from an A stream, whose ring left fragments 0..7 -- fetch 8..15 now.
+    // NEXT_A: followed by an A stream -- only its fragments 0..7 are fetched at the end (ring slots 0..7).
+#define WS_B_STREAM(accA, accB, base_cur, TOPUP, NEXT_A, rs_nxt, base_nxt, voff_nxt, HOOK)                     \
+    if (TOPUP) {                                                                                               \
+        _Pragma("unroll") for (int f = 8; f < 16; ++f) ring[f] = ws_load2(rs_bF, lane16, (base_cur) + f * 1024); \
+    }                                                                                                          \
     _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                           \
-        const f32x4n av = ring[m % 8];                                                                         \
+        const f32x4n av = ring[m % 16];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
             if (m < 2) {                                                                                       \
                 if (i == 0) { if (m == 0) WS_MFMA_AGPR_B0(accA, av[i], wq[m][i]); else WS_MFMA_AGPR_B0(accB, av[i], wq[m][i]); } \
@@ -996,8 +1008,9 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
                 if (m & 1) WS_MFMA_VGPR_B(accB, av[i], wq[m][i]); else WS_MFMA_VGPR_B(accA, av[i], wq[m][i]);   \
             }                                                                                                  \
             if (i == 3) {                                                                                      \
-                if (m + 8 < 64) ring[m % 8] = ws_load2(rs_bF, lane16, (base_cur) + (m + 8) * 1024);            \
-                else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 64) * 1024);             \
+                if (m + 16 < 64) ring[m % 16] = ws_load2(rs_bF, lane16, (base_cur) + (m + 16) * 1024);         \
+                else if (!(NEXT_A)) ring[m % 16] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 16 - 64) * 1024); \
+                else if (m >= 56) ring[m - 56] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m - 56) * 1024);   \
             }                                                                                                  \
             if (i & 1) {                                                                                       \
                 HOOK(2 * m + (i >> 1) - 4);                                                                    \
@@ -1016,27 +1029,23 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         const bool more = t > 0;        // the B streams of this step exist
         // ---------------- A(0,t); in its gaps: the tail of B(1,t+1), then the way into A(1,t)
         {
-            f32x16 x;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { pA0[q] = 0.f; x[q] = 0.f; }
+            for (int q = 0; q < 16; ++q) pA0[q] = 0.f;
             auto hook = [&](int k) {
                 b_tail(k, t + 1, 1, pB1, ctr1, 1u + n, s > 0);
                 way_in(k, ctr1, 1u + n);
             };
-            WS_A_STREAM(pA0, x, frag_a(t, 0), rs_dcF, frag_a(t, 1), lane16, hook)
-            pA0 += x;
+            WS_A_STREAM(pA0, frag_a(t, 0), rs_dcF, frag_a(t, 1), lane16, hook)
         }
         // ---------------- A(1,t); tail of A(0,t); way into B(0,t)
         {
-            f32x16 x;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { pA1[q] = 0.f; x[q] = 0.f; }
+            for (int q = 0; q < 16; ++q) pA1[q] = 0.f;
             auto hook = [&](int k) {
                 a_tail(k, t, 0, pA0, ctr0, 2u + n);
                 way_in(k, ctr0, more ? 2u + n : 0u);
             };
-            WS_A_STREAM(pA1, x, frag_a(t, 1), rs_bF, more ? frag_b(t, 0) : 0u, more ? lane16 : OOB, hook)
-            pA1 += x;
+            WS_A_STREAM(pA1, frag_a(t, 1), rs_bF, more ? frag_b(t, 0) : 0u, more ? lane16 : OOB, hook)
         }
         if (!more) break;
         // ---------------- B(0,t); tail of A(1,t); way into B(1,t)
@@ -1045,8 +1054,9 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             auto hook = [&](int k) {
                 a_tail(k, t, 1, pA1, ctr1, 2u + n);
                 way_in(k, ctr1, 2u + n);
+                tape_fetch(k, t, 0);
             };
-            WS_B_STREAM(pB0, x, frag_b(t, 0), rs_bF, frag_b(t, 1), lane16, hook)
+            WS_B_STREAM(pB0, x, frag_b(t, 0), true, false, rs_bF, frag_b(t, 1), lane16, hook)
             WS_MFMA_DRAIN();
             pB0 += x;
         }
@@ -1056,15 +1066,16 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             auto hook = [&](int k) {
                 b_tail(k, t, 0, pB0, ctr0, 3u + n, true);
                 way_in(k, ctr0, 3u + n);
+                tape_fetch(k, t, 1);
             };
-            WS_B_STREAM(pB1, x, frag_b(t, 1), rs_dcF, frag_a(t - 1, 0), lane16, hook)
+            WS_B_STREAM(pB1, x, frag_b(t, 1), false, true, rs_dcF, frag_a(t - 1, 0), lane16, hook)
             WS_MFMA_DRAIN();
             pB1 += x;
         }
     }
     // ---------------- the tail of A(1,0), on its own
 #pragma unroll
-    for (int k = 0; k <= 39; ++k) a_tail(k, 0, 1, pA1, ctr1, 2u * T);
+    for (int k = 1; k <= 39; ++k) a_tail(k, 0, 1, pA1, ctr1, 2u * T);
     ws_arrive(ctr1, j, 2u * T);
 #undef WS_A_STREAM
 #undef WS_B_STREAM
