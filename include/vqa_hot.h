@@ -261,7 +261,7 @@ int vqa_gru_seq_bwd_ws(const float* dh_T, const float* d_outs, const float* Wg_h
                        void* ws, void* stream);
 int vqa_gru_ws_bwd_supported(int T, int B, int H);
 int64_t vqa_gru_ws_workspace_bytes(int T);
-int vqa_gru_ws_set_mode(int mode);      /* -1 automatic, 0 never, 1 whenever supported */
+int vqa_gru_ws_set_mode(int mode);      /* bit 0: forward, bit 1: back-propagation, wherever they apply; -1 = 3 (default) */
 int vqa_gru_ws_set_form(int form);      /* tuning: 0 = sub-phase tails inside the next matrix stream (default), 1 = plain order */
 int vqa_gru_ws_set_stamps(unsigned long long* dev_words);   /* timing study (tools/gru_tune.py); NULL = off */
 

@@ -46,6 +46,19 @@ def tm(f, n=30):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def tm_cold(f, n=10):
+    """each call timed on its own after 1 GiB of unrelated writes (weights, tape and xp out of the caches, as in a step)"""
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    ts = []
+    for _ in range(n):
+        big.zero_()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 sync = torch.zeros(int(lib.vqa_gru_persistent_sync_bytes()) // 4, dtype=torch.int32, device="cuda")
 
 
@@ -105,6 +118,7 @@ if os.environ.get("WS") == "1":
         x.fill_(float("nan"))
     hs[1:].fill_(float("nan"))
     stamps = torch.zeros(2048, dtype=torch.int64, device="cuda")
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); big.zero_()      # the stamped launch starts from cold caches
     lib.vqa_gru_ws_set_stamps(P(stamps)); fwd_ws(); torch.cuda.synchronize(); lib.vqa_gru_ws_set_stamps(None)
     words = ws[:1024].view(torch.int32)
     print("ws: flags (min, max per half-chain)", [(int(words[32 * i: 32 * i + 32].min()), int(words[32 * i: 32 * i + 32].max())) for i in range(16)],
@@ -129,6 +143,7 @@ if os.environ.get("WS") == "1":
                 (t,) + tuple(d[4 * t: 4 * t + 4]) + (d[4 * t: 4 * t + 4].sum(),) + tuple(int(x) for x in dc[4 * t: 4 * t + 4]) +
                 (dc[4 * t: 4 * t + 4].sum() / d[4 * t: 4 * t + 4].sum() / 1e3,)))
         print("    all streams %.2f us; a gate stream is 256 MFMAs per wave = 16384 cycles, a candidate stream 8192" % (wall[-1] - wall[0]), flush=True)
+        print("    prologue (kernel entry -> first stream: placement, weights into registers and LDS, h_0 hand-off), cold caches: %.2f us" % ((raw[2047] - raw[2046]) / 100.0), flush=True)
         sl = stamps[1024:1536].cpu().numpy().astype("int64")
         if sl.any():        # a -DWS_SLOTS=1 build: cycles per slot of step 5 (a slot = 2 MFMAs in G streams, 1 in C streams)
             for si, nm in enumerate(("G0", "G1", "C0", "C1")):
@@ -138,6 +153,7 @@ if os.environ.get("WS") == "1":
                     print("      %3d: %s" % (r0 + 1, " ".join("%4d" % x for x in d[r0: r0 + 16])))
     for rep in range(3):
         print("  forward: stepwise %.1f us   weight-stationary %.1f us" % (tm(fwd), tm(fwd_ws)), flush=True)
+    print("  forward from cold caches (median of 10): stepwise %.1f us   weight-stationary %.1f us" % (tm_cold(fwd), tm_cold(fwd_ws)), flush=True)
     sys.exit(0)
 
 if os.environ.get("WSB") == "1":
@@ -160,6 +176,7 @@ if os.environ.get("WSB") == "1":
         print("  max |%s - stepwise| = %.3e  (max |.| %.3e)  nan %d" % (nm, float((a_ - b_).abs().max()), float(a_.abs().max()), int(torch.isnan(b_).sum())), flush=True)
     for rep in range(3):
         print("  backward: stepwise %.1f us   weight-stationary %.1f us" % (tm(bwd), tm(bwd_ws)), flush=True)
+    print("  backward from cold caches (median of 10): stepwise %.1f us   weight-stationary %.1f us" % (tm_cold(bwd), tm_cold(bwd_ws)), flush=True)
     sys.exit(0)
 
 if os.environ.get("GRAPH") == "1":

@@ -38,13 +38,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WS_DBG
 #define WS_DBG 0
 #endif
-// operand fragments in flight per wave in the spliced form (its tails' stores and slow loads sit in the same in-order
-// queue as the fragment loads: the deeper ring is their cover)
 #ifndef WS_SLOTS
 #define WS_SLOTS 0      // timing study: shader-clock stamp in every slot of step 5's four streams (tools/gru_tune.py WS_SLOTS=1)
-#endif
-#ifndef WS_RING2
-#define WS_RING2 8      // (8 or 16: the ring carries over from stream to stream, so its depth divides the 32 octets)
 #endif
 
 namespace {
@@ -197,12 +192,19 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wg[cb][m][i] = p[(int64_t)(8 * m + i) * (2 * H) + cb * H];
     }
-    for (int idx = tid; idx < 128 * 64; idx += WS_NT) {
-        const int oct = idx >> 6, l = idx & 63;
-        const float* p = a.Wc + (int64_t)(8 * oct + 4 * (l >> 5)) * H + 32 * j + (l & 31);
-        f32x4n v;
-        v.x = p[0]; v.y = p[H]; v.z = p[2 * H]; v.w = p[3 * H];
-        *reinterpret_cast<f32x4n*>(Wl + idx * 4) = v;
+    // (all of a thread's 32 x 4 loads in flight before the first LDS write: left as a loop of load-load-load-load-store
+    // the fill is 32 dependent round trips, 30 us from cold caches)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4n tmp[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int idx = tid + (16 * half + n) * WS_NT, oct = idx >> 6, l = idx & 63;
+            const float* p = a.Wc + (int64_t)(8 * oct + 4 * (l >> 5)) * H + 32 * j + (l & 31);
+            tmp[n].x = p[0]; tmp[n].y = p[H]; tmp[n].z = p[2 * H]; tmp[n].w = p[3 * H];
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) *reinterpret_cast<f32x4n*>(Wl + (tid + (16 * half + n) * WS_NT) * 4) = tmp[n];
     }
 
     // ---- this thread's float4 of every 32 x 32 tile: row lane % 32, state columns 32 j + 8 w + 4 (lane / 32) + 0..3
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
     float* Wl = smem;
     float* S = smem + 32768;
     constexpr int H = WS_H;
+    const unsigned long long t_entry = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     int chain, j;
     ws_place(a.sync, reinterpret_cast<int*>(S), chain, j);
@@ -457,12 +460,19 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wg[cb][m][i] = p[(int64_t)(8 * m + i) * (2 * H) + cb * H];
     }
-    for (int idx = tid; idx < 128 * 64; idx += WS_NT) {
-        const int oct = idx >> 6, l = idx & 63;
-        const float* p = a.Wc + (int64_t)(8 * oct + 4 * (l >> 5)) * H + 32 * j + (l & 31);
-        f32x4n v;
-        v.x = p[0]; v.y = p[H]; v.z = p[2 * H]; v.w = p[3 * H];
-        *reinterpret_cast<f32x4n*>(Wl + idx * 4) = v;
+    // (all of a thread's 32 x 4 loads in flight before the first LDS write: left as a loop of load-load-load-load-store
+    // the fill is 32 dependent round trips, 30 us from cold caches)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4n tmp[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int idx = tid + (16 * half + n) * WS_NT, oct = idx >> 6, l = idx & 63;
+            const float* p = a.Wc + (int64_t)(8 * oct + 4 * (l >> 5)) * H + 32 * j + (l & 31);
+            tmp[n].x = p[0]; tmp[n].y = p[H]; tmp[n].z = p[2 * H]; tmp[n].w = p[3 * H];
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) *reinterpret_cast<f32x4n*>(Wl + (tid + (16 * half + n) * WS_NT) * 4) = tmp[n];
     }
 
     const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
@@ -631,16 +641,20 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
         }
     };
 
-    f32x4n ring[WS_RING2];
+    f32x4n ring[16];                    // the candidate streams use slots 0..7
     ws_wait(ctr0, 1u, err, a.spin_limit);
 #pragma unroll
-    for (int m = 0; m < WS_RING2; ++m) ring[m] = ws_load2(rs_hF, lane16, frag_ld(0, 0) + m * 1024);
+    for (int m = 0; m < 8; ++m) ring[m] = ws_load2(rs_hF, lane16, frag_ld(0, 0) + m * 1024);
 
     // one sub-phase's matrix stream: 32 octets of this wave's k quarter, HOOK(slot - 4) in every slot
     // (cur: this sub-phase's fragments; nxt: the next one's, fetched into the ring slots as they fall free)
 #define WS_GATE_STREAM(accR, accU, rs_cur, base_cur, rs_nxt, base_nxt, voff_nxt, HOOK)                         \
+    /* 16 fragments ahead inside a gate stream (xp loads -- Infinity Cache or HBM, returned in order with the  */ \
+    /* fragments -- are issued at its head: 16 octets of 512 cycles are their cover); every stream hands the   */ \
+    /* next one 8 fragments, so a gate stream fetches its fragments 8..15 on entry                              */ \
+    _Pragma("unroll") for (int f = 8; f < 16; ++f) ring[f] = ws_load2(rs_cur, lane16, (base_cur) + f * 1024);  \
     _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                           \
-        const f32x4n av = ring[m % WS_RING2];                                                                   \
+        const f32x4n av = ring[m % 16];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
             if (m == 0 && i == 0) {                                                                            \
                 WS_MFMA_AGPR_B0(accR, av[i], wg[0][m][i]);                                                     \
@@ -653,8 +667,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
                 WS_MFMA_VGPR_B(accU, av[i], wg[1][m][i]);                                                      \
             }                                                                                                  \
             if (i == 3) {                                                                                      \
-                if (m + WS_RING2 < 32) ring[m % WS_RING2] = ws_load2(rs_cur, lane16, (base_cur) + (m + WS_RING2) * 1024);  \
-                else ring[m % WS_RING2] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + WS_RING2 - 32) * 1024); \
+                if (m + 16 < 32) ring[m % 16] = ws_load2(rs_cur, lane16, (base_cur) + (m + 16) * 1024);        \
+                else if (m >= 24) ring[m - 24] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m - 24) * 1024);   \
             }                                                                                                  \
             HOOK(4 * m + i - 4);                                                                               \
             if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();              \
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
         bq[1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + 1) * 64 + lane) * 4);                         \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                       \
-            const f32x4n av = ring[m % WS_RING2];                                                               \
+            const f32x4n av = ring[m % 8];                                                                     \
             const f32x4n bv = bq[m & 1];                                                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
                 if (m & 1) acc1 = WS_MFMA(av[i], bv[i], acc1);                                                 \
@@ -676,8 +690,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
                 if (i == 1 && m + 2 < 32)                                                                      \
                     bq[m & 1] = *reinterpret_cast<const f32x4n*>(Wl + ((32 * w + m + 2) * 64 + lane) * 4);     \
                 if (i == 3) {                                                                                  \
-                    if (m + WS_RING2 < 32) ring[m % WS_RING2] = ws_load2(rs_cur, lane16, (base_cur) + (m + WS_RING2) * 1024); \
-                    else ring[m % WS_RING2] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + WS_RING2 - 32) * 1024); \
+                    if (m + 8 < 32) ring[m % 8] = ws_load2(rs_cur, lane16, (base_cur) + (m + 8) * 1024);       \
+                    else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 32) * 1024);         \
                 }                                                                                              \
                 HOOK(4 * m + i - 4);                                                                           \
                 if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();          \
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) cA1[q] = 0.f;
     unsigned long long* stamp = (a.stamps != nullptr && blockIdx.x == 0 && tid == 0) ? a.stamps : nullptr;
+    if (stamp) { stamp[2046] = t_entry; stamp[2047] = wall_clock64(); }      // prologue: entry -> first stream
     long long* slots = (WS_SLOTS && stamp != nullptr) ? reinterpret_cast<long long*>(a.stamps) + 1024 : nullptr;      // 4 x 128 slot stamps of step 5
 
     for (int t = 0; t < T; ++t) {
@@ -817,10 +832,15 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             wq[m][0] = v.x; wq[m][1] = v.y; wq[m][2] = v.z; wq[m][3] = v.w;
         }
     }
-    for (int idx = tid; idx < 128 * 64; idx += WS_NT) {
-        const int oct = idx >> 6, l = idx & 63;
-        *reinterpret_cast<f32x4n*>(Wl + idx * 4) =
-            *reinterpret_cast<const f32x4n*>(a.Wc + (int64_t)(32 * j + (l & 31)) * H + 8 * oct + 4 * (l >> 5));
+    {
+        f32x4n tmp[32];                 // all 32 loads in flight before the first LDS write
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const int idx = tid + n * WS_NT, oct = idx >> 6, l = idx & 63;
+            tmp[n] = *reinterpret_cast<const f32x4n*>(a.Wc + (int64_t)(32 * j + (l & 31)) * H + 8 * oct + 4 * (l >> 5));
+        }
+#pragma unroll
+        for (int n = 0; n < 32; ++n) *reinterpret_cast<f32x4n*>(Wl + (tid + n * WS_NT) * 4) = tmp[n];
     }
 
     const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
@@ -1111,14 +1131,14 @@ const WsDevice& ws_device() {
     }
     return d;
 }
-int g_ws_mode = -1;                     // -1 automatic, 0 off, 1 on wherever it applies
+int g_ws_mode = 3;                      // bit 0: forward, bit 1: back-propagation (wherever they apply)
 int g_ws_form = 0;                      // tuning: 1 = the plain sub-phase order also for two half-chains (A/B of the splice)
 unsigned long long* g_ws_stamps = nullptr;
 
 }  // namespace
 
 extern "C" int vqa_gru_ws_set_mode(int mode) {
-    g_ws_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    g_ws_mode = mode < 0 ? 3 : (mode & 3);
     return VQA_OK;
 }
 extern "C" int vqa_gru_ws_set_form(int form) {
@@ -1133,7 +1153,7 @@ extern "C" int vqa_gru_ws_set_stamps(unsigned long long* dev_words) {
 // 1 when the weight-stationary recurrence applies: H = 1024, at most 512 rows (eight chains of 64), and a device of
 // exactly 8 x 32 CUs on which one 160 KB / 256-thread workgroup per CU is resident.
 extern "C" int vqa_gru_ws_supported(int T, int B, int H) {
-    if (g_ws_mode == 0) return 0;
+    if (!(g_ws_mode & 1)) return 0;
     if (T <= 0 || H != WS_H || B <= 0 || B > WS_CHAINS * 64) return 0;
     const WsDevice& d = ws_device();
     return (d.cus == WS_CHAINS * WS_CU && d.blocks >= 1) ? 1 : 0;
@@ -1178,7 +1198,7 @@ extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const floa
 // 1 when the weight-stationary back-propagation applies: as the forward form, and more than 256 rows (it exists in the
 // two-half form only)
 extern "C" int vqa_gru_ws_bwd_supported(int T, int B, int H) {
-    if (g_ws_mode == 0) return 0;
+    if (!(g_ws_mode & 2)) return 0;
     if (T <= 0 || H != WS_H || B <= 256 || B > WS_CHAINS * 64) return 0;
     const WsDevice& d = ws_device();
     return (d.cus == WS_CHAINS * WS_CU && d.blocks_bwd >= 1) ? 1 : 0;

@@ -62,6 +62,20 @@ def allreduce_flat_(flat, group=None, bucket_floats=None):
     return flat
 
 
+def _keep_the_collectives_company(group=None):
+    """The weight-stationary GRU back-propagation (csrc/gru_ws.hip) is one launch of 256 workgroups that must ALL be resident
+    (one per CU, 160 KB of LDS each) before any of them gets past its first step.  Under RCCL the first gradient bucket's
+    all-reduce kernel is running on some CUs when that launch arrives: the recurrence would wait for the collective to end
+    instead of running beside it.  So with more than one rank on RCCL the back-propagation stays on the per-step kernels
+    (the forward form, which has no collective beside it, stays on); VQA_HOT_GRU_WS_DP=1 keeps both (unmeasured: no
+    multi-GPU node was available to this build)."""
+    import os
+    if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+            and dist.get_backend(group) == "nccl" and os.environ.get("VQA_HOT_GRU_WS_DP") != "1"):
+        from . import _lib
+        _lib.load().vqa_gru_ws_set_mode(1)
+
+
 class GradAllReduce:
     """Callable handed to FusionEngine.train_step(allreduce=...)."""
 
@@ -84,6 +98,7 @@ class BucketedAllReduce:
 
     def __init__(self, group=None, timing=False):
         self.group = group
+        _keep_the_collectives_company(group)
         self._works = []
         self.timing = timing          # bench.py: measure the time the compute stream spends blocked in finish()
         self._events = []             # (before, after) event pairs on the compute stream, one per finish()
