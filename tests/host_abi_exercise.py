@@ -162,4 +162,18 @@ ok(lib.vqa_clock_sample(500.0, 8, 8, None, None) == -1 and lib.vqa_clock_sample(
    lib.vqa_clock_sample(1e5, 4096, 8, C.c_void_p(4096), None) == -1, "clock sampler arguments")
 ok(lib.vqa_gemm_set_gru_config(30) == 0 and lib.vqa_gemm_set_gru_config(19) == -1 and lib.vqa_gemm_set_gru_config(-1) == 0, "gru config ids")
 
+# weight-stationary recurrence: sizes, refusals and switches (no launch: no GPU here, so "supported" is 0 for every shape)
+ok(lib.vqa_gru_ws_workspace_bytes(14) == ((3 * 14 + 1) * 8 * 2 * 128 * 256 + 1024) * 4 and lib.vqa_gru_ws_workspace_bytes(-1) == 0, "ws workspace")
+ok(lib.vqa_gru_ws_workspace_bytes(1) % 16 == 0, "ws workspace alignment")
+for (T, B, H) in ((14, 512, 1024), (14, 513, 1024), (0, 512, 1024), (14, 512, 512), (3, 0, 1024)):
+    ok(lib.vqa_gru_ws_supported(T, B, H) == 0 and lib.vqa_gru_ws_bwd_supported(T, B, H) == 0, "ws needs a device %r" % ((T, B, H),))
+p4 = C.c_void_p(4096)
+ok(lib.vqa_gru_seq_fwd_ws(None, p4, p4, p4, p4, p4, p4, p4, p4, 14, 512, 1024, p4, None) == -1, "ws forward null xp")
+ok(lib.vqa_gru_seq_fwd_ws(p4, p4, p4, p4, p4, p4, p4, p4, p4, 14, 512, 1024, None, None) == -1, "ws forward null workspace")
+ok(lib.vqa_gru_seq_fwd_ws(p4, p4, p4, p4, p4, p4, p4, p4, p4, 14, 512, 1024, p4, None) == -4, "ws forward without a device")
+ok(lib.vqa_gru_seq_bwd_ws(None, None, p4, p4, p4, p4, p4, p4, p4, p4, 14, 512, 1024, p4, None) == -1, "ws backward null dh")
+ok(lib.vqa_gru_seq_bwd_ws(p4, None, p4, p4, p4, p4, p4, p4, p4, p4, 14, 512, 1024, p4, None) == -4, "ws backward without a device")
+ok(lib.vqa_gru_ws_set_mode(1) == 0 and lib.vqa_gru_ws_set_mode(0) == 0 and lib.vqa_gru_ws_set_mode(-1) == 0, "ws mode")
+ok(lib.vqa_gru_ws_set_form(3) == 0 and lib.vqa_gru_ws_set_form(0) == 0 and lib.vqa_gru_ws_set_stamps(None) == 0, "ws tuning switches")
+
 print("host ABI exercise: %d checks passed on %s" % (checks, _lib.lib_path()))
