@@ -469,17 +469,25 @@ def clock_pass(eng, lib, batches, rank, step_ms, steps=12):
         ka, kj = eng.make_keep_masks(seed=11 + rank, step=2000 + i)
         eng.train_step(batches[i % len(batches)], ka, kj, 1e-3)
     torch.cuda.synchronize()
-    _lib.check(lib.vqa_clock_sample(us, n, wgs, C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)), "vqa_clock_sample")
-    for i in range(steps + 2):
-        ka, kj = eng.make_keep_masks(seed=11 + rank, step=2002 + i)
-        eng.train_step(batches[i % len(batches)], ka, kj, 1e-3)
-    torch.cuda.synchronize()
+    # The sampler's waves sit on eight CUs for the whole pass; the weight-stationary recurrence (csrc/gru_ws.hip) needs every
+    # SIMD's whole register file on all 256 CUs and would wait for the sampler to leave.  The sampled steps therefore run the
+    # per-step recurrence kernels (same matrix work, 56 launches instead of 2 per direction).
+    lib.vqa_gru_ws_set_mode(0)
+    try:
+        _lib.check(lib.vqa_clock_sample(us, n, wgs, C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)), "vqa_clock_sample")
+        for i in range(steps + 2):
+            ka, kj = eng.make_keep_masks(seed=11 + rank, step=2002 + i)
+            eng.train_step(batches[i % len(batches)], ka, kj, 1e-3)
+        torch.cuda.synchronize()
+    finally:
+        lib.vqa_gru_ws_set_mode(-1)
     g = out.cpu().numpy()[:, 1:-1]                 # (first and last period: ramps)
     ghz = float(g.mean())                          # equal periods: cycles of the whole pass / its duration
     return {"shader_ghz": ghz, "median": float(np.median(g)), "min": float(g.min()), "max": float(g.max()), "nominal_ghz": 2.4,
             "f32_mfma_peak_at_clock": F32_MFMA_PEAK_TFLOPS * ghz / 2.4,
             "how": "mean over %d samples of %.1f ms on %d sampler waves (one per XCD) while %d train steps ran; "
-                   "cycles = s_memtime, time = s_memrealtime (100 MHz)" % (g.size, us / 1e3, wgs, steps)}
+                   "cycles = s_memtime, time = s_memrealtime (100 MHz); the sampled steps run the per-step recurrence kernels (the "
+                   "weight-stationary launches cannot share a CU with the sampler's waves)" % (g.size, us / 1e3, wgs, steps)}
 
 
 def groups_pass(eng, lib, batches, cfg, rank, steps=10):

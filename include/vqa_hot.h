@@ -247,7 +247,8 @@ int vqa_gru_persistent_set_census(unsigned* dev_words);   /* placement study (to
  * half-chains in anti-phase on the same waves).  Applies to H = 1024, B <= 512 on a device of 8 x 32 CUs
  * (vqa_gru_ws_supported).  `ws`: vqa_gru_ws_workspace_bytes(T) bytes of 16-byte-aligned device memory, contents
  * irrelevant (fragment-order hand-off buffers and counters; the call zeroes the counters).  After the stream has run
- * a non-zero 32-bit word at byte offset 2048 of `ws` reports a barrier time-out (results invalid).
+ * a non-zero 32-bit word at byte offset 2048 of `ws` reports a barrier time-out of this launch (results invalid);
+ * the word at byte offset 4092 is set with it and cleared by no launch: zero it once, look whenever convenient.
  * Replaces the loop of vlmap/modules.py:124-140 (dynamic_rnn over GRUCell). */
 int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs, float* r,
                        float* u, float* c, float* rh, int T, int B, int H, void* ws, void* stream);

@@ -500,3 +500,24 @@ def test_tuning_switches_of_the_step_keep_parity():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "9 passed" in r.stdout, r.stdout[-500:]       # the nine fusion fixtures
+
+
+def test_recurrence_time_out_is_raised_where_results_are_fetched():
+    """FusionEngine.check_recurrence: the sticky error word of the weight-stationary GRU launches (set when their bounded waits
+    give up, csrc/gru_ws.hip) turns report() into an exception instead of numbers; a healthy step leaves it at zero."""
+    from vqa_transfer_externaldata_amd import _lib
+    dims = dict(Vq=300, W=300, D=128, H=1024, A=40)
+    p, table, nbox, batch, am, masks = make_case(91, "vlmap_answer", 8, 4, 5, 16, dims)
+    eng = make_engine("vlmap_answer", p, table, nbox, am, 8, 4, 5, dims)
+    db = dev_batch(batch)
+    ka, kj = eng.make_keep_masks(3, 0)
+    eng.train_step(db, ka, kj, 1e-3)
+    assert np.isfinite(eng.report()["answer_train_loss"])
+    if eng._ws_err_word is False:
+        pytest.skip("no weight-stationary recurrence buffer for this shape")
+    eng._ws_err_word.fill_(1)
+    with pytest.raises(_lib.VqaHotError, match="recurrence timed out"):
+        eng.report()
+    eng._ws_err_word.zero_()
+    eng.train_step(db, ka, kj, 1e-3)
+    assert np.isfinite(eng.report()["answer_train_loss"])

@@ -703,6 +703,8 @@ def test_weight_stationary_gru_forward_equals_stepwise(T, B):
                 torch.cuda.synchronize()
                 words = ws[:1024].view(torch.int32)
                 assert int(words[512]) == 0                                   # no barrier time-out
+                assert int(words[1023]) == (0x7FC00000 if rep == 0 else 5)    # the sticky word: launches never touch it (NaN fill, then 5)
+                words[1023] = 5
                 assert words[576:584].tolist() == [32] * 8                    # every XCD hosted 32 of the 256 workgroups
                 for chain in range(8):      # a flag per (half-chain, CU): h_0 + 2 sub-phases per step handed off
                     if B > 256:             # chains of 64 rows; a live chain runs both of its half-chains

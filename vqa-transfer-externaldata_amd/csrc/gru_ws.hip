@@ -6,25 +6,29 @@
 // streamed all 12 MB of recurrent weights from the Infinity Cache in every step (its k loops ran at 0.6-0.7 of the
 // matrix rate, profiles/r2_gru_persistent_xcd.txt).  Here nothing but the state moves per step:
 //
-//   * eight chains, one per XCD: chain x = the workgroups with blockIdx.x % 8 == x (dispatched round-robin to XCD x)
-//     owns batch rows [64 x, 64 x + 64) -- rows are independent sequences, so hand-offs and barriers stay inside one
-//     XCD's 32 CUs and one L2;
+//   * eight chains, one per XCD: chain x = the workgroups that RUN on XCD x (ws_place) owns batch rows [64 x, 64 x + 64)
+//     (32 x .. for 256 rows and fewer) -- rows are independent sequences, so hand-offs and flags stay inside one XCD's
+//     32 CUs and one L2;
 //   * CU j of a chain owns the 32 state columns [32 j, 32 j + 32): the matching column slabs of the gate weights
-//     (1024 x 64 floats = 256 KB) live in the REGISTERS of its four waves (one wave per SIMD, 256 of its 512 VGPRs
-//     each: wave w holds the k quarter [256 w, 256 w + 256) as ready-made MFMA B fragments), the candidate slab
-//     (1024 x 32 = 128 KB) lives in LDS in fragment order;
+//     (1024 x 64 floats = 256 KB) live in the REGISTERS of its four waves (one wave per SIMD, 256 of its 512 registers
+//     each: wave w holds the k quarter [256 w, 256 w + 256) as ready-made MFMA B fragments, 224 of them in AGPRs that the
+//     MFMA reads directly), the candidate slab (1024 x 32 = 128 KB) lives in LDS in fragment order;
 //   * per step only the left operand moves: h_{t-1} and r * h_{t-1} of the chain's rows (128 KB each per 32-row
 //     half) are handed from the CUs that produce their columns to all CUs of the XCD in MFMA A-fragment order
 //     ([octet of k][lane][4]: one contiguous 1 KB per wave load, one dwordx4 per lane feeds 4 or 8 MFMAs);
 //   * the four waves split k; their partial tiles meet in LDS (32 KB, XOR-swizzled), every thread finishes one
 //     float4 of the tile (gate math in registers: h, u and the length of its row stay in registers over all steps);
 //   * a chain's 64 rows are two half-chains of 32 rows in ANTI-PHASE on the same waves: G(0,t) G(1,t) C(0,t) C(1,t).
-//     What a sub-phase waits for was produced one sub-phase ago on every CU, so the counter is already there when it
-//     is polled and the first operand fragments are fetched under the previous sub-phase's reduction and epilogue.
+//     What a sub-phase waits for was produced one sub-phase ago on every CU, and the tail of a sub-phase (reduction,
+//     gate math, stores, arrival) runs in the issue slots of the next one's matrix stream (gru_ws_fwd2_kernel; the
+//     plain order -- compute, tail, wait -- is gru_ws_fwd_kernel, used for one half-chain per XCD and as the A/B).
+//   The back-propagation through time (gru_ws_bwd2_kernel) is the same frame with W^T slabs.
 //
-// Hand-off protocol: as gru_persistent.hip (write-through stores, drain, workgroup barrier, one agent-scope atomic
-// per workgroup; consumers poll, barrier, then read).  Every hand-off address is written once per launch (the
-// fragment buffers are indexed by t), so no stale line can sit in an L1.  Spins are bounded and set an error word.
+// Hand-off protocol: every hand-off address is written once per launch (the fragment buffers are indexed by t) with a
+// plain store, so no stale line can sit in an L1 and the line stays in the chain's L2; every storing wave drains its
+// stores, the workgroup barriers, ONE plain 4-byte store raises the workgroup's flag (a 128-byte line of 32 flags per
+// half-chain); consumers load the line with one L1-bypassing request, barrier, then read.  Spins are bounded: a launch
+// whose workgroups cannot all become resident (another process on the GPU) sets an error word instead of hanging.
 #include <stdlib.h>
 
 #include "vqa_common.h"
@@ -104,12 +108,15 @@ __device__ __forceinline__ unsigned ws_flag_load(const unsigned* line) {      //
 __device__ __forceinline__ bool ws_flags_reached(unsigned v, unsigned epoch) {
     return __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;
 }
+// (err = word 512: this launch gave up -- zeroed by every launch; word 1023: some launch on this workspace gave up -- only
+// the host clears it)
 __device__ __forceinline__ void ws_spin(const unsigned* line, unsigned epoch, unsigned* err, unsigned limit) {   // wave 0
     unsigned spins = 0;
     while (!ws_flags_reached(ws_flag_load(line), epoch)) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(err + 511, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // word 1023
             break;
         }
     }
@@ -1137,6 +1144,13 @@ unsigned long long* g_ws_stamps = nullptr;
 
 }  // namespace
 
+namespace {
+// flags, this launch's error word and the placement counters back to zero; word 1023 (the sticky error word) stays
+int ws_reset(unsigned* sync, hipStream_t st) {
+    return hipMemsetAsync(sync, 0, 1023 * sizeof(unsigned), st) == hipSuccess ? VQA_OK : VQA_ERR_LAUNCH;
+}
+}  // namespace
+
 extern "C" int vqa_gru_ws_set_mode(int mode) {
     g_ws_mode = mode < 0 ? 3 : (mode & 3);
     return VQA_OK;
@@ -1166,7 +1180,8 @@ extern "C" int64_t vqa_gru_ws_workspace_bytes(int T) {
 
 // Whole forward recurrence in one launch; same tape contract as vqa_gru_seq_fwd (xp [T,B,3H] read only, hs [T+1,B,H]
 // with hs[0] given, r,u,c,rh [T,B,H]).  `ws`: vqa_gru_ws_workspace_bytes(T) of device memory (contents irrelevant).
-// After the stream has run, a non-zero word at ((unsigned*)ws)[512] reports a barrier time-out (results invalid).
+// After the stream has run, a non-zero word at ((unsigned*)ws)[512] reports a barrier time-out of THIS launch (results
+// invalid); word [1023] is set with it and never cleared by a launch (the caller zeroes it once and may look later).
 extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const float* Wc_h, const int32_t* len, float* hs,
                                   float* r, float* u, float* c, float* rh, int T, int B, int H, void* ws, void* stream) {
     VQA_REQUIRE(xp && Wg_h && Wc_h && len && hs && r && u && c && rh && ws, VQA_ERR_ARG);
@@ -1175,7 +1190,7 @@ extern "C" int vqa_gru_seq_fwd_ws(const float* xp, const float* Wg_h, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     WsArgs a;
     a.sync = static_cast<unsigned*>(ws);
-    if (hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return VQA_ERR_LAUNCH;
+    if (ws_reset(a.sync, st) != VQA_OK) return VQA_ERR_LAUNCH;
     a.hF = static_cast<float*>(ws) + 1024;
     a.rhF = a.hF + (int64_t)(T + 1) * WS_FRAG_T;
     a.xp = xp; a.Wg = Wg_h; a.Wc = Wc_h; a.len = len; a.hs = hs; a.r = r; a.u = u; a.c = c; a.rh = rh;
@@ -1217,7 +1232,7 @@ extern "C" int vqa_gru_seq_bwd_ws(const float* dh_T, const float* d_outs, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     WsBwdArgs a;
     a.sync = static_cast<unsigned*>(ws);
-    if (hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), st) != hipSuccess) return VQA_ERR_LAUNCH;
+    if (ws_reset(a.sync, st) != VQA_OK) return VQA_ERR_LAUNCH;
     a.dcF = static_cast<float*>(ws) + 1024;
     a.drF = a.dcF + (int64_t)T * WS_FRAG_T;
     a.duF = a.drF + (int64_t)T * WS_FRAG_T;

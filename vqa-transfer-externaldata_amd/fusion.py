@@ -334,6 +334,7 @@ class FusionEngine:
         self._p_struct = self._make_struct(self.params, all_required=True)
         self._g_struct = self._make_struct(self.grads, all_required=False)
         self._tensor_cache = {}
+        self._ws_err_word = None
         self._batch_keepalive = None
 
     # ------------------------------------------------------------------ parameters
@@ -435,6 +436,7 @@ class FusionEngine:
             self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
+        self._ws_err_word = None
         for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise", "_keep_word"):
             if hasattr(self, a):
                 delattr(self, a)
@@ -447,6 +449,7 @@ class FusionEngine:
             self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
+        self._ws_err_word = None
 
     # ------------------------------------------------------------------ workspace views
     def tensor(self, name):
@@ -684,12 +687,29 @@ class FusionEngine:
         self._graphs = {}
 
     # ------------------------------------------------------------------ results
+    def check_recurrence(self):
+        """The weight-stationary GRU launches (csrc/gru_ws.hip) need all their 256 workgroups resident at once; if something
+        else keeps CUs from them for seconds (another process computing on the same GPU), their bounded waits give up, set an
+        error word in the workspace and the step's numbers are garbage.  Called wherever results are fetched: raises instead
+        of returning them."""
+        if getattr(self, "_ws_err_word", None) is None:
+            off, n = C.c_int64(), C.c_int64()
+            if self.lib.vqa_fusion_tensor(C.byref(self.dims), b"gru_ws", C.byref(off), C.byref(n)) != 0:
+                self._ws_err_word = False        # this shape has no such buffer
+            else:
+                self._ws_err_word = self.workspace[off.value + 4 * 1023: off.value + 4 * 1024].view(torch.int32)      # the sticky word
+        if self._ws_err_word is not False and int(self._ws_err_word.item()) != 0:
+            raise _lib.VqaHotError("the persistent GRU recurrence timed out waiting for its workgroups (is another process "
+                                   "computing on this GPU?): results of this step are invalid; VQA_HOT_GRU_WS=0 selects the "
+                                   "per-step kernels")
+
     def report(self, global_rows=None, group=None):
         """The 13 report scalars of the reference (vqa/model_vlmap_answer.py:275-288) for the batch this engine
         ran.  Under data parallelism pass global_rows (= sum of the shard sizes): the per-sample statistics are
         summed over the shard, SUM-all-reduced, and the means / guarded ratios are taken over the GLOBAL batch by
         the same kernel -- every rank then reports what one process on the whole batch would."""
         import torch.distributed as dist
+        self.check_recurrence()
         if global_rows is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
             r = self.tensor("report")[:13].cpu().numpy()
         else:
