@@ -334,7 +334,7 @@ class FusionEngine:
         self._p_struct = self._make_struct(self.params, all_required=True)
         self._g_struct = self._make_struct(self.grads, all_required=False)
         self._tensor_cache = {}
-        self._ws_err_word = None
+        self._reset_recurrence_word()
         self._batch_keepalive = None
 
     # ------------------------------------------------------------------ parameters
@@ -436,7 +436,7 @@ class FusionEngine:
             self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
-        self._ws_err_word = None
+        self._reset_recurrence_word()
         for a in ("_keep_att", "_keep_joint", "_keep_joint2", "_keep_tile", "_noise", "_keep_word"):
             if hasattr(self, a):
                 delattr(self, a)
@@ -449,7 +449,7 @@ class FusionEngine:
             self.drop_graphs()
             self.workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
         self._tensor_cache = {}
-        self._ws_err_word = None
+        self._reset_recurrence_word()
 
     # ------------------------------------------------------------------ workspace views
     def tensor(self, name):
@@ -687,17 +687,27 @@ class FusionEngine:
         self._graphs = {}
 
     # ------------------------------------------------------------------ results
+    def _reset_recurrence_word(self):
+        """(re)locates the sticky error word of the weight-stationary GRU launches in the CURRENT workspace layout and
+        zeroes it: a resize moves the buffer over bytes that held something else"""
+        self._ws_err_word = False
+        if getattr(self, "workspace", None) is None or not hasattr(self, "dims"):
+            self._ws_err_word = None
+            return
+        off, n = C.c_int64(), C.c_int64()
+        if self.lib.vqa_fusion_tensor(C.byref(self.dims), b"gru_ws", C.byref(off), C.byref(n)) == 0:
+            self._ws_err_word = self.workspace[off.value + 4 * 1023: off.value + 4 * 1024].view(torch.int32)
+            self._ws_err_word.zero_()
+
     def check_recurrence(self):
         """The weight-stationary GRU launches (csrc/gru_ws.hip) need all their 256 workgroups resident at once; if something
         else keeps CUs from them for seconds (another process computing on the same GPU), their bounded waits give up, set an
         error word in the workspace and the step's numbers are garbage.  Called wherever results are fetched: raises instead
         of returning them."""
         if getattr(self, "_ws_err_word", None) is None:
-            off, n = C.c_int64(), C.c_int64()
-            if self.lib.vqa_fusion_tensor(C.byref(self.dims), b"gru_ws", C.byref(off), C.byref(n)) != 0:
-                self._ws_err_word = False        # this shape has no such buffer
-            else:
-                self._ws_err_word = self.workspace[off.value + 4 * 1023: off.value + 4 * 1024].view(torch.int32)      # the sticky word
+            self._reset_recurrence_word()
+        if self._ws_err_word is None:
+            return
         if self._ws_err_word is not False and int(self._ws_err_word.item()) != 0:
             raise _lib.VqaHotError("the persistent GRU recurrence timed out waiting for its workgroups (is another process "
                                    "computing on this GPU?): results of this step are invalid; VQA_HOT_GRU_WS=0 selects the "
