@@ -717,13 +717,16 @@ extern "C" int vqa_fusion_forward(const vqa_dims_t* dims, const vqa_params_t* P,
     const float* Wc_h = P->gru_wc + W * H;
     {
         ProbeScope ps("gru.fwd", c.st);
-        if (bt->live_rows != nullptr) {          // rows sorted by length: skip finished sequences
-            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
-                                     c.f("gru_c"), c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
-        } else if (gru_ws_on() && vqa_gru_ws_supported((int)T, (int)B, (int)H) == 1) {
+        // (a length-sorted batch whose longest row runs to T: the weight-stationary launch computes every row of every step
+        // under its length mask -- same results -- and is faster than the shrinking per-step kernels at these sizes)
+        const bool ws_ok = gru_ws_on() && (bt->live_rows == nullptr || (T > 0 && bt->live_rows[T - 1] > 0));
+        if (ws_ok && vqa_gru_ws_supported((int)T, (int)B, (int)H) == 1) {
             // one launch, recurrent weights resident in registers and LDS, eight XCD-local chains (csrc/gru_ws.hip)
             TRY(vqa_gru_seq_fwd_ws(xp, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), c.f("gru_rh"),
                                    (int)T, (int)B, (int)H, c.f("gru_ws"), c.st));
+        } else if (bt->live_rows != nullptr) {          // rows sorted by length: skip finished sequences
+            TRY(vqa_gru_seq_fwd_live(xp, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
+                                     c.f("gru_c"), c.f("gru_rh"), (int)T, (int)B, (int)H, c.st));
         } else {                                  // independent row chains in anti-phase (gru_chains)
             float* gr = c.f("gru_r"); float* gu = c.f("gru_u"); float* gc = c.f("gru_c"); float* grh = c.f("gru_rh");
             TRY(run_chains(c, B, [&](int, int64_t row0, int64_t rows, hipStream_t st) {
@@ -1076,12 +1079,13 @@ extern "C" int vqa_fusion_backward_phases(const vqa_dims_t* dims, const vqa_para
     const float* Wc_h = P->gru_wc + W * H;
     {
         ProbeScope ps("gru.bwd", c.st);
-        if (bt->live_rows != nullptr) {
-            TRY(vqa_gru_seq_bwd_live(dh, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
-                                     c.f("gru_c"), dxp, c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
-        } else if (gru_ws_on() && vqa_gru_ws_bwd_supported((int)T, (int)B, (int)H) == 1) {
+        const bool ws_ok = gru_ws_on() && (bt->live_rows == nullptr || (T > 0 && bt->live_rows[T - 1] > 0));
+        if (ws_ok && vqa_gru_ws_bwd_supported((int)T, (int)B, (int)H) == 1) {
             TRY(vqa_gru_seq_bwd_ws(dh, nullptr, Wg_h, Wc_h, bt->q_intseq_len, hs, c.f("gru_r"), c.f("gru_u"), c.f("gru_c"), dxp,
                                    (int)T, (int)B, (int)H, c.f("gru_ws"), c.st));
+        } else if (bt->live_rows != nullptr) {
+            TRY(vqa_gru_seq_bwd_live(dh, Wg_h, Wc_h, bt->q_intseq_len, bt->live_rows, hs, c.f("gru_r"), c.f("gru_u"),
+                                     c.f("gru_c"), dxp, c.f("d_h1"), (int)T, (int)B, (int)H, c.st));
         } else {
             const float* gr = c.f("gru_r"); const float* gu = c.f("gru_u"); const float* gc = c.f("gru_c");
             float* dh1 = c.f("d_h1");
