@@ -783,6 +783,43 @@ def test_weight_stationary_gru_backward_equals_stepwise(T, B, outs):
     assert lib.vqa_gru_seq_bwd_ws(P(dh), None, P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(dxp_b), T, 200, H, P(ws), None) == -4
 
 
+def test_weight_stationary_gru_waits_for_busy_cus_and_still_agrees():
+    """A launch whose 256 workgroups cannot all be placed at once (another stream's kernels hold CUs) waits for them -- its
+    bounded spins are long enough for that -- and computes the same numbers: the forward runs while large matrix products
+    keep a side stream busy, no error word, results equal to the quiet run bit for bit."""
+    import ctypes as C
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
+    T, B, H = 6, 512, 1024
+    if lib.vqa_gru_ws_supported(T, B, H) != 1:
+        pytest.skip("the weight-stationary recurrence does not apply on this device")
+    g = torch.Generator(device="cuda").manual_seed(77)
+    xp = torch.randn(T, B, 3 * H, device="cuda", generator=g) * 0.3
+    Wg = torch.randn(H, 2 * H, device="cuda", generator=g) * 0.04
+    Wc = torch.randn(H, H, device="cuda", generator=g) * 0.04
+    ln = torch.randint(1, T + 1, (B,), dtype=torch.int32, device="cuda", generator=g)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ws = torch.zeros(int(lib.vqa_gru_ws_workspace_bytes(T)) // 4, device="cuda")
+    big = torch.randn(8192, 8192, device="cuda", generator=g)
+    side = torch.cuda.Stream()
+    outs = []
+    for busy in (False, True):
+        hs = torch.zeros(T + 1, B, H, device="cuda")
+        r, u, c, rh = (torch.empty(T, B, H, device="cuda") for _ in range(4))
+        torch.cuda.synchronize()
+        if busy:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    big @ big                      # ~7 ms each: the recurrence's workgroups find the CUs taken
+        _lib.check(lib.vqa_gru_seq_fwd_ws(P(xp), P(Wg), P(Wc), P(ln), P(hs), P(r), P(u), P(c), P(rh), T, B, H, P(ws), None), "ws")
+        torch.cuda.synchronize()
+        words = ws[:1024].view(torch.int32)
+        assert int(words[512]) == 0 and int(words[1023]) == 0
+        outs.append((hs, r, u, c, rh))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_experimental_bf16x3_gemm_is_f32_equivalent():
     """csrc/gemm_bf16x3.hip (experiment, not on the default path): three-way bf16 splits + six bf16 MFMA products per
     a*b.  Its error against float64 must be of the order of the exact-f32 MFMA kernel's own (a few f32 ulps of the
