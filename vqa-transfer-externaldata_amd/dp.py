@@ -68,11 +68,16 @@ def _keep_the_collectives_company(group=None):
     all-reduce kernel is running on some CUs when that launch arrives: the recurrence would wait for the collective to end
     instead of running beside it.  So with more than one rank on RCCL the back-propagation stays on the per-step kernels
     (the forward form, which has no collective beside it, stays on); VQA_HOT_GRU_WS_DP=1 keeps both (unmeasured: no
-    multi-GPU node was available to this build)."""
+    multi-GPU node was available to this build).  Ranks that SHARE a GPU switch the form off altogether."""
     import os
-    if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-            and dist.get_backend(group) == "nccl" and os.environ.get("VQA_HOT_GRU_WS_DP") != "1"):
-        from . import _lib
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    from . import _lib
+    if torch.cuda.is_available() and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > torch.cuda.device_count():
+        # several ranks on ONE GPU (a rehearsal): two of those launches at once would each hold CUs the other needs and
+        # wait for each other until their bounded spins give up -- per-step kernels in both directions
+        _lib.load().vqa_gru_ws_set_mode(0)
+    elif dist.get_backend(group) == "nccl" and os.environ.get("VQA_HOT_GRU_WS_DP") != "1":
         _lib.load().vqa_gru_ws_set_mode(1)
 
 
