@@ -62,7 +62,7 @@ def allreduce_flat_(flat, group=None, bucket_floats=None):
     return flat
 
 
-def _keep_the_collectives_company(group=None):
+def _keep_the_collectives_company(group=None, overlapped=True):
     """The weight-stationary GRU back-propagation (csrc/gru_ws.hip) is one launch of 256 workgroups that must ALL be resident
     (one per CU, 160 KB of LDS each) before any of them gets past its first step.  Under RCCL the first gradient bucket's
     all-reduce kernel is running on some CUs when that launch arrives: the recurrence would wait for the collective to end
@@ -77,7 +77,7 @@ def _keep_the_collectives_company(group=None):
         # several ranks on ONE GPU (a rehearsal): two of those launches at once would each hold CUs the other needs and
         # wait for each other until their bounded spins give up -- per-step kernels in both directions
         _lib.load().vqa_gru_ws_set_mode(0)
-    elif dist.get_backend(group) == "nccl" and os.environ.get("VQA_HOT_GRU_WS_DP") != "1":
+    elif overlapped and dist.get_backend(group) == "nccl" and os.environ.get("VQA_HOT_GRU_WS_DP") != "1":
         _lib.load().vqa_gru_ws_set_mode(1)
 
 
@@ -87,6 +87,7 @@ class GradAllReduce:
     def __init__(self, engine=None, group=None, bucket_floats=None):
         self.group = group
         self.bucket_floats = bucket_floats
+        _keep_the_collectives_company(group, overlapped=False)      # (reduces after backward: only the shared-GPU case matters)
 
     def __call__(self, grad_flat):
         return allreduce_flat_(grad_flat, self.group, self.bucket_floats)
