@@ -301,14 +301,25 @@ def test_gather_from_the_bench_sized_table_is_bit_exact():
     assert torch.equal(V, table[idx]) and torch.equal(nb, nbox[idx])
 
 
-def test_full_size_bs512_forward_matches_oracle_f64():
+@pytest.mark.parametrize("recurrence", ["weight_stationary", "per_step"])
+def test_full_size_bs512_forward_matches_oracle_f64(recurrence):
     """BASELINE config 2 (bs 512, full dims) forward against the float64 oracle: logits within 1e-3
-    (north_star), argmax bit-exact, report scalars, and every trainable gradient (the big-tile GEMM paths)."""
+    (north_star), argmax bit-exact, report scalars, and every trainable gradient (the big-tile GEMM paths) -- with the
+    GRU recurrence as one weight-stationary launch per direction (the shipped path at this size, csrc/gru_ws.hip) and as
+    the per-step kernels (what other shapes, length-sorted batches and RCCL runs use)."""
+    from vqa_transfer_externaldata_amd import _lib
+    lib = _lib.load()
     dims = dict(Vq=4096, W=300, D=2048, H=1024, A=3000)
     B, R, T, N = 512, 36, 14, 256
     p, table, nbox, batch, am, masks = make_case(27, "vlmap_answer", B, R, T, N, dims, full_boxes=True)
     eng = make_engine("vlmap_answer", p, table, nbox, am, B, R, T, dims)
-    run_engine(eng, batch, masks)
+    lib.vqa_gru_ws_set_mode(3 if recurrence == "weight_stationary" else 0)
+    try:
+        if recurrence == "weight_stationary" and lib.vqa_gru_ws_bwd_supported(T, B, dims["H"]) != 1:
+            pytest.skip("the weight-stationary recurrence does not apply on this device")
+        run_engine(eng, batch, masks)
+    finally:
+        lib.vqa_gru_ws_set_mode(-1)
     loss, report, out, mid, tape = O.forward(to64(p), to64(batch), table.astype(np.float64), nbox, to64(am),
                                              to64(masks), "vlmap_answer")
     z = eng.tensor("logit").view(B, dims["A"]).cpu().numpy()
