@@ -145,12 +145,11 @@ if os.environ.get("WS") == "1":
         print("    all streams %.2f us; a gate stream is 256 MFMAs per wave = 16384 cycles, a candidate stream 8192" % (wall[-1] - wall[0]), flush=True)
         print("    prologue (kernel entry -> first stream: placement, weights into registers and LDS, h_0 hand-off), cold caches: %.2f us" % ((raw[2047] - raw[2046]) / 100.0), flush=True)
         sl = stamps[1024:1536].cpu().numpy().astype("int64")
-        if sl.any():        # a -DWS_SLOTS=1 build: cycles per slot of step 5 (a slot = 2 MFMAs in G streams, 1 in C streams)
+        if sl.any():        # a -DWS_SLOTS=n build: shader cycles between every n-th slot of step 5's streams
             for si, nm in enumerate(("G0", "G1", "C0", "C1")):
-                d = np.diff(sl[128 * si: 128 * si + 128])
-                print("    %s slot cycles (slot 1..127; tail micro-step k runs in slot k + 4):" % nm)
-                for r0 in range(0, 127, 16):
-                    print("      %3d: %s" % (r0 + 1, " ".join("%4d" % x for x in d[r0: r0 + 16])))
+                v = sl[128 * si: 128 * si + 128]
+                pos = np.nonzero(v)[0]
+                print("    %s cycles between stamped slots %s: %s" % (nm, pos.tolist(), np.diff(v[pos]).tolist()))
     for rep in range(3):
         print("  forward: stepwise %.1f us   weight-stationary %.1f us" % (tm(fwd), tm(fwd_ws)), flush=True)
     print("  forward from cold caches (median of 10): stepwise %.1f us   weight-stationary %.1f us" % (tm_cold(fwd), tm_cold(fwd_ws)), flush=True)

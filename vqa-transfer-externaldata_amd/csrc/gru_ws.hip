@@ -43,7 +43,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define WS_DBG 0
 #endif
 #ifndef WS_SLOTS
-#define WS_SLOTS 0      // timing study: shader-clock stamp in every slot of step 5's four streams (tools/gru_tune.py WS_SLOTS=1)
+#define WS_SLOTS 0      // timing study: shader-clock stamp in every WS_SLOTS-th slot of step 5's four streams (build with -DWS_SLOTS=16)
 #endif
 
 namespace {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
                 else if (m >= 24) ring[m - 24] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m - 24) * 1024);   \
             }                                                                                                  \
             HOOK(4 * m + i - 4);                                                                               \
-            if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();              \
+            if (WS_SLOTS && ((4 * m + i) % WS_SLOTS) == WS_SLOTS - 1 && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();              \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }                                                                                                      \
     }
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
                     else ring[m % 8] = ws_load2(rs_nxt, (voff_nxt), (base_nxt) + (m + 8 - 32) * 1024);         \
                 }                                                                                              \
                 HOOK(4 * m + i - 4);                                                                           \
-                if (WS_SLOTS && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();          \
+                if (WS_SLOTS && ((4 * m + i) % WS_SLOTS) == WS_SLOTS - 1 && slots != nullptr && t == 5) slots[SLOT_BASE + 4 * m + i] = clock64();          \
                 __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                                  \
         }                                                                                                      \
