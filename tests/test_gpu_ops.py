@@ -670,7 +670,7 @@ def test_persistent_gru_forward_equals_stepwise(T, B, H):
                                           P(outs[0][4]), T, B, 300, P(torch.zeros(64, dtype=torch.int32, device="cuda")), None) == -4
 
 
-@pytest.mark.parametrize("T,B", [(14, 512), (5, 300), (3, 40), (4, 20), (1, 512), (7, 481)])
+@pytest.mark.parametrize("T,B", [(14, 512), (5, 300), (3, 40), (4, 20), (1, 512), (7, 481), (6, 256), (2, 257)])
 def test_weight_stationary_gru_forward_equals_stepwise(T, B):
     """vqa_gru_seq_fwd_ws (csrc/gru_ws.hip: one launch, recurrent weights resident in registers and LDS, eight
     XCD-local chains of two 32-row half-chains in anti-phase) computes the recurrence of the per-step kernels -- hs, r, u,
