@@ -42,6 +42,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WS_DBG
 #define WS_DBG 0
 #endif
+#ifndef WS_EPI_ROWS8
+#define WS_EPI_ROWS8 1
+#endif
 #ifndef WS_SLOTS
 #define WS_SLOTS 0      // timing study: shader-clock stamp in every WS_SLOTS-th slot of step 5's four streams (build with -DWS_SLOTS=16)
 #endif
@@ -215,7 +218,11 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
     }
 
     // ---- this thread's float4 of every 32 x 32 tile: row lane % 32, state columns 32 j + 8 w + 4 (lane / 32) + 0..3
+#if WS_EPI_ROWS8        // (see gru_ws_fwd2_kernel: eight full cache lines per tail load / store)
+    const int e_row = 8 * w + (lane >> 3), e_col = 4 * (lane & 7);
+#else
     const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
+#endif
     const int64_t BH = (int64_t)B * H;
     const __amdgpu_buffer_rsrc_t rs_hF = ws_rs(a.hF, (int64_t)(T + 1) * WS_FRAG_T * 4);
     const __amdgpu_buffer_rsrc_t rs_rhF = ws_rs(a.rhF, (int64_t)T * WS_FRAG_T * 4);
@@ -225,7 +232,13 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd_kernel(WsArgs a) {
     const __amdgpu_buffer_rsrc_t rs_c = ws_rs(a.c, T * BH * 4), rs_rh = ws_rs(a.rh, T * BH * 4);
     // fragment buffer offsets (bytes): operand loads of this wave's k quarter, and this thread's hand-off store
     auto frag_ld = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 32 * w) * 1024 + lane * 16); };
+#if WS_EPI_ROWS8
+    auto frag_st = [&](int t, int hf) {
+        return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + (e_col >> 3)) * 1024 + (((e_col >> 2) & 1) * 32 + e_row) * 16);
+    };
+#else
     auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + w) * 1024 + lane * 16); };
+#endif
 
     f32x4n h_own[2], u_own[2];
     int len_own[2];
@@ -482,7 +495,14 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
         for (int n = 0; n < 16; ++n) *reinterpret_cast<f32x4n*>(Wl + (tid + (16 * half + n) * WS_NT) * 4) = tmp[n];
     }
 
+    // A thread's float4 of every 32 x 32 tile.  WS_EPI_ROWS8: row 8 w + lane / 8, columns 4 (lane % 8): a wave's tail loads and
+    // stores then cover 8 rows x 128 bytes = eight FULL cache lines per instruction (tape stores, xp loads) and the hand-off
+    // store eight full 128-byte pieces of the fragment buffer, instead of 32 rows x 32 bytes of 32 different lines.
+#if WS_EPI_ROWS8
+    const int e_row = 8 * w + (lane >> 3), e_col = 4 * (lane & 7);
+#else
     const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
+#endif
     const int64_t BH = (int64_t)B * H;
     const __amdgpu_buffer_rsrc_t rs_hF = ws_rs(a.hF, (int64_t)(T + 1) * WS_FRAG_T * 4);
     const __amdgpu_buffer_rsrc_t rs_rhF = ws_rs(a.rhF, (int64_t)T * WS_FRAG_T * 4);
@@ -492,7 +512,14 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
     const __amdgpu_buffer_rsrc_t rs_c = ws_rs(a.c, T * BH * 4), rs_rh = ws_rs(a.rh, T * BH * 4);
     // fragment buffers: uniform (scalar) part of the offsets; the per-lane part is lane * 16
     auto frag_ld = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 32 * w) * 1024); };
+#if WS_EPI_ROWS8
+    // this thread's columns 32 j + e_col .. + 3 = octet 4 j + e_col / 8, k half (e_col / 4) % 2 of the fragment order
+    auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j) * 1024); };
+    const unsigned frag_v = (unsigned)((e_col >> 3) * 1024 + ((((e_col >> 2) & 1) * 32 + e_row) * 16));
+#else
     auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + w) * 1024); };
+    const unsigned frag_v = (unsigned)lane * 16u;
+#endif
     const unsigned lane16 = (unsigned)lane * 16u;
 
     f32x4n h_own[2], u_own[2];
@@ -509,12 +536,12 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
         h_own[hf] = ws_load(rs_hs, o_std[hf]);
         u_own[hf] = (f32x4n)(0.f);
         len_own[hf] = ok[hf] ? a.len[grow] : 0;
-        ws_store2(rs_hF, lane16, frag_st(0, hf), h_own[hf], a.handoff_sc1 != 0);
+        ws_store2(rs_hF, frag_v, frag_st(0, hf), h_own[hf], a.handoff_sc1 != 0);
     }
     __syncthreads();
     ws_arrive(ctr0, j, 1u);
     ws_arrive(ctr1, j, 1u);
-    const unsigned lane16_st = (a.dbg & 2) ? 0xFFFFFFF0u : (unsigned)lane * 16u;
+    const unsigned lane16_st = (a.dbg & 2) ? 0xFFFFFFF0u : frag_v;
     if (a.dbg & 1) { o_std[0] = 0xFFFFFFF0u; o_std[1] = 0xFFFFFFF0u; }
     if (a.dbg & 4) { o_xp[0] = 0xFFFFFFF0u; o_xp[1] = 0xFFFFFFF0u; }
 
@@ -850,7 +877,11 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         for (int n = 0; n < 32; ++n) *reinterpret_cast<f32x4n*>(Wl + (tid + n * WS_NT) * 4) = tmp[n];
     }
 
+#if WS_EPI_ROWS8        // (see gru_ws_fwd2_kernel: eight full cache lines per tail load / store)
+    const int e_row = 8 * w + (lane >> 3), e_col = 4 * (lane & 7);
+#else
     const int e_row = lane & 31, e_col = 8 * w + 4 * (lane >> 5);
+#endif
     const int64_t BH = (int64_t)B * H;
     const __amdgpu_buffer_rsrc_t rs_dcF = ws_rs(a.dcF, (int64_t)T * WS_FRAG_T * 4);
     const __amdgpu_buffer_rsrc_t rs_drF = ws_rs(a.drF, (int64_t)T * WS_FRAG_T * 4);
@@ -864,7 +895,13 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
     // fragment buffers: scalar parts of the offsets (the per-lane part is lane * 16)
     auto frag_a = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 32 * w) * 1024); };          // A stream: 32 octets
     auto frag_b = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 64 * (w & 1)) * 1024); };    // B stream: 64 octets
+#if WS_EPI_ROWS8
+    auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j) * 1024); };
+    const unsigned frag_v = (unsigned)((e_col >> 3) * 1024 + ((((e_col >> 2) & 1) * 32 + e_row) * 16));
+#else
     auto frag_st = [&](int t, int hf) { return (unsigned)((((t * 8 + chain) * 2 + hf) * 128 + 4 * j + w) * 1024); };
+    const unsigned frag_v = (unsigned)lane * 16u;
+#endif
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned bh_step = (unsigned)(BH * 4), xp_step = (unsigned)((int64_t)B * 3 * H * 4);
 
@@ -911,8 +948,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         half_step(t, hf, g, uv, cv, hp, dc, du);
         ws_store2(rs_dxp, o_xp[hf], (unsigned)t * xp_step + 2 * H * 4, dc, false);
         ws_store2(rs_dxp, o_xp[hf], (unsigned)t * xp_step + H * 4, du, false);
-        ws_store2(rs_duF, lane16, frag_st(t, hf), du, false);
-        ws_store2(rs_dcF, lane16, frag_st(t, hf), dc, false);
+        ws_store2(rs_duF, frag_v, frag_st(t, hf), du, false);
+        ws_store2(rs_dcF, frag_v, frag_st(t, hf), dc, false);
         tr[hf] = ws_load2(rs_r, o_std[hf], (unsigned)t * bh_step);
     }
     __syncthreads();                    // the W_c^T slab is in LDS
@@ -956,7 +993,7 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
             vb = va * hp_own[hf] * tr[hf] * ((f32x4n)(1.f) - tr[hf]);           // dr_pre
         }
         if (k == 33) ws_store2(rs_dxp, o_xp[hf], ws_uni((unsigned)t * xp_step), vb, false);
-        if (k == 39) ws_store2(rs_drF, lane16, ws_uni(frag_st(t, hf)), vb, false);
+        if (k == 39) ws_store2(rs_drF, frag_v, ws_uni(frag_st(t, hf)), vb, false);
         if (k == 54) {
             asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
             ws_flag_store(ctr, j, epoch);
@@ -972,8 +1009,8 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
         if (k == 17 && live) half_step(t - 1, hf, va, tu[hf], tc[hf], th[hf], va, vb);      // va = dc_pre, vb = du_pre afterwards
         if (k == 33) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + 2 * H * 4), va, false);
         if (k == 35) ws_store2(rs_dxp, live ? o_xp[hf] : OOB, ws_uni((unsigned)(t - 1) * xp_step + H * 4), vb, false);
-        if (k == 37) ws_store2(rs_duF, live ? lane16 : OOB, ws_uni(frag_st(t - 1, hf)), vb, false);
-        if (k == 39) ws_store2(rs_dcF, live ? lane16 : OOB, ws_uni(frag_st(t - 1, hf)), va, false);
+        if (k == 37) ws_store2(rs_duF, live ? frag_v : OOB, ws_uni(frag_st(t - 1, hf)), vb, false);
+        if (k == 39) ws_store2(rs_dcF, live ? frag_v : OOB, ws_uni(frag_st(t - 1, hf)), va, false);
         if (k == 54) {
             asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
             if (live) ws_flag_store(ctr, j, epoch);
