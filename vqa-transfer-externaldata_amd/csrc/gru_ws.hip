@@ -42,6 +42,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WS_DBG
 #define WS_DBG 0
 #endif
+#ifndef WS_TOPUP_SPREAD
+#define WS_TOPUP_SPREAD 1   // a gate stream's fragments 8..15: one per octet over its first eight octets instead of a burst on entry
+#endif
 #ifndef WS_EPI_ROWS8
 #define WS_EPI_ROWS8 1
 #endif
@@ -686,9 +689,12 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_fwd2_kernel(WsArgs a) {
     /* 16 fragments ahead inside a gate stream (xp loads -- Infinity Cache or HBM, returned in order with the  */ \
     /* fragments -- are issued at its head: 16 octets of 512 cycles are their cover); every stream hands the   */ \
     /* next one 8 fragments, so a gate stream fetches its fragments 8..15 on entry                              */ \
-    _Pragma("unroll") for (int f = 8; f < 16; ++f) ring[f] = ws_load2(rs_cur, lane16, (base_cur) + f * 1024);  \
+    if (!WS_TOPUP_SPREAD) {                                                                                    \
+        _Pragma("unroll") for (int f = 8; f < 16; ++f) ring[f] = ws_load2(rs_cur, lane16, (base_cur) + f * 1024); \
+    }                                                                                                          \
     _Pragma("unroll") for (int m = 0; m < 32; ++m) {                                                           \
         const f32x4n av = ring[m % 16];                                                                        \
+        if (WS_TOPUP_SPREAD && m < 8) ring[8 + m] = ws_load2(rs_cur, lane16, (base_cur) + (8 + m) * 1024);     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
             if (m == 0 && i == 0) {                                                                            \
                 WS_MFMA_AGPR_B0(accR, av[i], wg[0][m][i]);                                                     \
