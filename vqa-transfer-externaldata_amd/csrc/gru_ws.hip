@@ -1063,11 +1063,12 @@ __global__ __launch_bounds__(WS_NT, 1) void gru_ws_bwd2_kernel(WsBwdArgs a) {
     // B stream: 16 fragments ahead.  TOPUP: entered from an A stream, whose ring left fragments 0..7 -- fetch 8..15 now.
     // NEXT_A: followed by an A stream -- only its fragments 0..7 are fetched at the end (ring slots 0..7).
 #define WS_B_STREAM(accA, accB, base_cur, TOPUP, NEXT_A, rs_nxt, base_nxt, voff_nxt, HOOK)                     \
-    if (TOPUP) {                                                                                               \
+    if ((TOPUP) && !WS_TOPUP_SPREAD) {                                                                         \
         _Pragma("unroll") for (int f = 8; f < 16; ++f) ring[f] = ws_load2(rs_bF, lane16, (base_cur) + f * 1024); \
     }                                                                                                          \
     _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                           \
         const f32x4n av = ring[m % 16];                                                                        \
+        if ((TOPUP) && WS_TOPUP_SPREAD && m < 8) ring[8 + m] = ws_load2(rs_bF, lane16, (base_cur) + (8 + m) * 1024); \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
             if (m < 2) {                                                                                       \
                 if (i == 0) { if (m == 0) WS_MFMA_AGPR_B0(accA, av[i], wq[m][i]); else WS_MFMA_AGPR_B0(accB, av[i], wq[m][i]); } \
